@@ -1,0 +1,187 @@
+/*
+ * moge_hip.h - C ABI of libmoge_hip.so: the MI355X-native (gfx950) implementation of the
+ * microsoft/MoGe `moge.model.v2.MoGeModel.infer()` hot path.
+ *
+ * Plain C, plain pointers and sizes, no torch types.  Every entry point names the reference interface it
+ * replaces (paths relative to the reference checkout).  The Python host (moge_amd/model/v2.py) binds these
+ * with ctypes and mirrors the reference's MoGeModel surface on top; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - all functions return 0 on success, a negative moge_status otherwise; moge_last_error() gives the text
+ *   - device pointers are raw HIP device addresses in the calling process (e.g. torch.Tensor.data_ptr())
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on it
+ *   - a handle is bound to one device and is not thread-safe; different handles are independent
+ */
+#ifndef MOGE_HIP_H
+#define MOGE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOGE_ABI_VERSION 1
+#define MOGE_MAX_TAPS 8
+#define MOGE_LEVELS 5
+
+typedef enum moge_status {
+    MOGE_OK = 0,
+    MOGE_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+    MOGE_ERR_HIP = -2,          /* a HIP runtime call failed */
+    MOGE_ERR_NOT_LOADED = -3,   /* weights missing */
+    MOGE_ERR_MISSING_KEY = -4,  /* a state-dict tensor the config requires was not supplied */
+    MOGE_ERR_NONFINITE = -5     /* focal/shift solve saw non-finite residuals at x0 (scipy raises ValueError) */
+} moge_status;
+
+typedef enum moge_precision {
+    MOGE_FP32 = 0,   /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity mode */
+    MOGE_FP16 = 1    /* fp16 storage, fp32 accumulate (v_mfma_f32_32x32x16_f16): the throughput mode */
+} moge_precision;
+
+typedef enum moge_remap { MOGE_REMAP_LINEAR = 0, MOGE_REMAP_SINH = 1, MOGE_REMAP_EXP = 2, MOGE_REMAP_SINH_EXP = 3 } moge_remap;
+
+/* heads-present bitmask */
+#define MOGE_HEAD_POINTS 1
+#define MOGE_HEAD_NORMAL 2
+#define MOGE_HEAD_MASK   4
+#define MOGE_HEAD_SCALE  8
+
+/* Mirrors the checkpoint's `model_config` (moge/model/v2.py:29-56, configs/train/v2.json:238-285).
+ * Only the released MoGe-2 layout is supported: 5 levels, resamplers [conv_transpose x3, bilinear],
+ * res-block norms "none", ReLU, replicate padding. */
+typedef struct moge_config {
+    int32_t embed_dim;                 /* ViT width D (384 / 768 / 1024)            vision_transformer.py:351-390 */
+    int32_t depth;                     /* ViT blocks                                                               */
+    int32_t num_heads;                 /* head_dim must be 64                                                      */
+    int32_t n_taps;                    /* len(intermediate_layers)                  modules.py:82                  */
+    int32_t taps[MOGE_MAX_TAPS];       /* block indices whose output is tapped                                     */
+    int32_t dims[MOGE_LEVELS];         /* dim_res_blocks (dims[0] == encoder dim_out)                              */
+    int32_t neck_res_blocks[MOGE_LEVELS];
+    int32_t head_res_blocks[MOGE_LEVELS];
+    int32_t heads;                     /* MOGE_HEAD_* bitmask                                                      */
+    int32_t scale_hidden;              /* scale_head dims = [D, scale_hidden, scale_hidden, 1]                     */
+    int32_t remap_output;              /* moge_remap                                v2.py:122-136                  */
+} moge_config;
+
+/* One state-dict entry handed to moge_load_weights: fp32, contiguous, host memory. */
+typedef struct moge_tensor_desc {
+    const char* name;                  /* reference state-dict key, e.g. "encoder.backbone.blocks.0.attn.qkv.weight" */
+    const float* data;
+    int64_t numel;
+} moge_tensor_desc;
+
+/* Device output buffers of one call, owned by the caller (NULL = not wanted / head absent). */
+typedef struct moge_outputs {
+    float* points;        /* (B,H,W,3) */
+    float* depth;         /* (B,H,W)   infer only */
+    float* normal;        /* (B,H,W,3) */
+    float* mask_prob;     /* (B,H,W)   forward: sigmoid probability */
+    uint8_t* mask;        /* (B,H,W)   infer: validity mask, 0/1 */
+    float* intrinsics;    /* (B,3,3)   infer only */
+    float* metric_scale;  /* (B,)      */
+    float* focal;         /* (B,) optional: recovered focal (relative to half diagonal) */
+    float* shift;         /* (B,) optional: recovered z shift */
+} moge_outputs;
+
+/* infer flags (v2.py:199-201) */
+#define MOGE_FORCE_PROJECTION 1
+#define MOGE_APPLY_MASK 2
+
+typedef struct moge_handle moge_handle;
+
+/* Kernel classes for the built-in HIP-event profiler (bench.py roofline). */
+enum { MOGE_KC_GEMM = 0, MOGE_KC_ATTN = 1, MOGE_KC_CONV = 2, MOGE_KC_NORM = 3, MOGE_KC_PRE = 4, MOGE_KC_POST = 5,
+       MOGE_KC_RECOVER = 6, MOGE_KC_COUNT = 7 };
+typedef struct moge_profile {
+    double ms[MOGE_KC_COUNT];        /* summed kernel time per class (HIP events on the launch stream) */
+    double flops[MOGE_KC_COUNT];     /* algorithmic FLOPs (2*MAC) launched per class */
+    double bytes[MOGE_KC_COUNT];     /* algorithmic HBM bytes (compulsory reads+writes) per class */
+    int64_t launches[MOGE_KC_COUNT];
+} moge_profile;
+
+int moge_abi_version(void);
+const char* moge_last_error(void);
+
+/* replaces MoGeModel.__init__ (v2.py:30-57): build the model skeleton for `cfg` on HIP device `device`. */
+int moge_create(const moge_config* cfg, int device, moge_handle** out);
+void moge_destroy(moge_handle* h);
+
+/* replaces nn.Module.load_state_dict (v2.py:105): upload the fp32 master copy of every tensor the config
+ * needs.  Unknown names are ignored (strict=False); a missing required tensor -> MOGE_ERR_MISSING_KEY. */
+int moge_load_weights(moge_handle* h, const moge_tensor_desc* descs, int n, void* stream);
+
+/* Multi-GPU weight distribution: the fp32 master blob is one contiguous device buffer whose
+ * layout depends on the config only.  Rank 0 loads it with moge_load_weights; other ranks call
+ * moge_alloc_master, receive the bytes with an RCCL broadcast into the returned pointer (the host does that
+ * with torch.distributed), then call moge_master_ready. */
+int moge_alloc_master(moge_handle* h);
+int moge_master_blob(moge_handle* h, void** dev_ptr, size_t* bytes);
+int moge_master_ready(moge_handle* h);
+
+/* replaces nn.Module.half()/.float() (scripts/infer.py:82-84): select the compute precision.  Packs the
+ * kernel-layout weight set for that precision on first use (both sets may stay resident). */
+int moge_set_precision(moge_handle* h, int precision, void* stream);
+
+/* bytes of device workspace a call with these shapes needs (grown lazily by forward/infer). */
+int moge_workspace_bytes(moge_handle* h, int B, int H, int W, int token_rows, int token_cols, size_t* bytes);
+
+/* replaces MoGeModel.forward (v2.py:138-192).  image: device, (B,3,H,W), fp32 (img_dtype 0) or fp16 (1),
+ * values in [0,1].  token_rows/cols = base_h/base_w computed by the host exactly as v2.py:142-147.
+ * Writes points (remapped), normal (unit), mask_prob, metric_scale. */
+int moge_forward(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int token_rows, int token_cols,
+                 const moge_outputs* out, void* stream);
+
+/* replaces MoGeModel.infer (v2.py:194-303) after the host has resolved num_tokens: forward + focal/shift
+ * recovery (geometry_torch.py:115-170; MINPACK lmdif in fp64 on device) + intrinsics + re-projection +
+ * metric scale + masking.  fov_x_deg: NULL, or device pointer to B floats (degrees). */
+int moge_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int token_rows, int token_cols,
+               const float* fov_x_deg, int flags, const moge_outputs* out, void* stream);
+
+/* replaces the post-processing half of infer (v2.py:246-289) on caller-supplied forward outputs: used to
+ * test the recovery path in isolation.  points/normal/mask_prob are read; all outputs written. */
+int moge_postprocess(moge_handle* h, const float* points_in, const float* normal_in, const float* mask_prob_in,
+                     const float* metric_scale_in, int B, int H, int W, const float* fov_x_deg, int flags,
+                     const moge_outputs* out, void* stream);
+
+/* Synchronise `stream` and report the sticky device-side status of the calls since the last sync
+ * (MOGE_ERR_NONFINITE if a recovery solve saw non-finite residuals). */
+int moge_sync(moge_handle* h, void* stream);
+
+/* HIP-event profiler: when enabled every kernel launch is bracketed by events on its stream. */
+int moge_profile_enable(moge_handle* h, int on);
+int moge_profile_read(moge_handle* h, moge_profile* out, int reset);   /* synchronises pending events */
+
+/* Debug taps for stage-level parity: copy an internal activation of the LAST forward to a caller buffer as
+ * fp32.  name: "tokens0", "tap<k>", "cls", "features", "neck<l>", "head_<points|normal|mask>_x4".
+ * Layout is the library's own (token-major / NHWC); *numel receives the element count. */
+int moge_debug_tap(moge_handle* h, const char* name, float* dst, int64_t dst_capacity, int64_t* numel, void* stream);
+
+/* ---- per-kernel test entry points (stage-level parity; tests/ only) -------------------------------- */
+/* C[M,N] = A[M,K] * W[N,K]^T + bias, fp32 in/out on device; computed in `precision`. act: 0 none 1 relu 2 gelu */
+int moge_test_gemm(int precision, const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
+                   int act, void* stream);
+/* LayerNorm rows of x[rows, D], eps 1e-6 */
+int moge_test_layernorm(int precision, const float* x, const float* w, const float* b, float* y, int rows, int D, void* stream);
+/* softmax(q k^T / 8) v for q,k,v (B,nh,N,64) fp32 -> o (B,N,nh*64) */
+int moge_test_attention(int precision, const float* q, const float* k, const float* v, float* o, int B, int nh, int N, void* stream);
+/* 3x3 replicate-padded conv, NHWC: x (B,H,W,Cin), w (Cout,Cin,3,3) torch layout, y (B,H,W,Cout); relu_in applies ReLU to x */
+int moge_test_conv3x3(int precision, const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
+                      int Cin, int Cout, int relu_in, void* stream);
+/* ConvTranspose2d k2 s2, NHWC: x (B,H,W,Cin), w (Cin,Cout,2,2) torch layout, y (B,2H,2W,Cout) */
+int moge_test_convt2x2(int precision, const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
+                       int Cin, int Cout, void* stream);
+/* image (B,3,H,W) fp32 -> antialiased bilinear resize to (14*rows,14*cols), normalised, NCHW fp32 */
+int moge_test_preprocess(const float* image, float* out, int B, int H, int W, int rows, int cols, void* stream);
+/* pos_embed (1+37*37, D) -> (1+rows*cols, D) bicubic with the +0.1 kludge */
+int moge_test_posembed(const float* pos, float* out, int D, int rows, int cols, void* stream);
+/* focal/shift solve on (B,H,W,3) points + (B,H,W) 0/1 mask; focal_in NULL or (B,) */
+int moge_test_recover(const float* points, const uint8_t* mask, const float* focal_in, int B, int H, int W,
+                      float* focal, float* shift, int32_t* status, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOGE_HIP_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of libmoge_hip.so (include/moge_hip.h).  The product path: there is NO fallback - if the HIP
+library is missing or does not load, importing this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: libmoge_hip.so binds to the libamdhip64.so.7 torch has loaded)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libmoge_hip.so")
+
+MOGE_MAX_TAPS = 8
+MOGE_LEVELS = 5
+FP32, FP16 = 0, 1
+HEAD_POINTS, HEAD_NORMAL, HEAD_MASK, HEAD_SCALE = 1, 2, 4, 8
+FORCE_PROJECTION, APPLY_MASK = 1, 2
+REMAP = {"linear": 0, "sinh": 1, "exp": 2, "sinh_exp": 3}
+ERR_NONFINITE = -5
+KC_NAMES = ["gemm", "attn", "conv", "norm", "pre", "post", "recover"]
+
+
+class MogeConfig(C.Structure):
+    _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32), ("n_taps", C.c_int32),
+                ("taps", C.c_int32 * MOGE_MAX_TAPS), ("dims", C.c_int32 * MOGE_LEVELS),
+                ("neck_res_blocks", C.c_int32 * MOGE_LEVELS), ("head_res_blocks", C.c_int32 * MOGE_LEVELS),
+                ("heads", C.c_int32), ("scale_hidden", C.c_int32), ("remap_output", C.c_int32)]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("points", C.c_void_p), ("depth", C.c_void_p), ("normal", C.c_void_p), ("mask_prob", C.c_void_p),
+                ("mask", C.c_void_p), ("intrinsics", C.c_void_p), ("metric_scale", C.c_void_p),
+                ("focal", C.c_void_p), ("shift", C.c_void_p)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * 7), ("flops", C.c_double * 7), ("bytes", C.c_double * 7), ("launches", C.c_int64 * 7)]
+
+
+class MogeError(RuntimeError):
+    pass
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m moge_amd.build` (hipcc, gfx950). "
+                          "moge_amd has no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.c_void_p
+    sig = {
+        "moge_abi_version": (C.c_int, []),
+        "moge_last_error": (C.c_char_p, []),
+        "moge_create": (C.c_int, [C.POINTER(MogeConfig), i32, C.POINTER(vp)]),
+        "moge_destroy": (None, [vp]),
+        "moge_load_weights": (C.c_int, [vp, C.POINTER(TensorDesc), i32, vp]),
+        "moge_alloc_master": (C.c_int, [vp]),
+        "moge_master_blob": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "moge_master_ready": (C.c_int, [vp]),
+        "moge_set_precision": (C.c_int, [vp, i32, vp]),
+        "moge_workspace_bytes": (C.c_int, [vp, i32, i32, i32, i32, i32, C.POINTER(C.c_size_t)]),
+        "moge_forward": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(Outputs), vp]),
+        "moge_infer": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, C.POINTER(Outputs), vp]),
+        "moge_postprocess": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, C.POINTER(Outputs), vp]),
+        "moge_sync": (C.c_int, [vp, vp]),
+        "moge_profile_enable": (C.c_int, [vp, i32]),
+        "moge_profile_read": (C.c_int, [vp, C.POINTER(Profile), i32]),
+        "moge_debug_tap": (C.c_int, [vp, C.c_char_p, vp, i64, C.POINTER(i64), vp]),
+        "moge_test_gemm": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, vp]),
+        "moge_test_layernorm": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, vp]),
+        "moge_test_attention": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, vp]),
+        "moge_test_conv3x3": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, vp]),
+        "moge_test_convt2x2": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, vp]),
+        "moge_test_preprocess": (C.c_int, [f32p, f32p, i32, i32, i32, i32, i32, vp]),
+        "moge_test_posembed": (C.c_int, [f32p, f32p, i32, i32, i32, vp]),
+        "moge_test_recover": (C.c_int, [f32p, vp, f32p, i32, i32, i32, f32p, f32p, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    if lib.moge_abi_version() != 1:
+        raise ImportError("libmoge_hip.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+EXPORTS = ["moge_abi_version", "moge_last_error", "moge_create", "moge_destroy", "moge_load_weights", "moge_alloc_master",
+           "moge_master_blob", "moge_master_ready", "moge_set_precision", "moge_workspace_bytes", "moge_forward", "moge_infer",
+           "moge_postprocess", "moge_sync", "moge_profile_enable", "moge_profile_read", "moge_debug_tap", "moge_test_gemm",
+           "moge_test_layernorm", "moge_test_attention", "moge_test_conv3x3", "moge_test_convt2x2", "moge_test_preprocess",
+           "moge_test_posembed", "moge_test_recover"]
+
+
+def check(code: int) -> None:
+    if code == 0:
+        return
+    msg = (lib.moge_last_error() or b"").decode(errors="replace")
+    if code == ERR_NONFINITE:
+        raise ValueError(msg or "Residuals are not finite in the initial point.")      # what scipy raises in the reference
+    raise MogeError(f"libmoge_hip error {code}: {msg}")
+
+
+def stream_ptr(device=None) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+class DevView:
+    """Zero-copy torch view of a raw device buffer (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2, "strides": None}

@@ -1,0 +1,160 @@
+// Shared device/host definitions for libmoge_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef _Float16 f16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// --------------------------------------------------------------------------------------------
+// Storage-type traits.  Everything matrix-shaped moves in 16-byte "chunks" along the contraction
+// axis: 8 halves or 4 floats.  One "k-step" of the 32x32 MFMA consumes two chunks (lane half hi = lane>>5
+// takes chunk 2*s+hi), which is ONE v_mfma_f32_32x32x16_f16 or FOUR v_mfma_f32_32x32x2_f32.
+// C/D layout of both: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5), r in [0,16).
+// --------------------------------------------------------------------------------------------
+template <typename T> struct TT;
+template <> struct TT<f16> {
+    static constexpr int CH = 8;            // elements per 16-byte chunk
+    static constexpr int PREC = 1;
+};
+template <> struct TT<float> {
+    static constexpr int CH = 4;
+    static constexpr int PREC = 0;
+};
+
+template <typename T>
+__device__ __forceinline__ void mma_step(f32x16& acc, const u32x4& a, const u32x4& b);
+template <>
+__device__ __forceinline__ void mma_step<f16>(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_step<float>(f32x16& acc, const u32x4& a, const u32x4& b) {
+    const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], acc, 0, 0, 0);
+}
+
+// row of the 32x32 accumulator tile held in register r by a lane of half `hi`
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// convert 4 floats to storage type and store (8 B for f16, 16 B for f32); dst 8/16-byte aligned
+__device__ __forceinline__ void store4(f16* dst, float a, float b, float c, float d) {
+    f16x4 v = {(f16)a, (f16)b, (f16)c, (f16)d};
+    *reinterpret_cast<f16x4*>(dst) = v;
+}
+__device__ __forceinline__ void store4(float* dst, float a, float b, float c, float d) {
+    f32x4 v = {a, b, c, d};
+    *reinterpret_cast<f32x4*>(dst) = v;
+}
+__device__ __forceinline__ void load4(const f16* src, float* o) {
+    f16x4 v = *reinterpret_cast<const f16x4*>(src);
+    o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+}
+__device__ __forceinline__ void load4(const float* src, float* o) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+
+// elementwise ReLU on a 16-byte chunk of storage type T
+template <typename T> __device__ __forceinline__ u32x4 relu_chunk(u32x4 v);
+template <> __device__ __forceinline__ u32x4 relu_chunk<f16>(u32x4 v) {
+    f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = h[i] > (f16)0 ? h[i] : (f16)0;
+    return __builtin_bit_cast(u32x4, h);
+}
+template <> __device__ __forceinline__ u32x4 relu_chunk<float>(u32x4 v) {
+    f32x4 h = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+    for (int i = 0; i < 4; i++) h[i] = fmaxf(h[i], 0.f);
+    return __builtin_bit_cast(u32x4, h);
+}
+
+// a*wa + b*wb + c*wc + d*wd on 16-byte chunks (fp32 math), used by the fused bilinear x2 loader
+template <typename T> __device__ __forceinline__ u32x4 blend4_chunk(u32x4 a, u32x4 b, u32x4 c, u32x4 d, float wa, float wb, float wc, float wd);
+template <> __device__ __forceinline__ u32x4 blend4_chunk<f16>(u32x4 a, u32x4 b, u32x4 c, u32x4 d, float wa, float wb, float wc, float wd) {
+    f16x8 x = __builtin_bit_cast(f16x8, a), y = __builtin_bit_cast(f16x8, b), z = __builtin_bit_cast(f16x8, c), w = __builtin_bit_cast(f16x8, d), o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = (f16)((float)x[i] * wa + (float)y[i] * wb + (float)z[i] * wc + (float)w[i] * wd);
+    return __builtin_bit_cast(u32x4, o);
+}
+template <> __device__ __forceinline__ u32x4 blend4_chunk<float>(u32x4 a, u32x4 b, u32x4 c, u32x4 d, float wa, float wb, float wc, float wd) {
+    f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b), z = __builtin_bit_cast(f32x4, c), w = __builtin_bit_cast(f32x4, d), o;
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = x[i] * wa + y[i] * wb + z[i] * wc + w[i] * wd;
+    return __builtin_bit_cast(u32x4, o);
+}
+
+// LDS swizzle of the chunk index inside a tile row.  CPR = chunks per row (8 -> 128-byte rows, 16 -> 256-byte rows).
+// ds_read_b128 is served in 16-lane groups over a 256-byte bank row: with these XORs the 16 lanes of a group
+// (16 different rows, same logical chunk) hit 16 distinct 16-byte slots.
+template <int CPR> __device__ __forceinline__ int swz(int row, int c);
+template <> __device__ __forceinline__ int swz<8>(int row, int c) { return c ^ ((row >> 1) & 7); }
+template <> __device__ __forceinline__ int swz<16>(int row, int c) { return c ^ (row & 15); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// torch.linspace(start, end, steps) element i in fp32 (ATen: symmetric evaluation around the middle)
+__device__ __forceinline__ float linspace_at(float start, float end, float step, int steps, int i) {
+    return (i < steps / 2) ? (start + step * (float)i) : (end - step * (float)(steps - 1 - i));
+}
+
+// --------------------------------------------------------------------------------------------
+// GEMM / implicit-GEMM conv argument blocks (see gemm.hip)
+// --------------------------------------------------------------------------------------------
+enum { AMODE_LINEAR = 0, AMODE_CONV3 = 1, AMODE_CONV3_UP2 = 2 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_PATCH = 2, EPI_QKV = 3, EPI_CONVT = 4 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+
+struct UVTerm {            // out[n] += wu[n]*u(x) + wv[n]*v(y): the 1x1 conv of the (u,v) planes (v2.py:154-160)
+    const float* wu;       // null -> disabled
+    const float* wv;
+    float u0, u1, ustep, v0, v1, vstep;
+};
+
+struct GemmArgs {
+    // A operand (activations)
+    const void* a;
+    int lda;               // LINEAR: row stride in elements
+    int H, W, C;           // CONV3*: OUTPUT spatial dims (= input dims, or 2x input dims for UP2) and input channels
+    int relu_in;           // apply ReLU to A on load
+    // W operand: [N][ldw] storage type, K-contiguous
+    const void* w;
+    int ldw;
+    int M, N, K;           // K in elements (multiple of the chunk size)
+    // epilogue
+    int epi;
+    int act;
+    const float* bias;     // [N] fp32 or null
+    void* out;             // storage type (EPI_STORE / EPI_CONVT)
+    int ldc;
+    const void* add;       // storage type, same indexing as out (EPI_STORE), or null
+    int ldadd;
+    UVTerm uv;
+    int pixW, pixH;        // spatial dims of a row index m = (b*pixH + y)*pixW + x  (uv term, EPI_CONVT)
+    // EPI_RESID: x[m*ldc+n] += gamma[n]*(acc+bias[n])   (fp32 residual stream)
+    float* xres;
+    const float* gamma;
+    // EPI_PATCH: xres[(b*Ntok+1+p)*N + n] = acc + bias[n] + pos[(1+p)*N + n]
+    const float* pos;
+    int Np, Ntok;
+    // EPI_QKV: scatter to q,k (B,nh,Ntok,64) and vT (B,nh,64,Npad); q pre-scaled by qscale
+    void* q; void* k; void* vT;
+    int nh, Npad, D;
+    float qscale;
+    // EPI_CONVT: n = (dy*2+dx)*Cout + co -> out[((b*2H+2y+dy)*2W+2x+dx)*Cout+co]
+    int Cout;
+};
+
+// host-side launchers (gemm.hip)
+template <typename T> int launch_gemm(const GemmArgs& g, int amode, hipStream_t st);

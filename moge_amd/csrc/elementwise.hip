@@ -1,0 +1,273 @@
+// Bandwidth-bound kernels of the encoder side: image resize+normalise+patchify, position-embedding bicubic
+// resample, cls-row init, LayerNorm.  All fp32 math; storage type T on the GEMM-facing side.
+#include "common.h"
+
+// --------------------------------------------------------------------------------------------
+// K0: antialiased bilinear resize (F.interpolate(..., mode="bilinear", antialias=True), modules.py:121) of the
+// input image to (14*rows, 14*cols), ImageNet normalisation (modules.py:122), written directly in the im2col layout
+// the patch-embed GEMM wants: A0[(b*Np + py*cols + px)][c*196 + iy*14 + ix], row stride ldk (zero padded to ldk).
+// ATen's _upsample_bilinear2d_aa: triangle filter of support max(scale,1), weights normalised per output pixel.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void aa_range(int o, float scale, int in_size, int& lo, int& n, float& center, float& invscale, float& support) {
+    support = scale >= 1.f ? scale : 1.f;
+    invscale = scale >= 1.f ? 1.f / scale : 1.f;
+    center = scale * (o + 0.5f);
+    lo = (int)(center - support + 0.5f);
+    lo = lo < 0 ? 0 : lo;
+    int hi = (int)(center + support + 0.5f);
+    hi = hi > in_size ? in_size : hi;
+    n = hi - lo;
+}
+__device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
+
+template <typename TIn, typename TOut>
+__global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict__ out, int B, int H, int W, int rows, int cols,
+                                  int ldk, int nchw_out, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int OH = rows * 14, OW = cols * 14;
+    const long total = (long)B * 3 * OH * OW;
+    const float scale_y = (float)H / (float)OH, scale_x = (float)W / (float)OW;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ox = idx % OW;
+        long t = idx / OW;
+        const int oy = t % OH; t /= OH;
+        const int c = t % 3;
+        const int b = t / 3;
+        int ylo, yn, xlo, xn; float yc, yis, ysup, xc, xis, xsup;
+        aa_range(oy, scale_y, H, ylo, yn, yc, yis, ysup);
+        aa_range(ox, scale_x, W, xlo, xn, xc, xis, xsup);
+        float wysum = 0.f, wxsum = 0.f;
+        for (int j = 0; j < yn; j++) wysum += tri((j + ylo - yc + 0.5f) * yis);
+        for (int i = 0; i < xn; i++) wxsum += tri((i + xlo - xc + 0.5f) * xis);
+        const TIn* src = img + ((size_t)b * 3 + c) * H * W;
+        // horizontal pass first, then vertical (ATen's separable order), fp32 accumulation
+        float acc = 0.f;
+        for (int j = 0; j < yn; j++) {
+            const float wy = tri((j + ylo - yc + 0.5f) * yis) / wysum;
+            const TIn* rowp = src + (size_t)(ylo + j) * W + xlo;
+            float h = 0.f;
+            for (int i = 0; i < xn; i++) h += (tri((i + xlo - xc + 0.5f) * xis) / wxsum) * (float)rowp[i];
+            acc += wy * h;
+        }
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        const float v = (acc - mean) / sd;
+        if (nchw_out) {
+            out[idx] = (TOut)v;
+        } else {
+            const int py = oy / 14, iy = oy - py * 14, px = ox / 14, ix = ox - px * 14;
+            out[((size_t)b * rows * cols + (size_t)py * cols + px) * ldk + c * 196 + iy * 14 + ix] = (TOut)v;
+        }
+    }
+}
+
+template <typename TIn, typename TOut>
+int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out,
+                      const float* mean, const float* std_, hipStream_t st) {
+    const long total = (long)B * 3 * rows * 14 * cols * 14;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((preprocess_kernel<TIn, TOut>), dim3(blocks), dim3(256), 0, st, (const TIn*)img, (TOut*)out, B, H, W, rows, cols,
+                       ldk, nchw_out, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2]);
+    return (int)hipGetLastError();
+}
+template int launch_preprocess<float, f16>(const void*, void*, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+template int launch_preprocess<float, float>(const void*, void*, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+template int launch_preprocess<f16, f16>(const void*, void*, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+template int launch_preprocess<f16, float>(const void*, void*, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+
+// zero the K padding columns [kfrom, ldk) of the im2col matrix (written once per forward)
+template <typename T>
+__global__ void zero_cols_kernel(T* a, long rowsN, int ldk, int kfrom) {
+    const int w = ldk - kfrom;
+    const long total = rowsN * w;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / w;
+        a[r * ldk + kfrom + (i - r * w)] = (T)0.f;
+    }
+}
+template <typename T>
+int launch_zero_cols(void* a, long rowsN, int ldk, int kfrom, hipStream_t st) {
+    if (kfrom >= ldk) return 0;
+    long total = rowsN * (ldk - kfrom);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(zero_cols_kernel<T>, dim3(blocks), dim3(256), 0, st, (T*)a, rowsN, ldk, kfrom);
+    return (int)hipGetLastError();
+}
+template int launch_zero_cols<f16>(void*, long, int, int, hipStream_t);
+template int launch_zero_cols<float>(void*, long, int, int, hipStream_t);
+
+// --------------------------------------------------------------------------------------------
+// Position embedding for an (rows x cols) grid: bicubic (A=-0.75, align_corners=False, no antialias) resample of the
+// 37x37 pre-training grid with the reference's scale_factor=(n+0.1)/37 kludge (vision_transformer.py:187-221):
+// src = (dst+0.5)*rscale - 0.5 with rscale = float(1/scale_factor); taps clamp-indexed.  Row 0 = cls position.
+// Bypassed (plain copy) iff rows == cols == 37.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cubic_w(float t, float w[4]) {
+    const float A = -0.75f;
+    float x = t + 1.f;
+    w[0] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+    x = t;
+    w[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    x = 1.f - t;
+    w[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    x = 2.f - t;
+    w[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+}
+
+__global__ void posembed_kernel(const float* __restrict__ pos, float* __restrict__ out, int D, int M, int rows, int cols,
+                                float rscale_y, float rscale_x, int bypass) {
+    const long total = (long)(1 + rows * cols) * D;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int d = idx % D;
+        const int p = idx / D;
+        if (p == 0 || bypass) { out[idx] = pos[idx]; continue; }
+        const int oy = (p - 1) / cols, ox = (p - 1) - oy * cols;
+        const float sy = rscale_y * (oy + 0.5f) - 0.5f, sx = rscale_x * (ox + 0.5f) - 0.5f;
+        const float fy = floorf(sy), fx = floorf(sx);
+        const int iy = (int)fy, ix = (int)fx;
+        float wy[4], wx[4];
+        cubic_w(sy - fy, wy);
+        cubic_w(sx - fx, wx);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int yy = iy - 1 + j; yy = yy < 0 ? 0 : (yy > M - 1 ? M - 1 : yy);
+            float r = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int xx = ix - 1 + i; xx = xx < 0 ? 0 : (xx > M - 1 ? M - 1 : xx);
+                r += wx[i] * pos[(size_t)(1 + yy * M + xx) * D + d];
+            }
+            acc += wy[j] * r;
+        }
+        out[idx] = acc;
+    }
+}
+int launch_posembed(const float* pos, float* out, int D, int rows, int cols, hipStream_t st) {
+    const int M = 37;
+    const int bypass = (rows == M && cols == M) ? 1 : 0;
+    const float ry = (float)(1.0 / ((double)(rows + 0.1) / M)), rx = (float)(1.0 / ((double)(cols + 0.1) / M));
+    const long total = (long)(1 + rows * cols) * D;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(posembed_kernel, dim3(blocks), dim3(256), 0, st, pos, out, D, M, rows, cols, ry, rx, bypass);
+    return (int)hipGetLastError();
+}
+
+// x[b, 0, :] = cls_token + pos[0]   (vision_transformer.py:230-231)
+__global__ void cls_row_kernel(float* x, const float* cls, const float* pos, int B, int Ntok, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, d = i - b * D;
+    x[(size_t)b * Ntok * D + d] = cls[d] + pos[d];
+}
+int launch_cls_row(float* x, const float* cls, const float* pos, int B, int Ntok, int D, hipStream_t st) {
+    hipLaunchKernelGGL(cls_row_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, x, cls, pos, B, Ntok, D);
+    return (int)hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------
+// LayerNorm (eps 1e-6, vision_transformer.py:95): one wave per row of the fp32 residual stream, two-pass in
+// registers.  D % 128 == 0, D <= 1024 (ViT-S/B/L).  Output modes:
+//   plain: out[row*ldo + col]
+//   tap  : (get_intermediate_layers, vision_transformer.py:321-324) token 0 -> cls_out[b*D + col] (fp32, optional),
+//          token t>0 -> out[(b*Np + t-1)*ldo + coloff + col]  (the K-concatenated output-projection operand)
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        T* __restrict__ out, float* __restrict__ cls_out, long rowsN, int D, int ldo,
+                                                        int coloff, int tap_mode, int Ntok) {
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rowsN) return;
+    const int nit = D >> 7;                       // 128 columns per pass (float2 per lane)
+    const float* xr = x + row * (long)D;
+    f32x2 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (i < nit) { v[i] = *reinterpret_cast<const f32x2*>(xr + i * 128 + lane * 2); s += v[i][0] + v[i][1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (i < nit) { const float a = v[i][0] - mean, c = v[i][1] - mean; q += a * a + c * c; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)D + 1e-6f);
+    T* op = nullptr; float* cp = nullptr;
+    if (tap_mode) {
+        const long b = row / Ntok; const int t = (int)(row - b * Ntok);
+        if (t == 0) { if (!cls_out) return; cp = cls_out + b * D; }
+        else op = out + (b * (Ntok - 1) + t - 1) * (long)ldo + coloff;
+    } else {
+        op = out + row * (long)ldo + coloff;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (i < nit) {
+            const int col = i * 128 + lane * 2;
+            const f32x2 ww = *reinterpret_cast<const f32x2*>(w + col), bb = *reinterpret_cast<const f32x2*>(bias + col);
+            const float y0 = (v[i][0] - mean) * rstd * ww[0] + bb[0], y1 = (v[i][1] - mean) * rstd * ww[1] + bb[1];
+            if (cp) { cp[col] = y0; cp[col + 1] = y1; }
+            else { op[col] = (T)y0; op[col + 1] = (T)y1; }
+        }
+}
+template <typename T>
+int launch_layernorm(const float* x, const float* w, const float* b, void* out, float* cls_out, long rowsN, int D, int ldo, int coloff,
+                     int tap_mode, int Ntok, hipStream_t st) {
+    if (D % 128 != 0 || D > 1024) return -1;
+    hipLaunchKernelGGL(layernorm_kernel<T>, dim3((unsigned)((rowsN + 3) / 4)), dim3(256), 0, st, x, w, b, (T*)out, cls_out, rowsN, D, ldo, coloff,
+                       tap_mode, Ntok);
+    return (int)hipGetLastError();
+}
+template int launch_layernorm<f16>(const float*, const float*, const float*, void*, float*, long, int, int, int, int, int, hipStream_t);
+template int launch_layernorm<float>(const float*, const float*, const float*, void*, float*, long, int, int, int, int, int, hipStream_t);
+
+// --------------------------------------------------------------------------------------------
+// small helpers: fp32 <-> storage conversions (weight packing, test entry points, debug taps)
+// --------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ void convert_kernel(const TS* s, TD* d, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d[i] = (TD)(float)s[i];
+}
+template <typename TS, typename TD>
+int launch_convert(const void* s, void* d, long n, hipStream_t st) {
+    if (n <= 0) return 0;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((convert_kernel<TS, TD>), dim3(blocks), dim3(256), 0, st, (const TS*)s, (TD*)d, n);
+    return (int)hipGetLastError();
+}
+template int launch_convert<float, f16>(const void*, void*, long, hipStream_t);
+template int launch_convert<float, float>(const void*, void*, long, hipStream_t);
+template int launch_convert<f16, float>(const void*, void*, long, hipStream_t);
+
+// generic strided repack: dst[o0*ds0 + o1*ds1 + o2*ds2 + o3] = src[o0*ss0 + o1*ss1 + o2*ss2 + o3*ss3], dims (n0,n1,n2,n3)
+template <typename TD>
+__global__ void repack_kernel(const float* src, TD* dst, int n0, int n1, int n2, int n3, long ss0, long ss1, long ss2, long ss3,
+                              long ds0, long ds1, long ds2) {
+    const long total = (long)n0 * n1 * n2 * n3;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long t = i;
+        const int i3 = t % n3; t /= n3;
+        const int i2 = t % n2; t /= n2;
+        const int i1 = t % n1; t /= n1;
+        const int i0 = (int)t;
+        dst[i0 * ds0 + i1 * ds1 + i2 * ds2 + i3] = (TD)src[i0 * ss0 + i1 * ss1 + i2 * ss2 + i3 * ss3];
+    }
+}
+template <typename TD>
+int launch_repack(const float* src, void* dst, int n0, int n1, int n2, int n3, long ss0, long ss1, long ss2, long ss3, long ds0, long ds1,
+                  long ds2, hipStream_t st) {
+    const long total = (long)n0 * n1 * n2 * n3;
+    if (total <= 0) return 0;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(repack_kernel<TD>, dim3(blocks), dim3(256), 0, st, src, (TD*)dst, n0, n1, n2, n3, ss0, ss1, ss2, ss3, ds0, ds1, ds2);
+    return (int)hipGetLastError();
+}
+template int launch_repack<f16>(const float*, void*, int, int, int, int, long, long, long, long, long, long, long, hipStream_t);
+template int launch_repack<float>(const float*, void*, int, int, int, int, long, long, long, long, long, long, long, hipStream_t);

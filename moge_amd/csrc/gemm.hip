@@ -1,0 +1,313 @@
+// MFMA GEMM / implicit-GEMM convolution for gfx950 with fused epilogues.
+//
+//   C[M,N] = A[M,K] * W[N,K]^T      A: activations (token-major / NHWC), W: packed weights, both K-contiguous.
+//
+// One kernel template serves every matrix-shaped op of the MoGe-2 hot path:
+//   linear layers of the ViT        attention.py:72,79  mlp.py:35,38  patch_embed.py:75 (conv14/s14 as GEMM)
+//   1x1 convs                       modules.py:128-131, 209, 231
+//   ConvTranspose2d k2/s2           modules.py:162  (GEMM to 4*Cout + pixel-shuffle store)
+//   3x3 replicate-padded convs      modules.py:53,59,148-181 (implicit GEMM, K = 9*Cin, clamp-indexed loads,
+//                                   optional ReLU prologue, optional fused bilinear x2 upsample modules.py:157)
+//
+// Design (CDNA4): the block computes a BM x BN tile; K is consumed in 128-byte slabs (64 halves / 32 floats) that
+// are staged global -> registers -> LDS (16-byte chunks, XOR-swizzled so ds_read_b128 is bank-conflict free),
+// double buffered with one barrier per slab and the next slab's global loads in flight during the MFMAs.
+// The MFMA is issued "swapped" (A-operand = weight rows, B-operand = activation rows) so each lane owns one
+// output row m and 4 consecutive output columns n per register quad -> vector stores and vector bias loads.
+// Storage type T selects the instruction: f16 -> v_mfma_f32_32x32x16_f16, float -> v_mfma_f32_32x32x2_f32
+// (exact fp32, the parity mode).  Accumulation is fp32 in both.
+#include "common.h"
+
+template <typename T>
+__device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float v0, float v1, float v2, float v3) {
+    if (m >= g.M || n >= g.N) return;
+    float v[4] = {v0, v1, v2, v3};
+    if (g.bias) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] += b[i];
+    }
+    switch (g.epi) {
+    case EPI_STORE: {
+        if (g.uv.wu) {
+            const int x = m % g.pixW;
+            const int y = (m / g.pixW) % g.pixH;
+            const float u = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, g.pixW, x);
+            const float vv = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, g.pixH, y);
+            const f32x4 wu = *reinterpret_cast<const f32x4*>(g.uv.wu + n);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(g.uv.wv + n);
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] += wu[i] * u + wv[i] * vv;
+        }
+        if (g.add) {
+            float a[4];
+            load4(reinterpret_cast<const T*>(g.add) + (size_t)m * g.ldadd + n, a);
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] += a[i];
+        }
+        if (g.act == ACT_RELU) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = fmaxf(v[i], 0.f);
+        } else if (g.act == ACT_GELU) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = gelu_erf(v[i]);
+        }
+        store4(reinterpret_cast<T*>(g.out) + (size_t)m * g.ldc + n, v[0], v[1], v[2], v[3]);
+        break;
+    }
+    case EPI_RESID: {
+        float* p = g.xres + (size_t)m * g.ldc + n;
+        f32x4 x = *reinterpret_cast<f32x4*>(p);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] += gm[i] * v[i];
+        *reinterpret_cast<f32x4*>(p) = x;
+        break;
+    }
+    case EPI_PATCH: {
+        const int b = m / g.Np, p = m - b * g.Np;
+        const f32x4 pe = *reinterpret_cast<const f32x4*>(g.pos + (size_t)(1 + p) * g.N + n);
+        f32x4 o = {v[0] + pe[0], v[1] + pe[1], v[2] + pe[2], v[3] + pe[3]};
+        *reinterpret_cast<f32x4*>(g.xres + ((size_t)b * g.Ntok + 1 + p) * g.N + n) = o;
+        break;
+    }
+    case EPI_QKV: {
+        const int which = n / g.D;
+        const int rem = n - which * g.D;
+        const int hd = rem >> 6, d = rem & 63;
+        const int b = m / g.Ntok, tok = m - b * g.Ntok;
+        const size_t bh = (size_t)b * g.nh + hd;
+        if (which == 0) {
+            store4(reinterpret_cast<T*>(g.q) + (bh * g.Ntok + tok) * 64 + d, v[0] * g.qscale, v[1] * g.qscale, v[2] * g.qscale, v[3] * g.qscale);
+        } else if (which == 1) {
+            store4(reinterpret_cast<T*>(g.k) + (bh * g.Ntok + tok) * 64 + d, v[0], v[1], v[2], v[3]);
+        } else {
+            T* p = reinterpret_cast<T*>(g.vT) + (bh * 64 + d) * (size_t)g.Npad + tok;
+#pragma unroll
+            for (int i = 0; i < 4; i++) p[(size_t)i * g.Npad] = (T)v[i];
+        }
+        break;
+    }
+    case EPI_CONVT: {
+        const int qd = n / g.Cout, co = n - qd * g.Cout;
+        const int dy = qd >> 1, dx = qd & 1;
+        const int x = m % g.pixW;
+        const int t = m / g.pixW;
+        const int y = t % g.pixH, b = t / g.pixH;
+        const size_t idx = (((size_t)b * 2 * g.pixH + 2 * y + dy) * (2 * g.pixW) + 2 * x + dx) * g.Cout + co;
+        store4(reinterpret_cast<T*>(g.out) + idx, v[0], v[1], v[2], v[3]);
+        break;
+    }
+    }
+}
+
+template <typename T, int WM, int WN, int TM, int TN, int AMODE>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int CH = TT<T>::CH;
+    constexpr int A_IT = BM * 8 / NT, W_IT = BN * 8 / NT;
+    constexpr int RSTEP = NT / 8;                      // tile rows covered per load pass
+    constexpr int NTAP = (AMODE == AMODE_CONV3_UP2) ? 4 : 1;
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile/thread mismatch");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                    // [2][BM][128 B]
+    char* sW = smem + 2 * BM * 128;     // [2][BN][128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nbn = (g.N + BN - 1) / BN;
+    const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int Kchunks = g.K / CH;
+    const int nkt = (Kchunks + 7) >> 3;
+    const int c = tid & 7;              // this thread's chunk column inside every 128-byte slab
+    const int r0 = tid >> 3;            // first tile row this thread stages
+
+    // ---- per-thread A row descriptors ------------------------------------------------------
+    const T* a_base[A_IT];              // LINEAR: row pointer; CONV: image base pointer of the row's batch item
+    int a_y[A_IT], a_x[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; i++) {
+        int m = m0 + r0 + i * RSTEP;
+        m = m < g.M ? m : g.M - 1;
+        if (AMODE == AMODE_LINEAR) {
+            a_base[i] = reinterpret_cast<const T*>(g.a) + (size_t)m * g.lda;
+            a_y[i] = 0; a_x[i] = 0;
+        } else {
+            const int x = m % g.W;
+            const int t = m / g.W;
+            const int y = t % g.H, b = t / g.H;
+            const int Hin = (AMODE == AMODE_CONV3_UP2) ? g.H / 2 : g.H, Win = (AMODE == AMODE_CONV3_UP2) ? g.W / 2 : g.W;
+            a_base[i] = reinterpret_cast<const T*>(g.a) + (size_t)b * Hin * Win * g.C;
+            a_y[i] = y; a_x[i] = x;
+        }
+    }
+    const T* w_base[W_IT];
+#pragma unroll
+    for (int i = 0; i < W_IT; i++) {
+        int n = n0 + r0 + i * RSTEP;
+        n = n < g.N ? n : g.N - 1;
+        w_base[i] = reinterpret_cast<const T*>(g.w) + (size_t)n * g.ldw;
+    }
+    const int cpc = (AMODE == AMODE_LINEAR) ? 1 : g.C / CH;     // chunks per conv tap
+
+    u32x4 ra[A_IT * NTAP], rw[W_IT];
+    float bw[A_IT * 4];                 // UP2: bilinear weights of the 4 taps
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    auto load_slab = [&](int kt) {
+        const int kc = kt * 8 + c;
+        const bool kvalid = kc < Kchunks;
+        if (AMODE == AMODE_LINEAR) {
+#pragma unroll
+            for (int i = 0; i < A_IT; i++)
+                ra[i] = kvalid ? *reinterpret_cast<const u32x4*>(a_base[i] + (size_t)kc * CH) : zero4;
+        } else {
+            const int tap = kc / cpc;
+            const int cc = kc - tap * cpc;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+            for (int i = 0; i < A_IT; i++) {
+                int yy = a_y[i] + dy, xx = a_x[i] + dx;
+                yy = yy < 0 ? 0 : (yy > g.H - 1 ? g.H - 1 : yy);      // replicate padding (modules.py:53)
+                xx = xx < 0 ? 0 : (xx > g.W - 1 ? g.W - 1 : xx);
+                if (AMODE == AMODE_CONV3) {
+                    ra[i] = kvalid ? *reinterpret_cast<const u32x4*>(a_base[i] + ((size_t)yy * g.W + xx) * g.C + cc * CH) : zero4;
+                } else {
+                    // virtual bilinear x2 upsample (align_corners=False): src = dst/2 - 0.25, clamped at 0
+                    const int Hin = g.H / 2, Win = g.W / 2;
+                    float sy = fmaxf(0.5f * yy - 0.25f, 0.f), sx = fmaxf(0.5f * xx - 0.25f, 0.f);
+                    const int y0 = (int)sy, x0 = (int)sx;
+                    const int y1 = y0 + 1 < Hin ? y0 + 1 : Hin - 1, x1 = x0 + 1 < Win ? x0 + 1 : Win - 1;
+                    const float ly = sy - y0, lx = sx - x0;
+                    bw[i * 4 + 0] = (1.f - ly) * (1.f - lx); bw[i * 4 + 1] = (1.f - ly) * lx;
+                    bw[i * 4 + 2] = ly * (1.f - lx);         bw[i * 4 + 3] = ly * lx;
+                    const T* p = a_base[i] + cc * CH;
+                    ra[i * 4 + 0] = kvalid ? *reinterpret_cast<const u32x4*>(p + ((size_t)y0 * Win + x0) * g.C) : zero4;
+                    ra[i * 4 + 1] = kvalid ? *reinterpret_cast<const u32x4*>(p + ((size_t)y0 * Win + x1) * g.C) : zero4;
+                    ra[i * 4 + 2] = kvalid ? *reinterpret_cast<const u32x4*>(p + ((size_t)y1 * Win + x0) * g.C) : zero4;
+                    ra[i * 4 + 3] = kvalid ? *reinterpret_cast<const u32x4*>(p + ((size_t)y1 * Win + x1) * g.C) : zero4;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W_IT; i++)
+            rw[i] = kvalid ? *reinterpret_cast<const u32x4*>(w_base[i] + (size_t)kc * CH) : zero4;
+    };
+
+    auto store_slab = [&](int buf) {
+        char* dA = sA + buf * BM * 128;
+        char* dW = sW + buf * BN * 128;
+#pragma unroll
+        for (int i = 0; i < A_IT; i++) {
+            const int row = r0 + i * RSTEP;
+            u32x4 v;
+            if (AMODE == AMODE_CONV3_UP2)
+                v = blend4_chunk<T>(ra[i * 4], ra[i * 4 + 1], ra[i * 4 + 2], ra[i * 4 + 3], bw[i * 4], bw[i * 4 + 1], bw[i * 4 + 2], bw[i * 4 + 3]);
+            else
+                v = ra[i];
+            if (g.relu_in) v = relu_chunk<T>(v);
+            *reinterpret_cast<u32x4*>(dA + row * 128 + (swz<8>(row, c) << 4)) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < W_IT; i++) {
+            const int row = r0 + i * RSTEP;
+            *reinterpret_cast<u32x4*>(dW + row * 128 + (swz<8>(row, c) << 4)) = rw[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_slab(kt + 1);            // global loads in flight during the MFMAs below
+        const char* cA = sA + buf * BM * 128;
+        const char* cW = sW + buf * BN * 128;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int cs = 2 * s + hi;
+            u32x4 af[TM], wf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int row = (wm * TM + i) * 32 + l31;
+                af[i] = *reinterpret_cast<const u32x4*>(cA + row * 128 + (swz<8>(row, cs) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int row = (wn * TN + j) * 32 + l31;
+                wf[j] = *reinterpret_cast<const u32x4*>(cW + row * 128 + (swz<8>(row, cs) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) mma_step<T>(acc[i][j], wf[j], af[i]);     // D[n][m]
+        }
+        if (kt + 1 < nkt) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns row m, register quad g -> columns n..n+3 -------------------------
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int m = m0 + (wm * TM + i) * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int nb = n0 + (wn * TN + j) * 32 + 4 * hi;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                epilogue4<T>(g, m, nb + 8 * q, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        }
+    }
+}
+
+template <typename T, int WM, int WN, int TM, int TN, int AMODE>
+static int launch_cfg(const GemmArgs& g, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int smem = 2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    auto kern = gemm_kernel<T, WM, WN, TM, TN, AMODE>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(64 * WM * WN), smem, st, g);
+    return (int)hipGetLastError();
+}
+
+template <typename T, int AMODE>
+static int launch_by_n(const GemmArgs& g, hipStream_t st) {
+    if (g.N > 64) return launch_cfg<T, 2, 2, 2, 2, AMODE>(g, st);     // 128 x 128
+    if (g.N > 32) return launch_cfg<T, 4, 1, 1, 2, AMODE>(g, st);     // 128 x 64
+    return launch_cfg<T, 4, 1, 1, 1, AMODE>(g, st);                   // 128 x 32
+}
+
+template <typename T>
+int launch_gemm(const GemmArgs& g, int amode, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return -1;
+    if ((g.K % TT<T>::CH) != 0 || (g.N % 4) != 0) return -1;
+    if (amode != AMODE_LINEAR && (g.C % TT<T>::CH) != 0) return -1;
+    switch (amode) {
+    case AMODE_LINEAR: return launch_by_n<T, AMODE_LINEAR>(g, st);
+    case AMODE_CONV3: return launch_by_n<T, AMODE_CONV3>(g, st);
+    case AMODE_CONV3_UP2: return launch_by_n<T, AMODE_CONV3_UP2>(g, st);
+    }
+    return -1;
+}
+
+template int launch_gemm<f16>(const GemmArgs&, int, hipStream_t);
+template int launch_gemm<float>(const GemmArgs&, int, hipStream_t);

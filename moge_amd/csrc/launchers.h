@@ -1,0 +1,29 @@
+// Host-callable launchers of every kernel in libmoge_hip.so (definitions in the .hip files).
+#pragma once
+#include "common.h"
+
+template <typename T> int launch_attention(const void* q, const void* k, const void* vT, void* out, int B, int nh, int Ntok, int Npad, hipStream_t st);
+
+template <typename TIn, typename TOut>
+int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out, const float* mean,
+                      const float* std_, hipStream_t st);
+template <typename T> int launch_zero_cols(void* a, long rowsN, int ldk, int kfrom, hipStream_t st);
+int launch_posembed(const float* pos, float* out, int D, int rows, int cols, hipStream_t st);
+int launch_cls_row(float* x, const float* cls, const float* pos, int B, int Ntok, int D, hipStream_t st);
+template <typename T>
+int launch_layernorm(const float* x, const float* w, const float* b, void* out, float* cls_out, long rowsN, int D, int ldo, int coloff,
+                     int tap_mode, int Ntok, hipStream_t st);
+template <typename TS, typename TD> int launch_convert(const void* s, void* d, long n, hipStream_t st);
+template <typename TD>
+int launch_repack(const float* src, void* dst, int n0, int n1, int n2, int n3, long ss0, long ss1, long ss2, long ss3, long ds0, long ds1,
+                  long ds2, hipStream_t st);
+
+template <typename T>
+int launch_head_final(int kind, const void* x4, const float* w, const float* bias, float* out, int B, int Hd, int Wd, int C, int H, int W,
+                      int remap, hipStream_t st);
+int launch_mlp_layer(const float* in, const float* W, const float* bias, float* out, int B, int K, int N, int act, hipStream_t st);
+int launch_recover(const float* points, const float* mask_prob, const uint8_t* mask_u8, const float* fov_deg, const float* focal_in, int B,
+                   int H, int W, float* focal, float* shift, float* intrinsics, int* status, hipStream_t st);
+int launch_finalize(const float* points_in, const float* normal_in, const float* mask_prob, const float* metric, const float* shift,
+                    const float* intr, int B, int H, int W, int flags, float* points_out, float* depth_out, float* normal_out,
+                    uint8_t* mask_out, hipStream_t st);

@@ -1,0 +1,884 @@
+// Host side of libmoge_hip.so: handle, weight table + kernel-layout packing, workspace plan, the forward / infer
+// drivers and the C ABI declared in include/moge_hip.h.  No device code here; every launch goes through launchers.h.
+//
+// Reference call structure reproduced (paths relative to the reference checkout):
+//   forward   moge/model/v2.py:138-192   encoder moge/model/modules.py:120-136   ViT dinov2/models/vision_transformer.py:223-333
+//   decoder   moge/model/modules.py:242-254 (ConvStack.forward)                  infer  moge/model/v2.py:194-303
+#include "launchers.h"
+#include "../../include/moge_hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MOGE_ERR_HIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define LCHK(x) do { int e_ = (x); if (e_ != 0) return fail(e_ < 0 ? MOGE_ERR_INVALID : MOGE_ERR_HIP, "%s: launch failed (%d: %s) (%s:%d)", #x, e_, e_ > 0 ? hipGetErrorString((hipError_t)e_) : "unsupported shape", __FILE__, __LINE__); } while (0)
+#define CHK(x) do { int e_ = (x); if (e_ != 0) return e_; } while (0)
+
+static const char* HEAD_NAMES[3] = {"points_head", "normal_head", "mask_head"};
+static const int HEAD_BITS[3] = {MOGE_HEAD_POINTS, MOGE_HEAD_NORMAL, MOGE_HEAD_MASK};
+static const int HEAD_COUT[3] = {3, 3, 1};
+static const int KPATCH = 588, KPATCH_PAD = 592;     // 3*14*14 padded to a multiple of 8
+
+struct TInfo { size_t off; int64_t numel; bool loaded; };
+
+struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; };
+
+struct moge_handle {
+    moge_config cfg;
+    int device;
+    // fp32 master copy of the checkpoint (layout = f(config))
+    std::map<std::string, TInfo> table;
+    size_t master_floats = 0;
+    float* master = nullptr;
+    bool master_ready = false;
+    // derived fp32 vectors (bias sums, uv columns, expanded convT biases)
+    std::map<std::string, size_t> aux_off;
+    size_t aux_floats = 0;
+    float* aux = nullptr;
+    bool aux_ready = false;
+    // kernel-layout matrices per precision
+    std::map<std::string, size_t> pk_off;      // element offsets (same for both precisions)
+    size_t pk_elems = 0;
+    void* packed[2] = {nullptr, nullptr};
+    bool pk_ready[2] = {false, false};
+    int prec = MOGE_FP32;
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    // position-embedding cache
+    struct PosEntry { int rows, cols; float* ptr; };
+    std::vector<PosEntry> pos_cache;
+    int* d_status = nullptr;
+    float img_mean[3] = {0.485f, 0.456f, 0.406f}, img_std[3] = {0.229f, 0.224f, 0.225f};   // refreshed from the checkpoint buffers
+    // profiler
+    bool prof_on = false;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    moge_profile prof_acc;
+    // last forward (debug taps)
+    struct { bool valid = false; int prec, B, rows, cols; std::map<std::string, std::pair<size_t, std::pair<int64_t, int>>> bufs; } last;   // name -> (ws offset, (numel, kind 0=f32 1=T))
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// weight table
+// ------------------------------------------------------------------------------------------------------------
+static void tadd(moge_handle* h, const std::string& name, int64_t numel) {
+    TInfo t{h->master_floats, numel, false};
+    h->table[name] = t;
+    h->master_floats += (size_t)((numel + 63) / 64 * 64);
+}
+static void aadd(moge_handle* h, const std::string& name, int64_t numel) {
+    h->aux_off[name] = h->aux_floats;
+    h->aux_floats += (size_t)((numel + 63) / 64 * 64);
+}
+static void padd(moge_handle* h, const std::string& name, int64_t numel) {
+    h->pk_off[name] = h->pk_elems;
+    h->pk_elems += (size_t)((numel + 63) / 64 * 64);
+}
+static std::string S(const char* fmt, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return buf;
+}
+
+static void build_tables(moge_handle* h) {
+    const moge_config& c = h->cfg;
+    const int D = c.embed_dim, c0 = c.dims[0];
+    const std::string bb = "encoder.backbone.";
+    tadd(h, bb + "cls_token", D);
+    tadd(h, bb + "pos_embed", (int64_t)(1 + 37 * 37) * D);
+    tadd(h, bb + "patch_embed.proj.weight", (int64_t)D * KPATCH);
+    tadd(h, bb + "patch_embed.proj.bias", D);
+    padd(h, "patch.w", (int64_t)D * KPATCH_PAD);
+    for (int i = 0; i < c.depth; i++) {
+        const std::string p = bb + S("blocks.%d.", i);
+        tadd(h, p + "norm1.weight", D); tadd(h, p + "norm1.bias", D);
+        tadd(h, p + "attn.qkv.weight", (int64_t)3 * D * D); tadd(h, p + "attn.qkv.bias", 3 * D);
+        tadd(h, p + "attn.proj.weight", (int64_t)D * D); tadd(h, p + "attn.proj.bias", D);
+        tadd(h, p + "ls1.gamma", D);
+        tadd(h, p + "norm2.weight", D); tadd(h, p + "norm2.bias", D);
+        tadd(h, p + "mlp.fc1.weight", (int64_t)4 * D * D); tadd(h, p + "mlp.fc1.bias", 4 * D);
+        tadd(h, p + "mlp.fc2.weight", (int64_t)4 * D * D); tadd(h, p + "mlp.fc2.bias", D);
+        tadd(h, p + "ls2.gamma", D);
+        padd(h, S("blk%d.qkv", i), (int64_t)3 * D * D);
+        padd(h, S("blk%d.proj", i), (int64_t)D * D);
+        padd(h, S("blk%d.fc1", i), (int64_t)4 * D * D);
+        padd(h, S("blk%d.fc2", i), (int64_t)4 * D * D);
+    }
+    tadd(h, bb + "norm.weight", D); tadd(h, bb + "norm.bias", D);
+    for (int k = 0; k < c.n_taps; k++) {
+        tadd(h, S("encoder.output_projections.%d.weight", k), (int64_t)c0 * D);
+        tadd(h, S("encoder.output_projections.%d.bias", k), c0);
+    }
+    tadd(h, "encoder.image_mean", 3);
+    tadd(h, "encoder.image_std", 3);
+    padd(h, "outproj.w", (int64_t)c0 * c.n_taps * D);
+    aadd(h, "outproj.bias", c0);
+
+    auto stack = [&](const std::string& name, bool neck, const int* nres, int cout) {
+        for (int l = 0; l < MOGE_LEVELS; l++) {
+            const int cl = c.dims[l];
+            const int cin = neck ? (l == 0 ? c0 + 2 : 2) : cl;
+            tadd(h, name + S(".input_blocks.%d.weight", l), (int64_t)cl * cin);
+            tadd(h, name + S(".input_blocks.%d.bias", l), cl);
+            if (neck) {
+                aadd(h, name + S(".in%d.wu", l), cl);
+                aadd(h, name + S(".in%d.wv", l), cl);
+                if (l == 0) padd(h, name + ".in0.w", (int64_t)cl * c0);
+                else aadd(h, name + S(".rs%d.bias2", l - 1), cl);
+            } else {
+                padd(h, name + S(".in%d.w", l), (int64_t)cl * cl);
+            }
+        }
+        for (int l = 0; l < MOGE_LEVELS - 1; l++) {
+            const int ci = c.dims[l], co = c.dims[l + 1];
+            if (l < 3) {
+                tadd(h, name + S(".resamplers.%d.0.weight", l), (int64_t)ci * co * 4);
+                tadd(h, name + S(".resamplers.%d.0.bias", l), co);
+                tadd(h, name + S(".resamplers.%d.1.weight", l), (int64_t)co * co * 9);
+                tadd(h, name + S(".resamplers.%d.1.bias", l), co);
+                padd(h, name + S(".rs%d.wT", l), (int64_t)4 * co * ci);
+                padd(h, name + S(".rs%d.w3", l), (int64_t)co * 9 * co);
+                aadd(h, name + S(".rs%d.biasT", l), 4 * co);
+            } else {
+                tadd(h, name + S(".resamplers.%d.1.weight", l), (int64_t)co * ci * 9);
+                tadd(h, name + S(".resamplers.%d.1.bias", l), co);
+                padd(h, name + S(".rs%d.w3", l), (int64_t)co * 9 * ci);
+            }
+        }
+        for (int l = 0; l < MOGE_LEVELS; l++)
+            for (int j = 0; j < nres[l]; j++) {
+                const int cl = c.dims[l];
+                for (int li = 2; li <= 5; li += 3) {
+                    tadd(h, name + S(".res_blocks.%d.%d.layers.%d.weight", l, j, li), (int64_t)cl * cl * 9);
+                    tadd(h, name + S(".res_blocks.%d.%d.layers.%d.bias", l, j, li), cl);
+                    padd(h, name + S(".res%d.%d.w%d", l, j, li == 2 ? 1 : 2), (int64_t)cl * 9 * cl);
+                }
+            }
+        if (cout > 0) {
+            tadd(h, name + ".output_blocks.4.weight", (int64_t)cout * c.dims[4]);
+            tadd(h, name + ".output_blocks.4.bias", cout);
+        }
+    };
+    stack("neck", true, c.neck_res_blocks, 0);
+    for (int k = 0; k < 3; k++)
+        if (c.heads & HEAD_BITS[k]) stack(HEAD_NAMES[k], false, c.head_res_blocks, HEAD_COUT[k]);
+    if (c.heads & MOGE_HEAD_SCALE) {
+        const int hd = c.scale_hidden;
+        tadd(h, "scale_head.0.weight", (int64_t)hd * D); tadd(h, "scale_head.0.bias", hd);
+        tadd(h, "scale_head.2.weight", (int64_t)hd * hd); tadd(h, "scale_head.2.bias", hd);
+        tadd(h, "scale_head.4.weight", hd); tadd(h, "scale_head.4.bias", 1);
+    }
+}
+
+static const float* M(moge_handle* h, const std::string& name) { return h->master + h->table.at(name).off; }
+static float* A(moge_handle* h, const std::string& name) { return h->aux + h->aux_off.at(name); }
+template <typename T> static const T* P(moge_handle* h, const std::string& name) { return reinterpret_cast<const T*>(h->packed[TT<T>::PREC]) + h->pk_off.at(name); }
+template <typename T> static T* Pm(moge_handle* h, const std::string& name) { return reinterpret_cast<T*>(h->packed[TT<T>::PREC]) + h->pk_off.at(name); }
+
+// ------------------------------------------------------------------------------------------------------------
+// packing (device side, from the fp32 master)
+// ------------------------------------------------------------------------------------------------------------
+static int build_aux(moge_handle* h, hipStream_t st) {
+    if (h->aux_ready) return 0;
+    const moge_config& c = h->cfg;
+    if (!h->aux) HIPCHK(hipMalloc(&h->aux, h->aux_floats * sizeof(float)));
+    HIPCHK(hipMemsetAsync(h->aux, 0, h->aux_floats * sizeof(float), st));
+    const int c0 = c.dims[0];
+    // outproj.bias = sum_k bias_k : n_taps strided adds via repack (dst += not available) -> do on host-visible path: tiny D2H/H2D
+    {
+        std::vector<float> acc(c0, 0.f), tmp(c0);
+        for (int k = 0; k < c.n_taps; k++) {
+            HIPCHK(hipMemcpyAsync(tmp.data(), M(h, S("encoder.output_projections.%d.bias", k)), c0 * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int i = 0; i < c0; i++) acc[i] += tmp[i];
+        }
+        HIPCHK(hipMemcpyAsync(A(h, "outproj.bias"), acc.data(), c0 * sizeof(float), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    // neck uv columns + combined biases
+    for (int l = 0; l < MOGE_LEVELS; l++) {
+        const int cl = c.dims[l];
+        const int cin = l == 0 ? c0 + 2 : 2;
+        const float* w = M(h, S("neck.input_blocks.%d.weight", l));
+        LCHK(launch_repack<float>(w + (cin - 2), A(h, S("neck.in%d.wu", l)), cl, 1, 1, 1, cin, 0, 0, 0, 1, 0, 0, st));
+        LCHK(launch_repack<float>(w + (cin - 1), A(h, S("neck.in%d.wv", l)), cl, 1, 1, 1, cin, 0, 0, 0, 1, 0, 0, st));
+        if (l > 0) {
+            std::vector<float> a(cl), b(cl);
+            HIPCHK(hipMemcpyAsync(a.data(), M(h, S("neck.resamplers.%d.1.bias", l - 1)), cl * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(b.data(), M(h, S("neck.input_blocks.%d.bias", l)), cl * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int i = 0; i < cl; i++) a[i] += b[i];
+            HIPCHK(hipMemcpyAsync(A(h, S("neck.rs%d.bias2", l - 1)), a.data(), cl * sizeof(float), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+    }
+    auto stack = [&](const std::string& name) -> int {
+        for (int l = 0; l < 3; l++) {
+            const int co = c.dims[l + 1];
+            LCHK(launch_repack<float>(M(h, name + S(".resamplers.%d.0.bias", l)), A(h, name + S(".rs%d.biasT", l)), 4, 1, 1, co, 0, 0, 0, 1, co, 0, 0, st));
+        }
+        return 0;
+    };
+    CHK(stack("neck"));
+    for (int k = 0; k < 3; k++)
+        if (c.heads & HEAD_BITS[k]) CHK(stack(HEAD_NAMES[k]));
+    h->aux_ready = true;
+    return 0;
+}
+
+template <typename T>
+static int pack_weights(moge_handle* h, hipStream_t st) {
+    const int pr = TT<T>::PREC;
+    if (h->pk_ready[pr]) return 0;
+    const moge_config& c = h->cfg;
+    const int D = c.embed_dim, c0 = c.dims[0];
+    if (!h->packed[pr]) HIPCHK(hipMalloc(&h->packed[pr], h->pk_elems * sizeof(T)));
+    HIPCHK(hipMemsetAsync(h->packed[pr], 0, h->pk_elems * sizeof(T), st));
+    const std::string bb = "encoder.backbone.";
+    // patch embed [D][588] -> [D][592]
+    LCHK(launch_repack<T>(M(h, bb + "patch_embed.proj.weight"), Pm<T>(h, "patch.w"), D, 1, 1, KPATCH, KPATCH, 0, 0, 1, KPATCH_PAD, 0, 0, st));
+    for (int i = 0; i < c.depth; i++) {
+        const std::string p = bb + S("blocks.%d.", i);
+        LCHK((launch_convert<float, T>(M(h, p + "attn.qkv.weight"), Pm<T>(h, S("blk%d.qkv", i)), (long)3 * D * D, st)));
+        LCHK((launch_convert<float, T>(M(h, p + "attn.proj.weight"), Pm<T>(h, S("blk%d.proj", i)), (long)D * D, st)));
+        LCHK((launch_convert<float, T>(M(h, p + "mlp.fc1.weight"), Pm<T>(h, S("blk%d.fc1", i)), (long)4 * D * D, st)));
+        LCHK((launch_convert<float, T>(M(h, p + "mlp.fc2.weight"), Pm<T>(h, S("blk%d.fc2", i)), (long)4 * D * D, st)));
+    }
+    // output projections: [c0][D] x n_taps -> [c0][n_taps*D]
+    for (int k = 0; k < c.n_taps; k++)
+        LCHK(launch_repack<T>(M(h, S("encoder.output_projections.%d.weight", k)), Pm<T>(h, "outproj.w") + (size_t)k * D, c0, 1, 1, D, D, 0, 0, 1,
+                              (long)c.n_taps * D, 0, 0, st));
+    // neck.in0: [c0][c0+2] -> [c0][c0]
+    LCHK(launch_repack<T>(M(h, "neck.input_blocks.0.weight"), Pm<T>(h, "neck.in0.w"), c0, 1, 1, c0, c0 + 2, 0, 0, 1, c0, 0, 0, st));
+    auto conv3 = [&](const float* w, T* dst, int co, int ci) -> int {
+        // torch [co][ci][3][3] -> [co][tap*ci + ci]
+        return launch_repack<T>(w, dst, co, 9, 1, ci, (long)ci * 9, 1, 0, 9, (long)9 * ci, ci, 0, st);
+    };
+    auto stack = [&](const std::string& name, bool neck, const int* nres) -> int {
+        for (int l = 0; l < MOGE_LEVELS; l++)
+            if (!neck) LCHK((launch_convert<float, T>(M(h, name + S(".input_blocks.%d.weight", l)), Pm<T>(h, name + S(".in%d.w", l)), (long)c.dims[l] * c.dims[l], st)));
+        for (int l = 0; l < MOGE_LEVELS - 1; l++) {
+            const int ci = c.dims[l], co = c.dims[l + 1];
+            if (l < 3) {
+                // ConvTranspose2d weight [ci][co][2][2] -> [(dy*2+dx)*co + o][ci]
+                LCHK(launch_repack<T>(M(h, name + S(".resamplers.%d.0.weight", l)), Pm<T>(h, name + S(".rs%d.wT", l)), 4, co, 1, ci, 1, 4, 0, (long)co * 4,
+                                      (long)co * ci, ci, 0, st));
+                LCHK(conv3(M(h, name + S(".resamplers.%d.1.weight", l)), Pm<T>(h, name + S(".rs%d.w3", l)), co, co));
+            } else {
+                LCHK(conv3(M(h, name + S(".resamplers.%d.1.weight", l)), Pm<T>(h, name + S(".rs%d.w3", l)), co, ci));
+            }
+        }
+        for (int l = 0; l < MOGE_LEVELS; l++)
+            for (int j = 0; j < nres[l]; j++) {
+                LCHK(conv3(M(h, name + S(".res_blocks.%d.%d.layers.2.weight", l, j)), Pm<T>(h, name + S(".res%d.%d.w1", l, j)), c.dims[l], c.dims[l]));
+                LCHK(conv3(M(h, name + S(".res_blocks.%d.%d.layers.5.weight", l, j)), Pm<T>(h, name + S(".res%d.%d.w2", l, j)), c.dims[l], c.dims[l]));
+            }
+        return 0;
+    };
+    CHK(stack("neck", true, c.neck_res_blocks));
+    for (int k = 0; k < 3; k++)
+        if (c.heads & HEAD_BITS[k]) CHK(stack(HEAD_NAMES[k], false, c.head_res_blocks));
+    h->pk_ready[pr] = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// workspace plan
+// ------------------------------------------------------------------------------------------------------------
+struct Plan {
+    size_t total = 0;
+    size_t patches, x, xn, q, k, vT, attn, hidden, tapcat, cls, mlp1, mlp2, metric, feat, neck[MOGE_LEVELS], scratch[3];
+    size_t maskprob, focal, shift, intr, pts_tmp, nrm_tmp;
+    int B, H, W, rows, cols, Np, Ntok, Npad;
+    size_t scratch_elems;
+};
+static size_t take(Plan& p, size_t bytes) {
+    const size_t off = p.total;
+    p.total += (bytes + 255) / 256 * 256;
+    return off;
+}
+static Plan make_plan(const moge_config& c, int prec, int B, int H, int W, int rows, int cols) {
+    Plan p;
+    const size_t s = prec == MOGE_FP16 ? 2 : 4;
+    const int D = c.embed_dim;
+    p.B = B; p.H = H; p.W = W; p.rows = rows; p.cols = cols;
+    p.Np = rows * cols; p.Ntok = p.Np + 1; p.Npad = (p.Ntok + 63) / 64 * 64;
+    const size_t BN = (size_t)B * p.Ntok, BP = (size_t)B * p.Np;
+    p.patches = take(p, BP * KPATCH_PAD * s);
+    p.x = take(p, BN * D * 4);
+    p.xn = take(p, BN * D * s);
+    p.q = take(p, BN * D * s);
+    p.k = take(p, BN * D * s);
+    p.vT = take(p, (size_t)B * D * p.Npad * s);
+    p.attn = take(p, BN * D * s);
+    p.hidden = take(p, BN * 4 * D * s);
+    p.tapcat = take(p, BP * c.n_taps * D * s);
+    p.cls = take(p, (size_t)B * D * 4);
+    p.mlp1 = take(p, (size_t)B * (c.scale_hidden > 0 ? c.scale_hidden : 1) * 4);
+    p.mlp2 = take(p, (size_t)B * (c.scale_hidden > 0 ? c.scale_hidden : 1) * 4);
+    p.metric = take(p, (size_t)B * 4);
+    p.feat = take(p, BP * c.dims[0] * s);
+    size_t mx = 0;
+    for (int l = 0; l < MOGE_LEVELS; l++) {
+        const size_t e = BP * ((size_t)1 << (2 * l)) * c.dims[l];
+        p.neck[l] = take(p, e * s);
+        if (e > mx) mx = e;
+    }
+    p.scratch_elems = mx;
+    for (int i = 0; i < 3; i++) p.scratch[i] = take(p, mx * s);
+    const size_t px = (size_t)B * H * W;
+    p.maskprob = take(p, px * 4);
+    p.pts_tmp = take(p, px * 12);
+    p.nrm_tmp = take(p, px * 12);
+    p.focal = take(p, (size_t)B * 4);
+    p.shift = take(p, (size_t)B * 4);
+    p.intr = take(p, (size_t)B * 36);
+    return p;
+}
+static int ensure_ws(moge_handle* h, size_t bytes) {
+    if (bytes <= h->ws_bytes) return 0;
+    if (h->ws) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
+    HIPCHK(hipMalloc(&h->ws, bytes));
+    h->ws_bytes = bytes;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// profiler
+// ------------------------------------------------------------------------------------------------------------
+static hipEvent_t ev_get(moge_handle* h) {
+    if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    moge_handle* h; hipStream_t st; ProfRec r; bool on;
+    ProfScope(moge_handle* h_, hipStream_t st_, int cls, double flops, double bytes) : h(h_), st(st_), on(h_->prof_on) {
+        if (on) { r.cls = cls; r.flops = flops; r.bytes = bytes; r.e0 = ev_get(h); r.e1 = ev_get(h); hipEventRecord(r.e0, st); }
+    }
+    ~ProfScope() { if (on) { hipEventRecord(r.e1, st); h->prof_pending.push_back(r); } }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------
+static GemmArgs gemm_args() { GemmArgs g; memset(&g, 0, sizeof(g)); return g; }
+
+static UVTerm uv_term(const float* wu, const float* wv, int pixW, int pixH, double aspect) {
+    UVTerm u;
+    const double sx = aspect / std::sqrt(1 + aspect * aspect), sy = 1 / std::sqrt(1 + aspect * aspect);
+    u.wu = wu; u.wv = wv;
+    u.u0 = (float)(-sx * (pixW - 1) / pixW); u.u1 = (float)(sx * (pixW - 1) / pixW);
+    u.v0 = (float)(-sy * (pixH - 1) / pixH); u.v1 = (float)(sy * (pixH - 1) / pixH);
+    u.ustep = pixW > 1 ? (u.u1 - u.u0) / (float)(pixW - 1) : 0.f;
+    u.vstep = pixH > 1 ? (u.v1 - u.v0) / (float)(pixH - 1) : 0.f;
+    return u;
+}
+
+template <typename T>
+static int run_gemm(moge_handle* h, const GemmArgs& g, int amode, int cls, hipStream_t st, double kalgo = 0) {
+    const double k = kalgo > 0 ? kalgo : (double)g.K;
+    const double flops = 2.0 * g.M * (double)g.N * k;
+    const double bytes = ((double)g.M * k + (double)g.N * k + (double)g.M * g.N) * sizeof(T);
+    ProfScope ps(h, st, cls, flops, bytes);
+    LCHK(launch_gemm<T>(g, amode, st));
+    return 0;
+}
+
+template <typename T>
+static int conv3x3(moge_handle* h, const T* in, const T* w, const float* bias, T* out, int B, int Hh, int Ww, int Cin, int Cout, int relu_in,
+                   int act, const T* add, const UVTerm* uv, bool up2, hipStream_t st) {
+    GemmArgs g = gemm_args();
+    g.a = in; g.H = Hh; g.W = Ww; g.C = Cin; g.relu_in = relu_in;
+    g.w = w; g.ldw = 9 * Cin;
+    g.M = B * Hh * Ww; g.N = Cout; g.K = 9 * Cin;
+    g.epi = EPI_STORE; g.act = act; g.bias = bias; g.out = out; g.ldc = Cout; g.add = add; g.ldadd = Cout;
+    g.pixW = Ww; g.pixH = Hh;
+    if (uv) g.uv = *uv;
+    return run_gemm<T>(h, g, up2 ? AMODE_CONV3_UP2 : AMODE_CONV3, MOGE_KC_CONV, st);
+}
+
+template <typename T>
+static int conv1x1(moge_handle* h, const T* in, const T* w, const float* bias, T* out, long Mrows, int Cin, int Cout, const T* add,
+                   const UVTerm* uv, int pixW, int pixH, hipStream_t st) {
+    GemmArgs g = gemm_args();
+    g.a = in; g.lda = Cin; g.w = w; g.ldw = Cin;
+    g.M = (int)Mrows; g.N = Cout; g.K = Cin;
+    g.epi = EPI_STORE; g.bias = bias; g.out = out; g.ldc = Cout; g.add = add; g.ldadd = Cout;
+    g.pixW = pixW; g.pixH = pixH;
+    if (uv) g.uv = *uv;
+    return run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_CONV, st);
+}
+
+template <typename T>
+static int convT2(moge_handle* h, const T* in, const T* w, const float* biasT, T* out, int B, int Hh, int Ww, int Cin, int Cout, hipStream_t st) {
+    GemmArgs g = gemm_args();
+    g.a = in; g.lda = Cin; g.w = w; g.ldw = Cin;
+    g.M = B * Hh * Ww; g.N = 4 * Cout; g.K = Cin;
+    g.epi = EPI_CONVT; g.bias = biasT; g.out = out; g.Cout = Cout; g.pixW = Ww; g.pixH = Hh;
+    return run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_CONV, st);
+}
+
+template <typename T>
+static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* x, T* tmp, int B, int Hh, int Ww, int C, hipStream_t st) {
+    for (int j = 0; j < n; j++) {
+        // x = x + conv2(relu(conv1(relu(x))))   (modules.py:47-68 with norms = Identity)
+        CHK(conv3x3<T>(h, x, P<T>(h, name + S(".res%d.%d.w1", l, j)), M(h, name + S(".res_blocks.%d.%d.layers.2.bias", l, j)), tmp, B, Hh, Ww, C, C, 1,
+                       ACT_RELU, nullptr, nullptr, false, st));
+        CHK(conv3x3<T>(h, tmp, P<T>(h, name + S(".res%d.%d.w2", l, j)), M(h, name + S(".res_blocks.%d.%d.layers.5.bias", l, j)), x, B, Hh, Ww, C, C, 0,
+                       ACT_NONE, x, nullptr, false, st));
+    }
+    return 0;
+}
+
+static int get_pos(moge_handle* h, int rows, int cols, hipStream_t st, const float** out) {
+    for (auto& e : h->pos_cache)
+        if (e.rows == rows && e.cols == cols) { *out = e.ptr; return 0; }
+    float* p;
+    HIPCHK(hipMalloc(&p, (size_t)(1 + rows * cols) * h->cfg.embed_dim * sizeof(float)));
+    LCHK(launch_posembed(M(h, "encoder.backbone.pos_embed"), p, h->cfg.embed_dim, rows, cols, st));
+    h->pos_cache.push_back({rows, cols, p});
+    *out = p;
+    return 0;
+}
+
+template <typename T>
+static int forward_impl(moge_handle* h, const void* image, int img_dtype, const Plan& pl, float* o_points, float* o_normal, float* o_maskprob,
+                        float* o_metric, hipStream_t st) {
+    const moge_config& c = h->cfg;
+    const int D = c.embed_dim, nh = c.num_heads, L = c.depth, c0 = c.dims[0];
+    const int B = pl.B, rows = pl.rows, cols = pl.cols, Np = pl.Np, Ntok = pl.Ntok, Npad = pl.Npad;
+    const double aspect = (double)pl.W / (double)pl.H;
+    char* ws = h->ws;
+    T* patches = (T*)(ws + pl.patches);
+    float* x = (float*)(ws + pl.x);
+    T* xn = (T*)(ws + pl.xn);
+    T* qb = (T*)(ws + pl.q);
+    T* kb = (T*)(ws + pl.k);
+    T* vT = (T*)(ws + pl.vT);
+    T* attn = (T*)(ws + pl.attn);
+    T* hidden = (T*)(ws + pl.hidden);
+    T* tapcat = (T*)(ws + pl.tapcat);
+    float* cls = (float*)(ws + pl.cls);
+    T* feat = (T*)(ws + pl.feat);
+    const std::string bb = "encoder.backbone.";
+    const long BN = (long)B * Ntok, BP = (long)B * Np;
+
+    // ---- K0: resize + normalise + patchify (modules.py:121-122, patch_embed.py:75) ------------------------------
+    const float* mean = h->img_mean; const float* sd = h->img_std;
+    {
+        ProfScope ps(h, st, MOGE_KC_PRE, 0, (double)B * 3 * pl.H * pl.W * (img_dtype ? 2 : 4) + (double)BP * KPATCH_PAD * sizeof(T));
+        LCHK(launch_zero_cols<T>(patches, BP, KPATCH_PAD, KPATCH, st));
+        if (img_dtype == 0) LCHK((launch_preprocess<float, T>(image, patches, B, pl.H, pl.W, rows, cols, KPATCH_PAD, 0, mean, sd, st)));
+        else LCHK((launch_preprocess<f16, T>(image, patches, B, pl.H, pl.W, rows, cols, KPATCH_PAD, 0, mean, sd, st)));
+    }
+    const float* pos;
+    CHK(get_pos(h, rows, cols, st, &pos));
+    LCHK(launch_cls_row(x, M(h, bb + "cls_token"), pos, B, Ntok, D, st));
+    {   // patch embed GEMM, epilogue adds bias + position embedding and writes the fp32 residual stream
+        GemmArgs g = gemm_args();
+        g.a = patches; g.lda = KPATCH_PAD; g.w = P<T>(h, "patch.w"); g.ldw = KPATCH_PAD;
+        g.M = (int)BP; g.N = D; g.K = KPATCH_PAD;
+        g.epi = EPI_PATCH; g.bias = M(h, bb + "patch_embed.proj.bias"); g.xres = x; g.pos = pos; g.Np = Np; g.Ntok = Ntok;
+        CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st, KPATCH));
+    }
+    HIPCHK(hipMemsetAsync(vT, 0, (size_t)B * D * Npad * sizeof(T), st));      // zero the key padding of V^T
+
+    // ---- ViT blocks (block.py:110-112) -----------------------------------------------------------------------------
+    int tap_k = 0;
+    for (int i = 0; i < L; i++) {
+        const std::string p = bb + S("blocks.%d.", i);
+        {
+            ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * D * (4 + sizeof(T)));
+            LCHK(launch_layernorm<T>(x, M(h, p + "norm1.weight"), M(h, p + "norm1.bias"), xn, nullptr, BN, D, D, 0, 0, Ntok, st));
+        }
+        {
+            GemmArgs g = gemm_args();
+            g.a = xn; g.lda = D; g.w = P<T>(h, S("blk%d.qkv", i)); g.ldw = D;
+            g.M = (int)BN; g.N = 3 * D; g.K = D;
+            g.epi = EPI_QKV; g.bias = M(h, p + "attn.qkv.bias"); g.q = qb; g.k = kb; g.vT = vT;
+            g.nh = nh; g.Npad = Npad; g.D = D; g.Ntok = Ntok;
+            g.qscale = 0.125f * 1.4426950408889634f;       // 1/sqrt(64) * log2(e): attention works in exp2
+            CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
+        }
+        {
+            ProfScope ps(h, st, MOGE_KC_ATTN, 4.0 * B * nh * (double)Ntok * Ntok * 64, (double)BN * D * 4 * sizeof(T));
+            LCHK(launch_attention<T>(qb, kb, vT, attn, B, nh, Ntok, Npad, st));
+        }
+        {
+            GemmArgs g = gemm_args();
+            g.a = attn; g.lda = D; g.w = P<T>(h, S("blk%d.proj", i)); g.ldw = D;
+            g.M = (int)BN; g.N = D; g.K = D;
+            g.epi = EPI_RESID; g.bias = M(h, p + "attn.proj.bias"); g.xres = x; g.ldc = D; g.gamma = M(h, p + "ls1.gamma");
+            CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
+        }
+        {
+            ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * D * (4 + sizeof(T)));
+            LCHK(launch_layernorm<T>(x, M(h, p + "norm2.weight"), M(h, p + "norm2.bias"), xn, nullptr, BN, D, D, 0, 0, Ntok, st));
+        }
+        {
+            GemmArgs g = gemm_args();
+            g.a = xn; g.lda = D; g.w = P<T>(h, S("blk%d.fc1", i)); g.ldw = D;
+            g.M = (int)BN; g.N = 4 * D; g.K = D;
+            g.epi = EPI_STORE; g.act = ACT_GELU; g.bias = M(h, p + "mlp.fc1.bias"); g.out = hidden; g.ldc = 4 * D;
+            CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
+        }
+        {
+            GemmArgs g = gemm_args();
+            g.a = hidden; g.lda = 4 * D; g.w = P<T>(h, S("blk%d.fc2", i)); g.ldw = 4 * D;
+            g.M = (int)BN; g.N = D; g.K = 4 * D;
+            g.epi = EPI_RESID; g.bias = M(h, p + "mlp.fc2.bias"); g.xres = x; g.ldc = D; g.gamma = M(h, p + "ls2.gamma");
+            CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
+        }
+        for (int k = 0; k < c.n_taps; k++)
+            if (c.taps[k] == i) {
+                // shared final LayerNorm on the tap, cls/patch split (vision_transformer.py:321-324); cls of the LAST tap only
+                ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * D * (4 + sizeof(T)));
+                LCHK(launch_layernorm<T>(x, M(h, bb + "norm.weight"), M(h, bb + "norm.bias"), tapcat, k == c.n_taps - 1 ? cls : nullptr, BN, D,
+                                         c.n_taps * D, k * D, 1, Ntok, st));
+                tap_k++;
+            }
+    }
+    if (tap_k != c.n_taps) return fail(MOGE_ERR_INVALID, "intermediate_layers must be distinct block indices < depth");
+    {   // sum_k Conv1x1_k(tap_k) == one GEMM over K = n_taps*D (modules.py:128-131)
+        GemmArgs g = gemm_args();
+        g.a = tapcat; g.lda = c.n_taps * D; g.w = P<T>(h, "outproj.w"); g.ldw = c.n_taps * D;
+        g.M = (int)BP; g.N = c0; g.K = c.n_taps * D;
+        g.epi = EPI_STORE; g.bias = A(h, "outproj.bias"); g.out = feat; g.ldc = c0;
+        CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
+    }
+    // ---- scale head (modules.py:184-192, v2.py:167,182) ---------------------------------------------------------
+    if ((c.heads & MOGE_HEAD_SCALE) && o_metric) {
+        float* m1 = (float*)(ws + pl.mlp1); float* m2 = (float*)(ws + pl.mlp2);
+        ProfScope ps(h, st, MOGE_KC_POST, 0, 0);
+        LCHK(launch_mlp_layer(cls, M(h, "scale_head.0.weight"), M(h, "scale_head.0.bias"), m1, B, D, c.scale_hidden, 1, st));
+        LCHK(launch_mlp_layer(m1, M(h, "scale_head.2.weight"), M(h, "scale_head.2.bias"), m2, B, c.scale_hidden, c.scale_hidden, 1, st));
+        LCHK(launch_mlp_layer(m2, M(h, "scale_head.4.weight"), M(h, "scale_head.4.bias"), o_metric, B, c.scale_hidden, 1, 2, st));
+    }
+
+    // ---- neck (modules.py:242-254; level-0 uv concat folded into a rank-2 epilogue term, v2.py:154-160) -----------
+    T* N[MOGE_LEVELS];
+    for (int l = 0; l < MOGE_LEVELS; l++) N[l] = (T*)(ws + pl.neck[l]);
+    T* Sc[3] = {(T*)(ws + pl.scratch[0]), (T*)(ws + pl.scratch[1]), (T*)(ws + pl.scratch[2])};
+    {
+        UVTerm uv = uv_term(A(h, "neck.in0.wu"), A(h, "neck.in0.wv"), cols, rows, aspect);
+        CHK(conv1x1<T>(h, feat, P<T>(h, "neck.in0.w"), M(h, "neck.input_blocks.0.bias"), N[0], BP, c0, c0, nullptr, &uv, cols, rows, st));
+        CHK(res_blocks<T>(h, "neck", 0, c.neck_res_blocks[0], N[0], Sc[0], B, rows, cols, c0, st));
+        for (int l = 1; l < MOGE_LEVELS; l++) {
+            const int Hh = rows << l, Ww = cols << l, ci = c.dims[l - 1], co = c.dims[l];
+            UVTerm uvl = uv_term(A(h, S("neck.in%d.wu", l)), A(h, S("neck.in%d.wv", l)), Ww, Hh, aspect);
+            if (l <= 3) {
+                CHK(convT2<T>(h, N[l - 1], P<T>(h, S("neck.rs%d.wT", l - 1)), A(h, S("neck.rs%d.biasT", l - 1)), Sc[0], B, Hh / 2, Ww / 2, ci, co, st));
+                CHK(conv3x3<T>(h, Sc[0], P<T>(h, S("neck.rs%d.w3", l - 1)), A(h, S("neck.rs%d.bias2", l - 1)), N[l], B, Hh, Ww, co, co, 0, ACT_NONE, nullptr,
+                               &uvl, false, st));
+            } else {
+                CHK(conv3x3<T>(h, N[l - 1], P<T>(h, S("neck.rs%d.w3", l - 1)), A(h, S("neck.rs%d.bias2", l - 1)), N[l], B, Hh, Ww, ci, co, 0, ACT_NONE, nullptr,
+                               &uvl, true, st));
+            }
+            CHK(res_blocks<T>(h, "neck", l, c.neck_res_blocks[l], N[l], Sc[1], B, Hh, Ww, co, st));
+        }
+    }
+    // ---- heads -------------------------------------------------------------------------------------------------------
+    float* outs[3] = {o_points, o_normal, o_maskprob};
+    for (int k = 0; k < 3; k++) {
+        if (!(c.heads & HEAD_BITS[k]) || !outs[k]) continue;
+        const std::string name = HEAD_NAMES[k];
+        int cur = 0;                       // Sc[cur] holds the running x
+        CHK(conv1x1<T>(h, N[0], P<T>(h, name + ".in0.w"), M(h, name + ".input_blocks.0.bias"), Sc[cur], BP, c0, c0, nullptr, nullptr, cols, rows, st));
+        CHK(res_blocks<T>(h, name, 0, c.head_res_blocks[0], Sc[cur], Sc[(cur + 1) % 3], B, rows, cols, c0, st));
+        for (int l = 1; l < MOGE_LEVELS; l++) {
+            const int Hh = rows << l, Ww = cols << l, ci = c.dims[l - 1], co = c.dims[l];
+            const int a = (cur + 1) % 3, b2 = (cur + 2) % 3;
+            int nxt;
+            if (l <= 3) {
+                CHK(convT2<T>(h, Sc[cur], P<T>(h, name + S(".rs%d.wT", l - 1)), A(h, name + S(".rs%d.biasT", l - 1)), Sc[a], B, Hh / 2, Ww / 2, ci, co, st));
+                CHK(conv3x3<T>(h, Sc[a], P<T>(h, name + S(".rs%d.w3", l - 1)), M(h, name + S(".resamplers.%d.1.bias", l - 1)), Sc[b2], B, Hh, Ww, co, co, 0,
+                               ACT_NONE, nullptr, nullptr, false, st));
+                nxt = b2;
+            } else {
+                CHK(conv3x3<T>(h, Sc[cur], P<T>(h, name + S(".rs%d.w3", l - 1)), M(h, name + S(".resamplers.%d.1.bias", l - 1)), Sc[a], B, Hh, Ww, ci, co, 0,
+                               ACT_NONE, nullptr, nullptr, true, st));
+                nxt = a;
+            }
+            // x = x + in_l(neck_l)   (in place: each element is read and written by the same lane)
+            CHK(conv1x1<T>(h, N[l], P<T>(h, name + S(".in%d.w", l)), M(h, name + S(".input_blocks.%d.bias", l)), Sc[nxt], (long)B * Hh * Ww, co, co, Sc[nxt],
+                           nullptr, Ww, Hh, st));
+            cur = nxt;
+            CHK(res_blocks<T>(h, name, l, c.head_res_blocks[l], Sc[cur], Sc[(cur + 1) % 3], B, Hh, Ww, co, st));
+        }
+        {
+            ProfScope ps(h, st, MOGE_KC_POST, 0, (double)B * (rows << 4) * (cols << 4) * c.dims[4] * sizeof(T));
+            LCHK(launch_head_final<T>(k, Sc[cur], M(h, name + ".output_blocks.4.weight"), M(h, name + ".output_blocks.4.bias"), outs[k], B, rows << 4,
+                                      cols << 4, c.dims[4], pl.H, pl.W, c.remap_output, st));
+        }
+    }
+    // remember buffers for debug taps
+    h->last.valid = true; h->last.prec = TT<T>::PREC; h->last.B = B; h->last.rows = rows; h->last.cols = cols;
+    h->last.bufs.clear();
+    h->last.bufs["x_final"] = {pl.x, {(int64_t)BN * D, 0}};
+    h->last.bufs["tapcat"] = {pl.tapcat, {(int64_t)BP * c.n_taps * D, 1}};
+    h->last.bufs["cls"] = {pl.cls, {(int64_t)B * D, 0}};
+    h->last.bufs["features"] = {pl.feat, {(int64_t)BP * c0, 1}};
+    for (int l = 0; l < MOGE_LEVELS; l++) h->last.bufs[S("neck%d", l)] = {pl.neck[l], {(int64_t)BP * ((int64_t)1 << (2 * l)) * c.dims[l], 1}};
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int moge_abi_version(void) { return MOGE_ABI_VERSION; }
+const char* moge_last_error(void) { return g_err.c_str(); }
+
+int moge_create(const moge_config* cfg, int device, moge_handle** out) {
+    if (!cfg || !out) return fail(MOGE_ERR_INVALID, "null argument");
+    const moge_config& c = *cfg;
+    if (c.embed_dim % 128 != 0 || c.embed_dim > 1024 || c.embed_dim != c.num_heads * 64)
+        return fail(MOGE_ERR_INVALID, "unsupported ViT width %d / heads %d (need head_dim 64, width %%128==0, <=1024)", c.embed_dim, c.num_heads);
+    if (c.n_taps < 1 || c.n_taps > MOGE_MAX_TAPS) return fail(MOGE_ERR_INVALID, "bad n_taps");
+    for (int l = 0; l < MOGE_LEVELS; l++)
+        if (c.dims[l] % 8 != 0 || c.dims[l] <= 0) return fail(MOGE_ERR_INVALID, "stack dims must be positive multiples of 8");
+    if (c.dims[4] > 64) return fail(MOGE_ERR_INVALID, "last level wider than 64 channels is not supported");
+    if ((c.heads & MOGE_HEAD_SCALE) && (c.scale_hidden <= 0 || c.scale_hidden % 4 != 0)) return fail(MOGE_ERR_INVALID, "bad scale_hidden");
+    HIPCHK(hipSetDevice(device));
+    moge_handle* h = new moge_handle();
+    h->cfg = c;
+    h->device = device;
+    memset(&h->prof_acc, 0, sizeof(h->prof_acc));
+    build_tables(h);
+    hipError_t e = hipMalloc(&h->d_status, sizeof(int));
+    if (e != hipSuccess) { delete h; return fail(MOGE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    hipMemset(h->d_status, 0, sizeof(int));
+    *out = h;
+    return 0;
+}
+
+void moge_destroy(moge_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    if (h->master) hipFree(h->master);
+    if (h->aux) hipFree(h->aux);
+    for (int i = 0; i < 2; i++) if (h->packed[i]) hipFree(h->packed[i]);
+    if (h->ws) hipFree(h->ws);
+    for (auto& e : h->pos_cache) hipFree(e.ptr);
+    if (h->d_status) hipFree(h->d_status);
+    for (auto& r : h->prof_pending) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto e : h->ev_pool) hipEventDestroy(e);
+    delete h;
+}
+
+int moge_alloc_master(moge_handle* h) {
+    if (!h) return fail(MOGE_ERR_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->master) {
+        HIPCHK(hipMalloc(&h->master, h->master_floats * sizeof(float)));
+        HIPCHK(hipMemset(h->master, 0, h->master_floats * sizeof(float)));
+    }
+    return 0;
+}
+
+int moge_master_blob(moge_handle* h, void** dev_ptr, size_t* bytes) {
+    if (!h || !h->master) return fail(MOGE_ERR_NOT_LOADED, "master blob not allocated");
+    if (dev_ptr) *dev_ptr = h->master;
+    if (bytes) *bytes = h->master_floats * sizeof(float);
+    return 0;
+}
+
+int moge_master_ready(moge_handle* h) {
+    if (!h || !h->master) return fail(MOGE_ERR_NOT_LOADED, "master blob not allocated");
+    HIPCHK(hipMemcpy(h->img_mean, M(h, "encoder.image_mean"), 3 * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h->img_std, M(h, "encoder.image_std"), 3 * sizeof(float), hipMemcpyDeviceToHost));
+    h->master_ready = true;
+    h->aux_ready = false; h->pk_ready[0] = h->pk_ready[1] = false;
+    for (auto& e : h->pos_cache) hipFree(e.ptr);
+    h->pos_cache.clear();
+    return 0;
+}
+
+int moge_load_weights(moge_handle* h, const moge_tensor_desc* descs, int n, void* stream) {
+    if (!h || !descs) return fail(MOGE_ERR_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    CHK(moge_alloc_master(h));
+    for (auto& kv : h->table) kv.second.loaded = false;
+    for (int i = 0; i < n; i++) {
+        auto it = h->table.find(descs[i].name ? descs[i].name : "");
+        if (it == h->table.end()) continue;                      // strict=False
+        if (it->second.numel != descs[i].numel)
+            return fail(MOGE_ERR_INVALID, "tensor %s has %lld elements, config expects %lld", descs[i].name, (long long)descs[i].numel, (long long)it->second.numel);
+        HIPCHK(hipMemcpyAsync(h->master + it->second.off, descs[i].data, (size_t)descs[i].numel * sizeof(float), hipMemcpyHostToDevice, st));
+        it->second.loaded = true;
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    for (auto& kv : h->table)
+        if (!kv.second.loaded) return fail(MOGE_ERR_MISSING_KEY, "state dict is missing %s", kv.first.c_str());
+    return moge_master_ready(h);
+}
+
+int moge_set_precision(moge_handle* h, int precision, void* stream) {
+    if (!h) return fail(MOGE_ERR_INVALID, "null handle");
+    if (precision != MOGE_FP32 && precision != MOGE_FP16) return fail(MOGE_ERR_INVALID, "bad precision");
+    if (!h->master_ready) return fail(MOGE_ERR_NOT_LOADED, "weights not loaded");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    CHK(build_aux(h, st));
+    if (precision == MOGE_FP16) CHK(pack_weights<f16>(h, st)); else CHK(pack_weights<float>(h, st));
+    h->prec = precision;
+    return 0;
+}
+
+int moge_workspace_bytes(moge_handle* h, int B, int H, int W, int token_rows, int token_cols, size_t* bytes) {
+    if (!h || !bytes) return fail(MOGE_ERR_INVALID, "null argument");
+    *bytes = make_plan(h->cfg, h->prec, B, H, W, token_rows, token_cols).total;
+    return 0;
+}
+
+static int check_call(moge_handle* h, const void* image, int B, int H, int W, int rows, int cols) {
+    if (!h || !image) return fail(MOGE_ERR_INVALID, "null argument");
+    if (!h->master_ready) return fail(MOGE_ERR_NOT_LOADED, "weights not loaded");
+    if (B <= 0 || H <= 0 || W <= 0 || rows <= 0 || cols <= 0) return fail(MOGE_ERR_INVALID, "bad shape");
+    if ((long)B * rows * cols * 256 > 2000000000L) return fail(MOGE_ERR_INVALID, "batch too large for 32-bit pixel indices");
+    HIPCHK(hipSetDevice(h->device));
+    return 0;
+}
+
+static int forward_dispatch(moge_handle* h, const void* image, int img_dtype, const Plan& pl, float* pts, float* nrm, float* mp, float* metric, hipStream_t st) {
+    if (!h->pk_ready[h->prec]) CHK(moge_set_precision(h, h->prec, st));
+    CHK(ensure_ws(h, pl.total));
+    if (h->prec == MOGE_FP16) return forward_impl<f16>(h, image, img_dtype, pl, pts, nrm, mp, metric, st);
+    return forward_impl<float>(h, image, img_dtype, pl, pts, nrm, mp, metric, st);
+}
+
+int moge_forward(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int rows, int cols, const moge_outputs* out, void* stream) {
+    CHK(check_call(h, image, B, H, W, rows, cols));
+    if (!out) return fail(MOGE_ERR_INVALID, "null outputs");
+    hipStream_t st = (hipStream_t)stream;
+    Plan pl = make_plan(h->cfg, h->prec, B, H, W, rows, cols);
+    return forward_dispatch(h, image, img_dtype, pl, out->points, out->normal, out->mask_prob, out->metric_scale, st);
+}
+
+static int post_impl(moge_handle* h, const Plan& pl, const float* pts_in, const float* nrm_in, const float* mp, const float* metric, const float* fov,
+                     int flags, const moge_outputs* out, hipStream_t st) {
+    const int B = pl.B, H = pl.H, W = pl.W;
+    float* focal = out->focal ? out->focal : (float*)(h->ws + pl.focal);
+    float* shift = out->shift ? out->shift : (float*)(h->ws + pl.shift);
+    float* intr = out->intrinsics ? out->intrinsics : (float*)(h->ws + pl.intr);
+    {
+        ProfScope ps(h, st, MOGE_KC_RECOVER, 0, (double)B * 4096 * 16);
+        LCHK(launch_recover(pts_in, mp, nullptr, fov, nullptr, B, H, W, focal, shift, intr, h->d_status, st));
+    }
+    {
+        const size_t px = (size_t)B * H * W;
+        ProfScope ps(h, st, MOGE_KC_POST, 0, (double)px * (12 + 12 + 4 + 12 + 4 + 12 + 1));
+        LCHK(launch_finalize(pts_in, nrm_in, mp, metric, shift, intr, B, H, W, flags, out->points, out->depth, out->normal, out->mask, st));
+    }
+    return 0;
+}
+
+int moge_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int rows, int cols, const float* fov_x_deg, int flags,
+               const moge_outputs* out, void* stream) {
+    CHK(check_call(h, image, B, H, W, rows, cols));
+    if (!out) return fail(MOGE_ERR_INVALID, "null outputs");
+    const moge_config& c = h->cfg;
+    if (!(c.heads & MOGE_HEAD_POINTS)) return fail(MOGE_ERR_INVALID, "infer needs a points head");
+    if (!out->points || !out->depth) return fail(MOGE_ERR_INVALID, "points and depth output buffers are required");
+    hipStream_t st = (hipStream_t)stream;
+    Plan pl = make_plan(c, h->prec, B, H, W, rows, cols);
+    CHK(ensure_ws(h, pl.total));
+    float* mp = (c.heads & MOGE_HEAD_MASK) ? (out->mask_prob ? out->mask_prob : (float*)(h->ws + pl.maskprob)) : nullptr;
+    float* nrm = (c.heads & MOGE_HEAD_NORMAL) ? out->normal : nullptr;
+    float* metric = (c.heads & MOGE_HEAD_SCALE) ? (out->metric_scale ? out->metric_scale : (float*)(h->ws + pl.metric)) : nullptr;
+    CHK(forward_dispatch(h, image, img_dtype, pl, out->points, nrm, mp, metric, st));
+    return post_impl(h, pl, out->points, nrm, mp, metric, fov_x_deg, flags, out, st);
+}
+
+int moge_postprocess(moge_handle* h, const float* points_in, const float* normal_in, const float* mask_prob_in, const float* metric_scale_in,
+                     int B, int H, int W, const float* fov_x_deg, int flags, const moge_outputs* out, void* stream) {
+    if (!h || !points_in || !out || !out->points || !out->depth) return fail(MOGE_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    Plan pl;
+    pl.B = B; pl.H = H; pl.W = W;
+    pl.focal = take(pl, (size_t)B * 4); pl.shift = take(pl, (size_t)B * 4); pl.intr = take(pl, (size_t)B * 36);
+    CHK(ensure_ws(h, pl.total));
+    return post_impl(h, pl, points_in, normal_in, mask_prob_in, metric_scale_in, fov_x_deg, flags, out, st);
+}
+
+int moge_sync(moge_handle* h, void* stream) {
+    if (!h) return fail(MOGE_ERR_INVALID, "null handle");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    int stv = 0;
+    HIPCHK(hipMemcpy(&stv, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (stv != 0) {
+        HIPCHK(hipMemset(h->d_status, 0, sizeof(int)));
+        return fail(stv, "Residuals are not finite in the initial point.");
+    }
+    return 0;
+}
+
+int moge_profile_enable(moge_handle* h, int on) {
+    if (!h) return fail(MOGE_ERR_INVALID, "null handle");
+    h->prof_on = on != 0;
+    return 0;
+}
+
+int moge_profile_read(moge_handle* h, moge_profile* out, int reset) {
+    if (!h || !out) return fail(MOGE_ERR_INVALID, "null argument");
+    for (auto& r : h->prof_pending) {
+        HIPCHK(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        h->prof_acc.ms[r.cls] += ms;
+        h->prof_acc.flops[r.cls] += r.flops;
+        h->prof_acc.bytes[r.cls] += r.bytes;
+        h->prof_acc.launches[r.cls] += 1;
+        h->ev_pool.push_back(r.e0);
+        h->ev_pool.push_back(r.e1);
+    }
+    h->prof_pending.clear();
+    *out = h->prof_acc;
+    if (reset) memset(&h->prof_acc, 0, sizeof(h->prof_acc));
+    return 0;
+}
+
+int moge_debug_tap(moge_handle* h, const char* name, float* dst, int64_t cap, int64_t* numel, void* stream) {
+    if (!h || !name) return fail(MOGE_ERR_INVALID, "null argument");
+    if (!h->last.valid) return fail(MOGE_ERR_INVALID, "no forward has run");
+    auto it = h->last.bufs.find(name);
+    if (it == h->last.bufs.end()) return fail(MOGE_ERR_INVALID, "unknown tap %s", name);
+    const int64_t n = it->second.second.first;
+    if (numel) *numel = n;
+    if (!dst) return 0;
+    if (cap < n) return fail(MOGE_ERR_INVALID, "tap buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    const char* src = h->ws + it->second.first;
+    if (it->second.second.second == 0 || h->last.prec == MOGE_FP32) LCHK((launch_convert<float, float>(src, dst, n, st)));
+    else LCHK((launch_convert<f16, float>(src, dst, n, st)));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+// Per-kernel test entry points of the C ABI (include/moge_hip.h, "moge_test_*").  tests/ only: they allocate
+// temporaries with hipMalloc, convert fp32 <-> storage type around the kernel under test and synchronise.
+#include "launchers.h"
+#include "../../include/moge_hip.h"
+#include <vector>
+#include <cstring>
+#include <cstdio>
+
+#define TCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "moge_test: %s -> %s\n", #x, hipGetErrorString(e_)); return MOGE_ERR_HIP; } } while (0)
+#define TL(x) do { int e_ = (x); if (e_ != 0) { fprintf(stderr, "moge_test: %s -> launch error %d\n", #x, e_); return e_ < 0 ? MOGE_ERR_INVALID : MOGE_ERR_HIP; } } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+
+template <typename T> static int to_t(const float* src, void* dst, long n, hipStream_t st) { return launch_convert<float, T>(src, dst, n, st); }
+template <typename T> static int from_t(const void* src, float* dst, long n, hipStream_t st);
+template <> int from_t<f16>(const void* src, float* dst, long n, hipStream_t st) { return launch_convert<f16, float>(src, dst, n, st); }
+template <> int from_t<float>(const void* src, float* dst, long n, hipStream_t st) { return launch_convert<float, float>(src, dst, n, st); }
+
+template <typename T>
+static int t_gemm(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act, hipStream_t st) {
+    const int CH = TT<T>::CH;
+    const int Kp = (K + CH - 1) / CH * CH;
+    DevBuf a, w, c;
+    TCHK(a.alloc((size_t)M * Kp * sizeof(T))); TCHK(w.alloc((size_t)N * Kp * sizeof(T))); TCHK(c.alloc((size_t)M * N * sizeof(T)));
+    TCHK(hipMemsetAsync(a.p, 0, (size_t)M * Kp * sizeof(T), st)); TCHK(hipMemsetAsync(w.p, 0, (size_t)N * Kp * sizeof(T), st));
+    TL(launch_repack<T>(A, a.p, M, 1, 1, K, K, 0, 0, 1, Kp, 0, 0, st));
+    TL(launch_repack<T>(W, w.p, N, 1, 1, K, K, 0, 0, 1, Kp, 0, 0, st));
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.a = a.p; g.lda = Kp; g.w = w.p; g.ldw = Kp; g.M = M; g.N = N; g.K = Kp;
+    g.epi = EPI_STORE; g.act = act; g.bias = bias; g.out = c.p; g.ldc = N;
+    TL(launch_gemm<T>(g, AMODE_LINEAR, st));
+    TL(from_t<T>(c.p, C, (long)M * N, st));
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+template <typename T>
+static int t_attention(const float* q, const float* k, const float* v, float* o, int B, int nh, int N, hipStream_t st) {
+    const int Npad = (N + 63) / 64 * 64;
+    const size_t n = (size_t)B * nh * N * 64;
+    DevBuf qb, kb, vb, ob, qs;
+    TCHK(qb.alloc(n * sizeof(T))); TCHK(kb.alloc(n * sizeof(T))); TCHK(vb.alloc((size_t)B * nh * 64 * Npad * sizeof(T))); TCHK(ob.alloc(n * sizeof(T)));
+    TCHK(qs.alloc(n * sizeof(float)));
+    TCHK(hipMemsetAsync(vb.p, 0, (size_t)B * nh * 64 * Npad * sizeof(T), st));
+    // q pre-scale by log2(e)/8 (what the QKV epilogue does): reuse repack with a scaled copy through host-free path
+    {
+        std::vector<float> hq(n);
+        TCHK(hipMemcpyAsync(hq.data(), q, n * sizeof(float), hipMemcpyDeviceToHost, st));
+        TCHK(hipStreamSynchronize(st));
+        const float sc = 0.125f * 1.4426950408889634f;
+        for (auto& x : hq) x *= sc;
+        TCHK(hipMemcpyAsync(qs.p, hq.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
+        TCHK(hipStreamSynchronize(st));
+    }
+    TL(to_t<T>((const float*)qs.p, qb.p, (long)n, st));
+    TL(to_t<T>(k, kb.p, (long)n, st));
+    // v (B*nh, N, 64) -> vT (B*nh, 64, Npad)
+    TL(launch_repack<T>(v, vb.p, B * nh, 64, 1, N, (long)N * 64, 1, 0, 64, (long)64 * Npad, Npad, 0, st));
+    TL(launch_attention<T>(qb.p, kb.p, vb.p, ob.p, B, nh, N, Npad, st));
+    TL(from_t<T>(ob.p, o, (long)n, st));
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+template <typename T>
+static int t_conv3(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int relu_in, int up2, hipStream_t st) {
+    // for up2, (H,W) are the INPUT dims and the output is (2H,2W)
+    const int Ho = up2 ? 2 * H : H, Wo = up2 ? 2 * W : W;
+    DevBuf xb, wb, yb;
+    const size_t nx = (size_t)B * H * W * Cin, ny = (size_t)B * Ho * Wo * Cout;
+    TCHK(xb.alloc(nx * sizeof(T))); TCHK(wb.alloc((size_t)Cout * 9 * Cin * sizeof(T))); TCHK(yb.alloc(ny * sizeof(T)));
+    TL(to_t<T>(x, xb.p, (long)nx, st));
+    TL(launch_repack<T>(w, wb.p, Cout, 9, 1, Cin, (long)Cin * 9, 1, 0, 9, (long)9 * Cin, Cin, 0, st));
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.a = xb.p; g.H = Ho; g.W = Wo; g.C = Cin; g.relu_in = relu_in;
+    g.w = wb.p; g.ldw = 9 * Cin; g.M = B * Ho * Wo; g.N = Cout; g.K = 9 * Cin;
+    g.epi = EPI_STORE; g.bias = bias; g.out = yb.p; g.ldc = Cout; g.pixW = Wo; g.pixH = Ho;
+    TL(launch_gemm<T>(g, up2 ? AMODE_CONV3_UP2 : AMODE_CONV3, st));
+    TL(from_t<T>(yb.p, y, (long)ny, st));
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+template <typename T>
+static int t_convt(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+    DevBuf xb, wb, yb, bb;
+    const size_t nx = (size_t)B * H * W * Cin, ny = (size_t)B * 4 * H * W * Cout;
+    TCHK(xb.alloc(nx * sizeof(T))); TCHK(wb.alloc((size_t)4 * Cout * Cin * sizeof(T))); TCHK(yb.alloc(ny * sizeof(T))); TCHK(bb.alloc(4 * Cout * sizeof(float)));
+    TL(to_t<T>(x, xb.p, (long)nx, st));
+    TL(launch_repack<T>(w, wb.p, 4, Cout, 1, Cin, 1, 4, 0, (long)Cout * 4, (long)Cout * Cin, Cin, 0, st));
+    TL(launch_repack<float>(bias, bb.p, 4, 1, 1, Cout, 0, 0, 0, 1, Cout, 0, 0, st));
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.a = xb.p; g.lda = Cin; g.w = wb.p; g.ldw = Cin; g.M = B * H * W; g.N = 4 * Cout; g.K = Cin;
+    g.epi = EPI_CONVT; g.bias = (const float*)bb.p; g.out = yb.p; g.Cout = Cout; g.pixW = W; g.pixH = H;
+    TL(launch_gemm<T>(g, AMODE_LINEAR, st));
+    TL(from_t<T>(yb.p, y, (long)ny, st));
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" {
+
+int moge_test_gemm(int precision, const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    return precision == MOGE_FP16 ? t_gemm<f16>(A, W, bias, C, M, N, K, act, st) : t_gemm<float>(A, W, bias, C, M, N, K, act, st);
+}
+
+int moge_test_layernorm(int precision, const float* x, const float* w, const float* b, float* y, int rows, int D, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (precision == MOGE_FP16) {
+        DevBuf yb;
+        TCHK(yb.alloc((size_t)rows * D * sizeof(f16)));
+        TL(launch_layernorm<f16>(x, w, b, yb.p, nullptr, rows, D, D, 0, 0, 1, st));
+        TL((launch_convert<f16, float>(yb.p, y, (long)rows * D, st)));
+    } else {
+        TL(launch_layernorm<float>(x, w, b, y, nullptr, rows, D, D, 0, 0, 1, st));
+    }
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int moge_test_attention(int precision, const float* q, const float* k, const float* v, float* o, int B, int nh, int N, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    return precision == MOGE_FP16 ? t_attention<f16>(q, k, v, o, B, nh, N, st) : t_attention<float>(q, k, v, o, B, nh, N, st);
+}
+
+int moge_test_conv3x3(int precision, const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int relu_in,
+                      void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int up2 = (relu_in >> 1) & 1, relu = relu_in & 1;      // bit 1 of relu_in selects the fused bilinear x2 loader
+    return precision == MOGE_FP16 ? t_conv3<f16>(x, w, bias, y, B, H, W, Cin, Cout, relu, up2, st) : t_conv3<float>(x, w, bias, y, B, H, W, Cin, Cout, relu, up2, st);
+}
+
+int moge_test_convt2x2(int precision, const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    return precision == MOGE_FP16 ? t_convt<f16>(x, w, bias, y, B, H, W, Cin, Cout, st) : t_convt<float>(x, w, bias, y, B, H, W, Cin, Cout, st);
+}
+
+int moge_test_preprocess(const float* image, float* out, int B, int H, int W, int rows, int cols, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+    TL((launch_preprocess<float, float>(image, out, B, H, W, rows, cols, 0, 1, mean, sd, st)));
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int moge_test_posembed(const float* pos, float* out, int D, int rows, int cols, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    TL(launch_posembed(pos, out, D, rows, cols, st));
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int moge_test_recover(const float* points, const uint8_t* mask, const float* focal_in, int B, int H, int W, float* focal, float* shift,
+                      int32_t* status, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    TL(launch_recover(points, nullptr, mask, nullptr, focal_in, B, H, W, focal, shift, nullptr, status, st));
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,365 @@
+"""Host-side mirror of the reference's `moge.model.v2.MoGeModel` (moge/model/v2.py:22-303) on top of the C ABI.
+
+Same names, argument meaning and error behaviour as the reference for the inference surface:
+`from_pretrained`, `.to/.cuda/.eval/.half/.float`, `.device`, `.dtype`, `.num_tokens_range`, `forward`, `infer`.
+All arithmetic happens in libmoge_hip.so; this file only resolves shapes (token grid: v2.py:142-147, default
+num_tokens: v2.py:236-238), owns the output tensors and translates status codes into the reference's exceptions."""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+from numbers import Number
+from pathlib import Path
+from typing import IO, Any, Dict, List, Optional, Union
+
+import torch
+
+from .. import _lib as L
+
+_VIT = {"dinov2_vits14": (384, 12, 6), "dinov2_vitb14": (768, 12, 12), "dinov2_vitl14": (1024, 24, 16)}
+_RESAMPLERS = ["conv_transpose", "conv_transpose", "conv_transpose", "bilinear"]
+_HEADS = [("points_head", L.HEAD_POINTS, 3), ("normal_head", L.HEAD_NORMAL, 3), ("mask_head", L.HEAD_MASK, 1)]
+
+
+def _check_stack(name: str, sc: Dict[str, Any], dims: List[int], neck: bool) -> List[int]:
+    if list(sc["dim_res_blocks"]) != list(dims):
+        raise NotImplementedError(f"{name}: dim_res_blocks must equal the neck's ({dims})")
+    res = sc.get("resamplers", "conv_transpose")
+    if list(res) != _RESAMPLERS:
+        raise NotImplementedError(f"{name}: only resamplers {_RESAMPLERS} (the released MoGe-2 layout) are implemented, got {res}")
+    if sc.get("res_block_in_norm", "layer_norm") != "none" or sc.get("res_block_hidden_norm", "group_norm") != "none":
+        raise NotImplementedError(f"{name}: only res_block_*_norm='none' is implemented")
+    if sc.get("activation", "relu") != "relu" or sc.get("dim_times_res_block_hidden", 1) != 1:
+        raise NotImplementedError(f"{name}: only ReLU res blocks with hidden = dim are implemented")
+    nres = sc.get("num_res_blocks", 1)
+    nres = list(nres) if isinstance(nres, (list, tuple)) else [nres] * 5
+    dim_in = list(sc["dim_in"])
+    want_in = [dims[0] + 2, 2, 2, 2, 2] if neck else list(dims)
+    if dim_in != want_in:
+        raise NotImplementedError(f"{name}: dim_in {dim_in} unsupported (expected {want_in})")
+    dim_out = sc.get("dim_out")
+    dim_out = list(dim_out) if isinstance(dim_out, (list, tuple)) else [dim_out] * 5
+    if neck and any(d is not None for d in dim_out):
+        raise NotImplementedError("neck.dim_out must be null")
+    return nres
+
+
+class MoGeModel:
+    """MI355X drop-in for moge.model.v2.MoGeModel (inference only)."""
+
+    def __init__(self, encoder: Dict[str, Any], neck: Dict[str, Any], points_head: Dict[str, Any] = None,
+                 mask_head: Dict[str, Any] = None, normal_head: Dict[str, Any] = None, scale_head: Dict[str, Any] = None,
+                 remap_output: str = "linear", num_tokens_range: List[int] = [1200, 3600], **deprecated_kwargs):
+        if deprecated_kwargs:
+            warnings.warn(f"The following deprecated/invalid arguments are ignored: {deprecated_kwargs}")
+        if remap_output not in L.REMAP:
+            raise ValueError(f"Invalid remap output type: {remap_output}")
+        backbone = encoder["backbone"]
+        if backbone not in _VIT:
+            raise NotImplementedError(f"backbone {backbone} is not supported (ViT-S/B/L-14 only)")
+        D, depth, heads = _VIT[backbone]
+        taps = encoder["intermediate_layers"]
+        taps = list(range(depth - taps, depth)) if isinstance(taps, int) else list(taps)
+        dims = list(neck["dim_res_blocks"])
+        if encoder["dim_out"] != dims[0] or len(dims) != 5:
+            raise NotImplementedError("encoder.dim_out must equal neck.dim_res_blocks[0]; 5 levels")
+        self.remap_output = remap_output
+        self.num_tokens_range = list(num_tokens_range)
+        self.model_config = dict(encoder=encoder, neck=neck, points_head=points_head, mask_head=mask_head,
+                                 normal_head=normal_head, scale_head=scale_head, remap_output=remap_output,
+                                 num_tokens_range=list(num_tokens_range))
+        cfg = L.MogeConfig()
+        cfg.embed_dim, cfg.depth, cfg.num_heads, cfg.n_taps = D, depth, heads, len(taps)
+        for i, t in enumerate(taps):
+            cfg.taps[i] = t
+        neck_res = _check_stack("neck", neck, dims, True)
+        head_res = None
+        bits = 0
+        self._head_names = []
+        for name, bit, cout in _HEADS:
+            sc = {"points_head": points_head, "normal_head": normal_head, "mask_head": mask_head}[name]
+            if sc is None:
+                continue
+            r = _check_stack(name, sc, dims, False)
+            do = sc.get("dim_out")
+            if not isinstance(do, (list, tuple)) or list(do[:4]) != [None] * 4 or do[4] != cout:
+                raise NotImplementedError(f"{name}: dim_out must be [null,null,null,null,{cout}]")
+            if head_res is not None and r != head_res:
+                raise NotImplementedError("all heads must share num_res_blocks")
+            head_res = r
+            bits |= bit
+            self._head_names.append(name)
+        if scale_head is not None:
+            sd = list(scale_head["dims"])
+            if len(sd) != 4 or sd[0] != D or sd[1] != sd[2] or sd[3] != 1:
+                raise NotImplementedError(f"scale_head dims {sd} unsupported (expected [D, h, h, 1])")
+            cfg.scale_hidden = sd[1]
+            bits |= L.HEAD_SCALE
+        for l in range(5):
+            cfg.dims[l] = dims[l]
+            cfg.neck_res_blocks[l] = neck_res[l]
+            cfg.head_res_blocks[l] = (head_res or [0] * 5)[l]
+        cfg.heads = bits
+        cfg.remap_output = L.REMAP[remap_output]
+        self._cfg = cfg
+        self._bits = bits
+        self._state: Optional[Dict[str, torch.Tensor]] = None       # host fp32 state dict until the model is placed on a GPU
+        self._handle = None
+        self._device = torch.device("cpu")
+        self._dtype = torch.float32
+        self._onnx_compatible_mode = False
+        self.training = False
+        self.sync_on_infer = True           # the reference synchronises inside recover_focal_shift; keep that contract
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self._dtype
+
+    @property
+    def onnx_compatible_mode(self) -> bool:
+        return self._onnx_compatible_mode
+
+    @onnx_compatible_mode.setter
+    def onnx_compatible_mode(self, value: bool):
+        if value:
+            raise NotImplementedError("onnx_compatible_mode is not implemented by the HIP path")
+        self._onnx_compatible_mode = False
+
+    def eval(self) -> "MoGeModel":
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True) -> "MoGeModel":
+        if mode:
+            raise NotImplementedError("moge_amd is inference-only")
+        return self
+
+    def requires_grad_(self, flag: bool = False) -> "MoGeModel":
+        return self
+
+    def half(self) -> "MoGeModel":
+        return self.to(torch.float16)
+
+    def float(self) -> "MoGeModel":
+        return self.to(torch.float32)
+
+    def cuda(self, device: Optional[Union[int, torch.device]] = None) -> "MoGeModel":
+        return self.to(torch.device("cuda", device if isinstance(device, int) else (device.index if device is not None else torch.cuda.current_device())))
+
+    def to(self, *args, **kwargs) -> "MoGeModel":
+        device, dtype = kwargs.get("device"), kwargs.get("dtype")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            elif a is not None:
+                device = a
+        if dtype is not None:
+            if dtype not in (torch.float16, torch.float32):
+                raise NotImplementedError(f"dtype {dtype} is not supported (float32 / float16)")
+            self._dtype = dtype
+        if device is not None:
+            device = torch.device(device)
+            if device.type == "cpu":
+                raise RuntimeError("moge_amd has no CPU path: the model must live on an MI355X (device 'cuda')")
+            if device.index is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+            if self._handle is not None and device != self._device:
+                self._release()
+            self._device = device
+            self._ensure_handle()
+        if self._handle is not None and self._state_ready:
+            with torch.cuda.device(self._device):
+                L.check(L.lib.moge_set_precision(self._handle, L.FP16 if self._dtype == torch.float16 else L.FP32, L.stream_ptr(self._device)))
+        return self
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return dict(self._state or {})
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        self._state = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in state_dict.items()}
+        if self._handle is not None:
+            self._upload()
+        return self
+
+    def _release(self):
+        if self._handle is not None:
+            L.lib.moge_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    _state_ready = False
+
+    def _ensure_handle(self):
+        if self._handle is not None:
+            return
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: moge_amd needs an MI355X (there is no CPU fallback)")
+        h = C.c_void_p()
+        L.check(L.lib.moge_create(C.byref(self._cfg), self._device.index, C.byref(h)))
+        self._handle = h
+        self._state_ready = False
+        if self._state is not None:
+            self._upload()
+
+    def _upload(self):
+        names = [k.encode() for k in self._state]
+        descs = (L.TensorDesc * len(names))()
+        for i, (k, v) in enumerate(self._state.items()):
+            descs[i].name = names[i]
+            descs[i].data = v.data_ptr()
+            descs[i].numel = v.numel()
+        with torch.cuda.device(self._device):
+            L.check(L.lib.moge_load_weights(self._handle, descs, len(names), L.stream_ptr(self._device)))
+        self._state_ready = True
+
+    # ------------------------------------------------------------------ multi-GPU weight distribution
+    def master_blob(self) -> torch.Tensor:
+        """uint8 view of the fp32 master weight blob on the device (source/target of the RCCL broadcast)."""
+        self._ensure_handle()
+        L.check(L.lib.moge_alloc_master(self._handle))
+        p, n = C.c_void_p(), C.c_size_t()
+        L.check(L.lib.moge_master_blob(self._handle, C.byref(p), C.byref(n)))
+        return torch.as_tensor(L.DevView(p.value, n.value), device=self._device)
+
+    def master_received(self):
+        L.check(L.lib.moge_master_ready(self._handle))
+        self._state_ready = True
+        self.to(self._dtype)
+
+    # ------------------------------------------------------------------ loading
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: Union[str, Path, IO[bytes]], model_kwargs: Optional[Dict[str, Any]] = None,
+                        **hf_kwargs) -> "MoGeModel":
+        """Same contract as the reference (v2.py:76-107): local .pt path or HF repo id; checkpoint = {'model_config', 'model'}."""
+        if Path(pretrained_model_name_or_path).exists():
+            checkpoint_path = pretrained_model_name_or_path
+        else:
+            from huggingface_hub import hf_hub_download
+            checkpoint_path = hf_hub_download(repo_id=pretrained_model_name_or_path, repo_type="model", filename="model.pt", **hf_kwargs)
+        checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+        model_config = checkpoint["model_config"]
+        if model_kwargs is not None:
+            model_config.update(model_kwargs)
+        model = cls(**model_config)
+        model.load_state_dict(checkpoint["model"], strict=False)
+        return model
+
+    # ------------------------------------------------------------------ compute
+    def _grid(self, H: int, W: int, num_tokens: int):
+        aspect = W / H
+        return round((num_tokens / aspect) ** 0.5), round((num_tokens * aspect) ** 0.5)        # python round: half-to-even (v2.py:147)
+
+    def _prep_image(self, image: torch.Tensor) -> torch.Tensor:
+        image = image.to(device=self._device)
+        if image.dtype not in (torch.float16, torch.float32):
+            image = image.float()
+        if self._dtype == torch.float16 and image.dtype != torch.float16:
+            image = image.half()                      # the reference casts the image to the model dtype (v2.py:229)
+        return image.contiguous()
+
+    def _precision(self, use_fp16: bool) -> int:
+        return L.FP16 if (self._dtype == torch.float16 or use_fp16) else L.FP32
+
+    def _set_precision(self, prec: int):
+        L.check(L.lib.moge_set_precision(self._handle, prec, L.stream_ptr(self._device)))
+
+    def forward(self, image: torch.Tensor, num_tokens: int) -> Dict[str, torch.Tensor]:
+        self._require_ready()
+        image = self._prep_image(image)
+        B, _, H, W = image.shape
+        rows, cols = self._grid(H, W, int(num_tokens))
+        dev = self._device
+        with torch.cuda.device(dev):
+            self._set_precision(L.FP16 if self._dtype == torch.float16 else L.FP32)
+            o = L.Outputs()
+            res: Dict[str, torch.Tensor] = {}
+            if self._bits & L.HEAD_POINTS:
+                res["points"] = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev); o.points = res["points"].data_ptr()
+            if self._bits & L.HEAD_NORMAL:
+                res["normal"] = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev); o.normal = res["normal"].data_ptr()
+            if self._bits & L.HEAD_MASK:
+                res["mask"] = torch.empty((B, H, W), dtype=torch.float32, device=dev); o.mask_prob = res["mask"].data_ptr()
+            if self._bits & L.HEAD_SCALE:
+                res["metric_scale"] = torch.empty((B,), dtype=torch.float32, device=dev); o.metric_scale = res["metric_scale"].data_ptr()
+            L.check(L.lib.moge_forward(self._handle, image.data_ptr(), 1 if image.dtype == torch.float16 else 0, B, H, W, rows, cols,
+                                       C.byref(o), L.stream_ptr(dev)))
+        if self._dtype == torch.float16:
+            res = {k: v.half() for k, v in res.items()}
+        return res
+
+    __call__ = forward
+
+    def _require_ready(self):
+        if self._handle is None or not self._state_ready:
+            raise RuntimeError("MoGeModel is not on a GPU yet (call .to('cuda')) or has no weights")
+
+    @torch.inference_mode()
+    def infer(self, image: torch.Tensor, num_tokens: int = None, resolution_level: int = 9, force_projection: bool = True,
+              apply_mask: bool = True, fov_x: Optional[Union[Number, torch.Tensor]] = None, use_fp16: bool = True) -> Dict[str, torch.Tensor]:
+        """Same parameters / returns as the reference `infer` (v2.py:194-303)."""
+        self._require_ready()
+        omit_batch_dim = image.dim() == 3
+        if omit_batch_dim:
+            image = image.unsqueeze(0)
+        image = self._prep_image(image)
+        B, _, H, W = image.shape
+        if num_tokens is None:
+            min_tokens, max_tokens = self.num_tokens_range
+            num_tokens = int(min_tokens + (resolution_level / 9) * (max_tokens - min_tokens))
+        rows, cols = self._grid(H, W, num_tokens)
+        dev = self._device
+        with torch.cuda.device(dev):
+            self._set_precision(self._precision(use_fp16))
+            o = L.Outputs()
+            res: Dict[str, torch.Tensor] = {}
+            has_points = bool(self._bits & L.HEAD_POINTS)
+            if not has_points:
+                raise NotImplementedError("infer() without a points head is not implemented")
+            res["points"] = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev); o.points = res["points"].data_ptr()
+            res["intrinsics"] = torch.empty((B, 3, 3), dtype=torch.float32, device=dev); o.intrinsics = res["intrinsics"].data_ptr()
+            res["depth"] = torch.empty((B, H, W), dtype=torch.float32, device=dev); o.depth = res["depth"].data_ptr()
+            if self._bits & L.HEAD_MASK:
+                res["mask"] = torch.empty((B, H, W), dtype=torch.bool, device=dev); o.mask = res["mask"].data_ptr()
+            if self._bits & L.HEAD_NORMAL:
+                res["normal"] = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev); o.normal = res["normal"].data_ptr()
+            fov_ptr = None
+            if fov_x is not None:
+                fov = torch.as_tensor(fov_x, dtype=torch.float32, device=dev)
+                if fov.ndim == 0:
+                    fov = fov[None].expand(B)
+                fov = fov.contiguous()
+                fov_ptr = fov.data_ptr()
+            flags = (L.FORCE_PROJECTION if force_projection else 0) | (L.APPLY_MASK if apply_mask else 0)
+            L.check(L.lib.moge_infer(self._handle, image.data_ptr(), 1 if image.dtype == torch.float16 else 0, B, H, W, rows, cols,
+                                     fov_ptr, flags, C.byref(o), L.stream_ptr(dev)))
+            if self.sync_on_infer:
+                L.check(L.lib.moge_sync(self._handle, L.stream_ptr(dev)))
+        if omit_batch_dim:
+            res = {k: v.squeeze(0) for k, v in res.items()}
+        return res
+
+    # ------------------------------------------------------------------ diagnostics
+    def debug_tap(self, name: str) -> torch.Tensor:
+        n = C.c_int64()
+        L.check(L.lib.moge_debug_tap(self._handle, name.encode(), None, 0, C.byref(n), L.stream_ptr(self._device)))
+        t = torch.empty((n.value,), dtype=torch.float32, device=self._device)
+        L.check(L.lib.moge_debug_tap(self._handle, name.encode(), t.data_ptr(), n.value, C.byref(n), L.stream_ptr(self._device)))
+        return t
+
+    def profile(self, on: bool):
+        L.check(L.lib.moge_profile_enable(self._handle, 1 if on else 0))
+
+    def profile_read(self, reset: bool = True) -> Dict[str, Dict[str, float]]:
+        p = L.Profile()
+        L.check(L.lib.moge_profile_read(self._handle, C.byref(p), 1 if reset else 0))
+        return {L.KC_NAMES[i]: dict(ms=p.ms[i], flops=p.flops[i], bytes=p.bytes[i], launches=p.launches[i]) for i in range(7)}

@@ -1,0 +1,88 @@
+"""ctypes helpers for the per-kernel C-ABI test entry points (tests only)."""
+import torch
+
+from moge_amd import _lib as L
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f(t):
+    return t.detach().to("cuda", torch.float32).contiguous()
+
+
+def st():
+    return L.stream_ptr()
+
+
+def gemm(prec, A, W, bias=None, act=0):
+    A, W = _f(A), _f(W)
+    bias = None if bias is None else _f(bias)
+    M, K = A.shape
+    N = W.shape[0]
+    C = torch.empty((M, N), device="cuda", dtype=torch.float32)
+    L.check(L.lib.moge_test_gemm(prec, _p(A), _p(W), _p(bias), _p(C), M, N, K, act, st()))
+    return C
+
+
+def layernorm(prec, x, w, b):
+    x, w, b = _f(x), _f(w), _f(b)
+    y = torch.empty_like(x)
+    L.check(L.lib.moge_test_layernorm(prec, _p(x), _p(w), _p(b), _p(y), x.shape[0], x.shape[1], st()))
+    return y
+
+
+def attention(prec, q, k, v):
+    q, k, v = _f(q), _f(k), _f(v)
+    B, nh, N, _ = q.shape
+    o = torch.empty((B, N, nh * 64), device="cuda", dtype=torch.float32)
+    L.check(L.lib.moge_test_attention(prec, _p(q), _p(k), _p(v), _p(o), B, nh, N, st()))
+    return o
+
+
+def conv3x3(prec, x_nhwc, w, bias, relu_in=False, up2=False):
+    x, w, bias = _f(x_nhwc), _f(w), _f(bias)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+    y = torch.empty((B, Ho, Wo, Cout), device="cuda", dtype=torch.float32)
+    L.check(L.lib.moge_test_conv3x3(prec, _p(x), _p(w), _p(bias), _p(y), B, H, W, Cin, Cout, (1 if relu_in else 0) | (2 if up2 else 0), st()))
+    return y
+
+
+def convt2x2(prec, x_nhwc, w, bias):
+    x, w, bias = _f(x_nhwc), _f(w), _f(bias)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[1]
+    y = torch.empty((B, 2 * H, 2 * W, Cout), device="cuda", dtype=torch.float32)
+    L.check(L.lib.moge_test_convt2x2(prec, _p(x), _p(w), _p(bias), _p(y), B, H, W, Cin, Cout, st()))
+    return y
+
+
+def preprocess(img, rows, cols):
+    img = _f(img)
+    B, _, H, W = img.shape
+    y = torch.empty((B, 3, rows * 14, cols * 14), device="cuda", dtype=torch.float32)
+    L.check(L.lib.moge_test_preprocess(_p(img), _p(y), B, H, W, rows, cols, st()))
+    return y
+
+
+def posembed(pos, rows, cols):
+    pos = _f(pos)
+    D = pos.shape[-1]
+    y = torch.empty((1 + rows * cols, D), device="cuda", dtype=torch.float32)
+    L.check(L.lib.moge_test_posembed(_p(pos), _p(y), D, rows, cols, st()))
+    return y
+
+
+def recover(points, mask, focal=None):
+    points = _f(points)
+    B, H, W, _ = points.shape
+    m = None if mask is None else mask.to("cuda", torch.uint8).contiguous()
+    f_in = None if focal is None else _f(focal)
+    f = torch.empty((B,), device="cuda", dtype=torch.float32)
+    s = torch.empty((B,), device="cuda", dtype=torch.float32)
+    status = torch.zeros((1,), device="cuda", dtype=torch.int32)
+    L.check(L.lib.moge_test_recover(_p(points), _p(m), _p(f_in), B, H, W, _p(f), _p(s), _p(status), st()))
+    return f, s, int(status.item())

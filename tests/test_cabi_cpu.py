@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library loads without a GPU and exports exactly what include/moge_hip.h declares; host-side
+shape logic of the Python mirror matches the reference's rules.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_match_header():
+    from moge_amd import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "moge_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(moge_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(L.EXPORTS)
+    for name in declared:
+        assert hasattr(L.lib, name), f"libmoge_hip.so does not export {name}"
+    assert L.lib.moge_abi_version() == 1
+
+
+def test_config_struct_layout():
+    from moge_amd import _lib as L
+    assert ctypes.sizeof(L.MogeConfig) == 4 * (4 + 8 + 5 + 5 + 5 + 3)
+    assert ctypes.sizeof(L.Outputs) == 9 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(L.Profile) == 7 * 8 * 4
+
+
+def test_model_mirror_host_logic():
+    from moge_amd.model import import_model_class_by_version
+    from oracle import moge_oracle as O
+    M = import_model_class_by_version("v2")
+    m = M(**O.named_configs()["moge-2-vitl-normal"])
+    assert m._grid(518, 518, 3600) == (60, 60) and m._grid(518, 1036, 3600) == (42, 85) and m._grid(1036, 518, 3600) == (85, 42)
+    assert m._cfg.embed_dim == 1024 and m._cfg.depth == 24 and list(m._cfg.taps)[:4] == [5, 11, 17, 23]
+    assert m.num_tokens_range == [1200, 3600] and m.dtype.is_floating_point and m.device.type == "cpu"
+    with pytest.raises(NotImplementedError):
+        import_model_class_by_version("v1")
+    with pytest.raises(ValueError):
+        M(**{**O.named_configs()["tiny-vits-normal"], "remap_output": "bogus"})
+    with pytest.raises(RuntimeError):
+        m.to("cpu")            # no CPU fallback, by design
+
+
+def test_create_rejects_bad_config_without_gpu():
+    from moge_amd import _lib as L
+    cfg = L.MogeConfig()
+    cfg.embed_dim, cfg.num_heads, cfg.depth, cfg.n_taps = 100, 2, 1, 1
+    h = ctypes.c_void_p()
+    assert L.lib.moge_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == -1
+    assert b"unsupported ViT width" in L.lib.moge_last_error()

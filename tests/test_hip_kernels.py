@@ -1,0 +1,157 @@
+"""GPU: every HIP kernel class against a plain PyTorch fp32 reference of the same op (torch ops on the GPU are the
+checker here, never the product path).  FP32 mode uses the exact-fp32 MFMA: tolerance 1e-4 relative to the output
+scale; FP16 mode (fp16 storage, fp32 accumulate): 2e-2."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 2e-4, 1: 2e-2}
+
+
+def relmax(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests import hip_util
+    return hip_util
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("M,N,K,act", [(300, 256, 192, 0), (129, 64, 72, 1), (77, 32, 40, 0), (1000, 1152, 384, 2), (128, 128, 64, 0),
+                                       (4097, 384, 1536, 0), (515, 96, 288, 0)])
+def test_gemm(H, prec, M, N, K, act):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = A.cuda() @ W.cuda().T + b.cuda()
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    out = H.gemm(prec, A, W, b, act)
+    assert relmax(out, ref) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("D", [384, 768, 1024])
+def test_layernorm(H, prec, D):
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(777, D, generator=g) * 3 + 0.5
+    w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    ref = F.layer_norm(x.cuda(), (D,), w.cuda(), b.cuda(), 1e-6)
+    assert relmax(H.layernorm(prec, x, w, b), ref) < (1e-5 if prec == 0 else 2e-3)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,nh,N", [(1, 1, 64), (2, 3, 130), (1, 2, 200), (1, 6, 1370), (1, 2, 3601)])
+def test_attention(H, prec, B, nh, N):
+    g = torch.Generator().manual_seed(N)
+    q, k, v = (torch.randn(B, nh, N, 64, generator=g) for _ in range(3))
+    q = q * 1.5
+    v[:, :, N // 2] += 5.0                      # asymmetric values: a transposed / permuted key order cannot pass
+    ref = F.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda()).permute(0, 2, 1, 3).reshape(B, N, nh * 64)
+    assert relmax(H.attention(prec, q, k, v), ref) < (2e-5 if prec == 0 else 1e-2)
+
+
+def test_attention_online_softmax_rescale(H):
+    """rule 26: force the running-max rescale branch - one key in a LATE tile dominates one query."""
+    g = torch.Generator().manual_seed(7)
+    B, nh, N = 1, 1, 300
+    q, k, v = (torch.randn(B, nh, N, 64, generator=g) for _ in range(3))
+    k[0, 0, 250] = q[0, 0, 10] * 4.0            # raw score ~ 4*|q|^2/8 >> others, appears in tile 3
+    ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).permute(0, 2, 1, 3).reshape(B, N, 64)
+    for prec in (0, 1):
+        assert relmax(H.attention(prec, q, k, v), ref) < (2e-5 if prec == 0 else 1e-2)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,Hh,Ww,Cin,Cout,relu", [(2, 13, 17, 32, 32, False), (1, 9, 20, 64, 128, True), (1, 31, 5, 32, 64, True), (1, 8, 8, 128, 256, False)])
+def test_conv3x3(H, prec, B, Hh, Ww, Cin, Cout, relu):
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, Hh, Ww, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xin = F.relu(x) if relu else x
+    ref = F.conv2d(F.pad(xin.cuda(), (1, 1, 1, 1), mode="replicate"), w.cuda(), b.cuda()).permute(0, 2, 3, 1)
+    out = H.conv3x3(prec, x.permute(0, 2, 3, 1), w, b, relu_in=relu)
+    assert relmax(out, ref) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_conv3x3_fused_bilinear_up2(H, prec):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 11, 7, generator=g)
+    w = torch.randn(32, 64, 3, 3, generator=g) / 24
+    b = torch.randn(32, generator=g)
+    up = F.interpolate(x.cuda(), scale_factor=2, mode="bilinear", align_corners=False)
+    ref = F.conv2d(F.pad(up, (1, 1, 1, 1), mode="replicate"), w.cuda(), b.cuda()).permute(0, 2, 3, 1)
+    assert relmax(H.conv3x3(prec, x.permute(0, 2, 3, 1), w, b, up2=True), ref) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_convtranspose2x2(H, prec):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 128, 6, 9, generator=g)
+    w = torch.randn(128, 64, 2, 2, generator=g) / 128 ** 0.5
+    b = torch.randn(64, generator=g)
+    ref = F.conv_transpose2d(x.cuda(), w.cuda(), b.cuda(), stride=2).permute(0, 2, 3, 1)
+    assert relmax(H.convt2x2(prec, x.permute(0, 2, 3, 1), w, b), ref) < TOL[prec]
+
+
+@pytest.mark.parametrize("Hh,Ww,rows,cols", [(98, 126, 10, 12), (140, 150, 7, 8), (518, 518, 60, 60), (300, 500, 9, 16)])
+def test_preprocess_matches_antialiased_interpolate(H, Hh, Ww, rows, cols):
+    g = torch.Generator().manual_seed(Hh)
+    img = torch.rand(2, 3, Hh, Ww, generator=g)
+    ref = F.interpolate(img, (rows * 14, cols * 14), mode="bilinear", align_corners=False, antialias=True)     # CPU reference (ATen)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    ref = (ref - mean) / std
+    assert float((H.preprocess(img, rows, cols).cpu() - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("rows,cols", [(10, 12), (60, 60), (42, 85), (37, 37), (7, 8)])
+def test_posembed_bicubic_kludge(H, rows, cols):
+    from oracle import moge_oracle as O
+    g = torch.Generator().manual_seed(rows)
+    pos = torch.randn(1, 1 + 37 * 37, 384, generator=g)
+    ref = O.pos_embed_for_grid(pos, rows, cols)[0]
+    assert float((H.posembed(pos[0], rows, cols).cpu() - ref).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+def test_recover_matches_oracle_lm(H, fixed):
+    from oracle import moge_oracle as O
+    g = torch.Generator().manual_seed(11)
+    B, Hh, Ww = 3, 70, 90
+    uv = O.view_plane_uv(Ww, Hh)
+    z = 1.0 + 2.0 * torch.rand(B, Hh, Ww, generator=g)
+    f_true = torch.tensor([0.7, 1.1, 1.6]).view(B, 1, 1, 1)
+    s_true = torch.tensor([0.2, -0.3, 0.05]).view(B, 1, 1)
+    xy = uv[None] * (z + s_true)[..., None] / f_true + 0.01 * torch.randn(B, Hh, Ww, 2, generator=g)
+    pts = torch.cat([xy, z[..., None]], dim=-1)
+    pts[2] = torch.randn(Hh, Ww, 3, generator=g)                 # ill-posed image
+    mask = torch.rand(B, Hh, Ww, generator=g) > 0.3
+    focal = torch.tensor([0.8, 1.0, 1.3]) if fixed else None
+    f_ref, s_ref = O.recover_focal_shift(pts, mask, focal)
+    f, s, status = H.recover(pts, mask, focal)
+    assert status == 0
+    np.testing.assert_allclose(s.cpu().numpy()[:2], s_ref.numpy()[:2], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(f.cpu().numpy()[:2], f_ref.numpy()[:2], rtol=1e-4)
+    np.testing.assert_allclose(s.cpu().numpy()[2], s_ref.numpy()[2], rtol=2e-2, atol=1e-4)      # ill-posed: trajectory-sensitive
+
+
+def test_recover_fallback_and_nonfinite(H):
+    pts = torch.rand(2, 32, 32, 3) + 0.5
+    mask = torch.zeros(2, 32, 32, dtype=torch.bool)
+    mask[1, 0, 0] = True                                     # 0 and 1 valid points -> focal=1, shift=0 (geometry_torch.py:153-156)
+    f, s, status = H.recover(pts, mask)
+    assert status == 0 and f.tolist() == [1.0, 1.0] and s.tolist() == [0.0, 0.0]
+    pts[0, :, :, 2] = 0.0                                    # z + 0 == 0 -> inf residuals at x0 -> scipy raises ValueError
+    f, s, status = H.recover(pts, torch.ones(2, 32, 32, dtype=torch.bool))
+    assert status == -5
