@@ -1,0 +1,168 @@
+"""bench.py - throughput of the MI355X-native `MoGeModel.infer()` hot path (driver contract).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is ONE infer() pass of the hot path over one batch of synthetic images that are already resident in HBM.
+Workload (BASELINE.json metric: images/sec, moge-2-vitl 518x518 fp16): configs[2] = moge-2-vitl (no normal head),
+batch 32 per GPU, torch.rand 3x518x518, default num_tokens 3600 (60x60 token grid, N=3601), fp16 weights
+(model.half()), full infer() including focal/shift recovery and masking; outputs stay on the device.
+For N>1 the driver launches one process per GPU (torch.distributed / RCCL): rank 0 builds the synthetic checkpoint,
+the fp32 master weight blob is broadcast once over xGMI, then every rank runs independent inference on its own
+shard (weak scaling: per-GPU batch fixed; no steady-state collective - SURVEY.md 8(e)).
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline      dominant kernel class (the MFMA GEMM of the ViT linears), HIP-event timed inside the timed region
+  cpu_baseline  the CPU oracle (oracle/moge_oracle.py, a restatement pinned to the reference) on ONE image of the
+                same workload on this box's host cores (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F16_TFLOPS = 2500.0        # dense fp16 MFMA, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+WORKLOAD_CONFIG = "moge-2-vitl"
+BATCH_PER_GPU = 32
+IMG = 518
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--config", default=WORKLOAD_CONFIG)
+    ap.add_argument("--num-tokens", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="disable the per-kernel HIP-event profiler")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from moge_amd.model import import_model_class_by_version
+    from moge_amd.parallel import broadcast_weights
+    from oracle import moge_oracle as O        # synthetic checkpoint generator + cpu_baseline leg only
+    MoGeModel = import_model_class_by_version("v2")
+    cfg = O.named_configs()[args.config]
+    sd = None
+    if rank == 0:
+        sd = O.synth_state_dict(cfg, 0, True)
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "model.pt")
+            O.save_checkpoint(path, cfg, sd)
+            model = MoGeModel.from_pretrained(path)      # the reference's loader contract
+    else:
+        model = MoGeModel(**cfg)
+    model.to(dev).eval()
+    if world > 1:
+        broadcast_weights(model, src=0)                  # one-time RCCL broadcast of the master blob
+    model.half()
+
+    B = args.batch
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    x = torch.rand(B, 3, IMG, IMG, generator=g).to(dev)
+    kw = {} if args.num_tokens is None else {"num_tokens": args.num_tokens}
+    num_tokens = args.num_tokens or int(model.num_tokens_range[0] + (9 / 9) * (model.num_tokens_range[1] - model.num_tokens_range[0]))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        model.infer(x, **kw)
+    if not args.no_profile:
+        model.profile(True)
+        model.profile_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.infer(x, **kw)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = None
+    if not args.no_profile:
+        prof = model.profile_read(reset=True)
+        model.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(out["intrinsics"]).all())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        # B=1 latency (p50), outside the timed region
+        lat = []
+        x1 = x[:1].contiguous()
+        for i in range(12):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            model.infer(x1, **kw)
+            torch.cuda.synchronize(dev)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat = sorted(lat[2:])
+        res = {
+            "metric": "images/sec (MoGeModel.infer, moge-2-vitl 518x518 fp16)", "value": round(value, 3), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{args.config} infer(): batch {B}/GPU x 3x{IMG}x{IMG} torch.rand, num_tokens {num_tokens}, "
+                                   f"fp16 weights, synthetic checkpoint (seed 0), inputs resident in HBM, outputs left on device",
+                       "global_batch": world * B, "parallelism": f"dp{world} (independent shards, one-time RCCL weight broadcast)"},
+            "p50_latency_ms_batch1": round(lat[len(lat) // 2], 3),
+        }
+        if prof is not None:
+            gm = prof["gemm"]
+            ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<f16,2,2,2,2,LINEAR> (ViT qkv/proj/fc1/fc2/out-proj GEMMs)",
+                               "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4),
+                               "traffic": None, "avg_launch_ms": round(gm["ms"] / max(gm["launches"], 1), 4), "launches": gm["launches"]}
+            tot_ms = sum(v["ms"] for v in prof.values())
+            tot_fl = sum(v["flops"] for v in prof.values())
+            res["kernel_classes"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] > 0 else None,
+                                         "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 and v["bytes"] > 0 else None}
+                                     for k, v in prof.items()}
+            res["whole_path"] = {"algorithmic_tflop_per_image": round(tot_fl / args.steps / B / 1e12, 4),
+                                 "mfma_frac_of_peak_end_to_end": round(tot_fl / args.steps / (ms_per_step * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
+                                 "kernel_ms_per_step": round(tot_ms / args.steps, 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            # bounded sample: ONE image of the same workload through the CPU oracle (fp32), all host threads
+            xc = x[:1].float().cpu()
+            t1 = time.perf_counter()
+            O.infer(cfg, sd, xc, **kw)
+            dt = time.perf_counter() - t1
+            res["cpu_baseline"] = {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"1 image of the same workload ({args.config}, 518x518, num_tokens {num_tokens}) through oracle.infer "
+                                             f"(torch CPU fp32 + scalar lmdif), {dt:.1f} s"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

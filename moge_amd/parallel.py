@@ -1,0 +1,44 @@
+"""Multi-GPU plumbing for the batch-sharded inference path.
+
+The path is embarrassingly parallel per image, so the only collective is the ONE-TIME broadcast of the fp32 master
+weight blob (vitl-normal: 1.3 GB) from the rank that read the checkpoint, over RCCL/xGMI (fully connected 8-GPU mesh:
+every peer has a direct link to the root).  After that every rank runs independent infer() calls on its own shard;
+there is no steady-state collective and nothing to all-reduce."""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def broadcast_weights(model, src: int = 0, group=None) -> None:
+    """Broadcast the master weight blob of `model` (a moge_amd MoGeModel already placed on this rank's GPU) from
+    rank `src`.  Non-source ranks need no checkpoint on disk: their blob is allocated from the config alone."""
+    blob = model.master_blob()                 # zero-copy uint8 view of the device buffer
+    dist.broadcast(blob, src=src, group=group)
+    if dist.get_rank(group) != src:
+        model.master_received()
+    torch.cuda.synchronize(model.device)
+
+
+def shard_batch(n_items: int, world: int, rank: int) -> range:
+    """Contiguous shard [lo, hi) of a batch of n_items for `rank` (sizes differ by at most one)."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return range(lo, lo + base + (1 if rank < extra else 0))
+
+
+def shard_mixed_shapes(shapes: Sequence[Sequence[int]], world: int, rank: int) -> List[List[int]]:
+    """BASELINE config 5 (mixed 518x1036 / 1036x518): bucket item indices by (H, W) - the ViT cannot mix shapes in one
+    batch - and give every rank a contiguous shard of every bucket, so ranks stay balanced in tokens."""
+    buckets = {}
+    for i, s in enumerate(shapes):
+        buckets.setdefault(tuple(s), []).append(i)
+    out = []
+    for key in sorted(buckets):
+        idx = buckets[key]
+        r = shard_batch(len(idx), world, rank)
+        if len(r):
+            out.append([idx[j] for j in r])
+    return out
