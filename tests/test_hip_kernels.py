@@ -147,11 +147,11 @@ def test_recover_matches_oracle_lm(H, fixed):
 
 
 def test_recover_fallback_and_nonfinite(H):
-    pts = torch.rand(2, 32, 32, 3) + 0.5
-    mask = torch.zeros(2, 32, 32, dtype=torch.bool)
-    mask[1, 0, 0] = True                                     # 0 and 1 valid points -> focal=1, shift=0 (geometry_torch.py:153-156)
+    pts = torch.rand(2, 70, 70, 3) + 0.5
+    mask = torch.zeros(2, 70, 70, dtype=torch.bool)
+    mask[1, 0, 0] = True                 # 0 and 1 sampled valid points -> focal=1, shift=0 (geometry_torch.py:153-156)
     f, s, status = H.recover(pts, mask)
     assert status == 0 and f.tolist() == [1.0, 1.0] and s.tolist() == [0.0, 0.0]
-    pts[0, :, :, 2] = 0.0                                    # z + 0 == 0 -> inf residuals at x0 -> scipy raises ValueError
-    f, s, status = H.recover(pts, torch.ones(2, 32, 32, dtype=torch.bool))
+    pts[0, :, :, 2] = 0.0                # z + 0 == 0 -> inf residuals at x0 -> scipy raises ValueError
+    f, s, status = H.recover(pts, torch.ones(2, 70, 70, dtype=torch.bool))
     assert status == -5
