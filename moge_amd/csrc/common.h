@@ -80,21 +80,6 @@ template <> __device__ __forceinline__ u32x4 relu_chunk<float>(u32x4 v) {
     return __builtin_bit_cast(u32x4, h);
 }
 
-// a*wa + b*wb + c*wc + d*wd on 16-byte chunks (fp32 math), used by the fused bilinear x2 loader
-template <typename T> __device__ __forceinline__ u32x4 blend4_chunk(u32x4 a, u32x4 b, u32x4 c, u32x4 d, float wa, float wb, float wc, float wd);
-template <> __device__ __forceinline__ u32x4 blend4_chunk<f16>(u32x4 a, u32x4 b, u32x4 c, u32x4 d, float wa, float wb, float wc, float wd) {
-    f16x8 x = __builtin_bit_cast(f16x8, a), y = __builtin_bit_cast(f16x8, b), z = __builtin_bit_cast(f16x8, c), w = __builtin_bit_cast(f16x8, d), o;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o[i] = (f16)((float)x[i] * wa + (float)y[i] * wb + (float)z[i] * wc + (float)w[i] * wd);
-    return __builtin_bit_cast(u32x4, o);
-}
-template <> __device__ __forceinline__ u32x4 blend4_chunk<float>(u32x4 a, u32x4 b, u32x4 c, u32x4 d, float wa, float wb, float wc, float wd) {
-    f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b), z = __builtin_bit_cast(f32x4, c), w = __builtin_bit_cast(f32x4, d), o;
-#pragma unroll
-    for (int i = 0; i < 4; i++) o[i] = x[i] * wa + y[i] * wb + z[i] * wc + w[i] * wd;
-    return __builtin_bit_cast(u32x4, o);
-}
-
 // LDS swizzle of the chunk index inside a tile row.  CPR = chunks per row (8 -> 128-byte rows, 16 -> 256-byte rows).
 // ds_read_b128 is served in 16-lane groups over a 256-byte bank row: with these XORs the 16 lanes of a group
 // (16 different rows, same logical chunk) hit 16 distinct 16-byte slots.
@@ -112,7 +97,7 @@ __device__ __forceinline__ float linspace_at(float start, float end, float step,
 // --------------------------------------------------------------------------------------------
 // GEMM / implicit-GEMM conv argument blocks (see gemm.hip)
 // --------------------------------------------------------------------------------------------
-enum { AMODE_LINEAR = 0, AMODE_CONV3 = 1, AMODE_CONV3_UP2 = 2 };
+enum { AMODE_LINEAR = 0, AMODE_CONV3 = 1 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_PATCH = 2, EPI_QKV = 3, EPI_CONVT = 4 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
@@ -126,7 +111,7 @@ struct GemmArgs {
     // A operand (activations)
     const void* a;
     int lda;               // LINEAR: row stride in elements
-    int H, W, C;           // CONV3*: OUTPUT spatial dims (= input dims, or 2x input dims for UP2) and input channels
+    int H, W, C;           // CONV3: spatial dims and input channels of the NHWC input
     int relu_in;           // apply ReLU to A on load
     // W operand: [N][ldw] storage type, K-contiguous
     const void* w;

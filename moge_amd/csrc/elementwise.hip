@@ -271,3 +271,43 @@ int launch_repack(const float* src, void* dst, int n0, int n1, int n2, int n3, l
 }
 template int launch_repack<f16>(const float*, void*, int, int, int, int, long, long, long, long, long, long, long, hipStream_t);
 template int launch_repack<float>(const float*, void*, int, int, int, int, long, long, long, long, long, long, long, hipStream_t);
+
+// --------------------------------------------------------------------------------------------
+// bilinear x2 upsample (align_corners=False) followed by a replicate-padded 3x3 conv (Resampler 'bilinear',
+// modules.py:155-159) == four 3x3 convs on the LOW-res map, one per output parity (py,px), with replicate clamping of the
+// low-res indices (the clamped bilinear taps and the replicate pad of the virtual hi-res map coincide with index
+// clamping).  hi-res row 2i   = .25 x[i-1] + .75 x[i],   hi-res row 2i+1 = .75 x[i] + .25 x[i+1], so with
+//   R[0] = [[.75,.25,0],[.25,.75,0],[0,.75,.25]]   R[1] = [[.25,.75,0],[0,.75,.25],[0,.25,.75]]     (R[p][dy+1][a+1])
+//   Weff[(py,px,co)][(a,b),ci] = sum_{dy,dx} W[co][ci][dy][dx] * R[py][dy][a] * R[px][dx][b].
+// dst: [(py*2+px)*Cout + co][(a*3+b)*Cin + ci], torch src: [co][ci][3][3].  Combination in fp32, one rounding to T.
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_phase_conv_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin) {
+    const float R[2][3][3] = {{{.75f, .25f, 0.f}, {.25f, .75f, 0.f}, {0.f, .75f, .25f}}, {{.25f, .75f, 0.f}, {0.f, .75f, .25f}, {0.f, .25f, .75f}}};
+    const long total = 4L * Cout * 9 * Cin;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long t = idx;
+        const int ci = t % Cin; t /= Cin;
+        const int tap = t % 9; t /= 9;
+        const int co = t % Cout; t /= Cout;
+        const int ph = (int)t;
+        const int py = ph >> 1, px = ph & 1, a = tap / 3, b = tap % 3;
+        const float* ws = w + ((size_t)co * Cin + ci) * 9;
+        float acc = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) acc += ws[dy * 3 + dx] * (R[py][dy][a] * R[px][dx][b]);
+        dst[idx] = (T)acc;
+    }
+}
+template <typename T>
+int launch_pack_phase_conv(const float* w, void* dst, int Cout, int Cin, hipStream_t st) {
+    const long total = 4L * Cout * 9 * Cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_phase_conv_kernel<T>, dim3(blocks), dim3(256), 0, st, w, (T*)dst, Cout, Cin);
+    return (int)hipGetLastError();
+}
+template int launch_pack_phase_conv<f16>(const float*, void*, int, int, hipStream_t);
+template int launch_pack_phase_conv<float>(const float*, void*, int, int, hipStream_t);

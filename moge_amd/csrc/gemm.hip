@@ -7,7 +7,8 @@
 //   1x1 convs                       modules.py:128-131, 209, 231
 //   ConvTranspose2d k2/s2           modules.py:162  (GEMM to 4*Cout + pixel-shuffle store)
 //   3x3 replicate-padded convs      modules.py:53,59,148-181 (implicit GEMM, K = 9*Cin, clamp-indexed loads,
-//                                   optional ReLU prologue, optional fused bilinear x2 upsample modules.py:157)
+//                                   optional ReLU prologue); bilinear x2 + 3x3 (modules.py:157-158) runs as a 4-phase
+//                                   3x3 conv on the LOW-res map with pre-combined weights (N = 4*Cout) + pixel shuffle
 //
 // Design (CDNA4): the block computes a BM x BN tile; K is consumed in 128-byte slabs (64 halves / 32 floats) that
 // are staged global -> registers -> LDS (16-byte chunks, XOR-swizzled so ds_read_b128 is bank-conflict free),
@@ -17,6 +18,7 @@
 // Storage type T selects the instruction: f16 -> v_mfma_f32_32x32x16_f16, float -> v_mfma_f32_32x32x2_f32
 // (exact fp32, the parity mode).  Accumulation is fp32 in both.
 #include "common.h"
+#include <cstdlib>
 
 template <typename T>
 __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float v0, float v1, float v2, float v3) {
@@ -94,6 +96,14 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float
         const int x = m % g.pixW;
         const int t = m / g.pixW;
         const int y = t % g.pixH, b = t / g.pixH;
+        if (g.uv.wu) {          // uv term evaluated at the HIGH-res pixel (2y+dy, 2x+dx); wu/wv indexed by output channel
+            const float u = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, 2 * g.pixW, 2 * x + dx);
+            const float vv = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, 2 * g.pixH, 2 * y + dy);
+            const f32x4 wu = *reinterpret_cast<const f32x4*>(g.uv.wu + co);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(g.uv.wv + co);
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] += wu[i] * u + wv[i] * vv;
+        }
         const size_t idx = (((size_t)b * 2 * g.pixH + 2 * y + dy) * (2 * g.pixW) + 2 * x + dx) * g.Cout + co;
         store4(reinterpret_cast<T*>(g.out) + idx, v[0], v[1], v[2], v[3]);
         break;
@@ -108,7 +118,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     constexpr int CH = TT<T>::CH;
     constexpr int A_IT = BM * 8 / NT, W_IT = BN * 8 / NT;
     constexpr int RSTEP = NT / 8;                      // tile rows covered per load pass
-    constexpr int NTAP = (AMODE == AMODE_CONV3_UP2) ? 4 : 1;
     static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile/thread mismatch");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -140,8 +149,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             const int x = m % g.W;
             const int t = m / g.W;
             const int y = t % g.H, b = t / g.H;
-            const int Hin = (AMODE == AMODE_CONV3_UP2) ? g.H / 2 : g.H, Win = (AMODE == AMODE_CONV3_UP2) ? g.W / 2 : g.W;
-            a_base[i] = reinterpret_cast<const T*>(g.a) + (size_t)b * Hin * Win * g.C;
+            a_base[i] = reinterpret_cast<const T*>(g.a) + (size_t)b * g.H * g.W * g.C;
             a_y[i] = y; a_x[i] = x;
         }
     }
@@ -154,8 +162,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     }
     const int cpc = (AMODE == AMODE_LINEAR) ? 1 : g.C / CH;     // chunks per conv tap
 
-    u32x4 ra[A_IT * NTAP], rw[W_IT];
-    float bw[A_IT * 4];                 // UP2: bilinear weights of the 4 taps
+    u32x4 ra[A_IT], rw[W_IT];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
     auto load_slab = [&](int kt) {
@@ -174,23 +181,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
                 int yy = a_y[i] + dy, xx = a_x[i] + dx;
                 yy = yy < 0 ? 0 : (yy > g.H - 1 ? g.H - 1 : yy);      // replicate padding (modules.py:53)
                 xx = xx < 0 ? 0 : (xx > g.W - 1 ? g.W - 1 : xx);
-                if (AMODE == AMODE_CONV3) {
-                    ra[i] = kvalid ? *reinterpret_cast<const u32x4*>(a_base[i] + ((size_t)yy * g.W + xx) * g.C + cc * CH) : zero4;
-                } else {
-                    // virtual bilinear x2 upsample (align_corners=False): src = dst/2 - 0.25, clamped at 0
-                    const int Hin = g.H / 2, Win = g.W / 2;
-                    float sy = fmaxf(0.5f * yy - 0.25f, 0.f), sx = fmaxf(0.5f * xx - 0.25f, 0.f);
-                    const int y0 = (int)sy, x0 = (int)sx;
-                    const int y1 = y0 + 1 < Hin ? y0 + 1 : Hin - 1, x1 = x0 + 1 < Win ? x0 + 1 : Win - 1;
-                    const float ly = sy - y0, lx = sx - x0;
-                    bw[i * 4 + 0] = (1.f - ly) * (1.f - lx); bw[i * 4 + 1] = (1.f - ly) * lx;
-                    bw[i * 4 + 2] = ly * (1.f - lx);         bw[i * 4 + 3] = ly * lx;
-                    const T* p = a_base[i] + cc * CH;
-                    ra[i * 4 + 0] = kvalid ? *reinterpret_cast<const u32x4*>(p + ((size_t)y0 * Win + x0) * g.C) : zero4;
-                    ra[i * 4 + 1] = kvalid ? *reinterpret_cast<const u32x4*>(p + ((size_t)y0 * Win + x1) * g.C) : zero4;
-                    ra[i * 4 + 2] = kvalid ? *reinterpret_cast<const u32x4*>(p + ((size_t)y1 * Win + x0) * g.C) : zero4;
-                    ra[i * 4 + 3] = kvalid ? *reinterpret_cast<const u32x4*>(p + ((size_t)y1 * Win + x1) * g.C) : zero4;
-                }
+                ra[i] = kvalid ? *reinterpret_cast<const u32x4*>(a_base[i] + ((size_t)yy * g.W + xx) * g.C + cc * CH) : zero4;
             }
         }
 #pragma unroll
@@ -204,11 +195,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < A_IT; i++) {
             const int row = r0 + i * RSTEP;
-            u32x4 v;
-            if (AMODE == AMODE_CONV3_UP2)
-                v = blend4_chunk<T>(ra[i * 4], ra[i * 4 + 1], ra[i * 4 + 2], ra[i * 4 + 3], bw[i * 4], bw[i * 4 + 1], bw[i * 4 + 2], bw[i * 4 + 3]);
-            else
-                v = ra[i];
+            u32x4 v = ra[i];
             if (g.relu_in) v = relu_chunk<T>(v);
             *reinterpret_cast<u32x4*>(dA + row * 128 + (swz<8>(row, c) << 4)) = v;
         }
@@ -273,6 +260,139 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// LINEAR-mode variant with direct-to-LDS staging (global_load_lds_dwordx4): no VGPR round trip, no ds_write pass.
+// One wave-instruction fills 8 tile rows (1 KiB, lane-linear in LDS); the XOR swizzle is applied to the per-lane
+// SOURCE chunk (lane p of a row fetches logical chunk p ^ ((row>>1)&7)), reads use the same XOR.  Requirements:
+// K % (8*CH) == 0 (no K tail: the DMA cannot zero-fill), no ReLU prologue.  Blocks are remapped so that each XCD
+// owns a contiguous range of tiles (A row-panels stay in one XCD's L2).
+// ------------------------------------------------------------------------------------------------------------
+#define GLDS_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define GLDS_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <typename T, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs g) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int CH = TT<T>::CH;
+    constexpr int RSTEP = NT / 8;
+    constexpr int A_IT = BM / RSTEP, W_IT = BN / RSTEP;
+    static_assert(BM % RSTEP == 0 && BN % RSTEP == 0 && (RSTEP % 16) == 0, "tile/thread mismatch");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;
+    char* sW = smem + 2 * BM * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nbn = (g.N + BN - 1) / BN;
+    // XCD-aware bijective remap (block b runs on XCD b % 8): XCD x gets a contiguous chunk of tile ids
+    const int nwg = gridDim.x;
+    int wg;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int bm = wg / nbn, bn = wg - bm * nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int nkt = g.K / (8 * CH);
+    const int r0 = tid >> 3;
+    const int csrc = (tid & 7) ^ ((r0 >> 1) & 7);       // logical chunk this lane fetches (same for every pass: RSTEP % 16 == 0)
+
+    const T* a_src[A_IT];
+    const T* w_src[W_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; i++) {
+        int m = m0 + r0 + i * RSTEP;
+        m = m < g.M ? m : g.M - 1;
+        a_src[i] = reinterpret_cast<const T*>(g.a) + (size_t)m * g.lda + csrc * CH;
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; i++) {
+        int n = n0 + r0 + i * RSTEP;
+        n = n < g.N ? n : g.N - 1;
+        w_src[i] = reinterpret_cast<const T*>(g.w) + (size_t)n * g.ldw + csrc * CH;
+    }
+    const int wrow = wave * 8;                           // first tile row this wave fills in each pass
+
+    auto issue = [&](int kt, int buf) {
+        char* dA = sA + buf * BM * 128 + wrow * 128;
+        char* dW = sW + buf * BN * 128 + wrow * 128;
+#pragma unroll
+        for (int i = 0; i < A_IT; i++)
+            __builtin_amdgcn_global_load_lds(GLDS_GPTR(a_src[i] + (size_t)kt * 8 * CH), GLDS_LPTR(dA + i * RSTEP * 128), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < W_IT; i++)
+            __builtin_amdgcn_global_load_lds(GLDS_GPTR(w_src[i] + (size_t)kt * 8 * CH), GLDS_LPTR(dW + i * RSTEP * 128), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
+        const char* cA = sA + buf * BM * 128;
+        const char* cW = sW + buf * BN * 128;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int cs = 2 * s + hi;
+            u32x4 af[TM], wf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int row = (wm * TM + i) * 32 + l31;
+                af[i] = *reinterpret_cast<const u32x4*>(cA + row * 128 + (swz<8>(row, cs) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int row = (wn * TN + j) * 32 + l31;
+                wf[j] = *reinterpret_cast<const u32x4*>(cW + row * 128 + (swz<8>(row, cs) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) mma_step<T>(acc[i][j], wf[j], af[i]);
+        }
+        __syncthreads();          // drains the DMA (vmcnt(0)) and orders it against the next slab's reads
+    }
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int m = m0 + (wm * TM + i) * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int nb = n0 + (wn * TN + j) * 32 + 4 * hi;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                epilogue4<T>(g, m, nb + 8 * q, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        }
+    }
+}
+
+template <typename T, int WM, int WN, int TM, int TN>
+static int launch_glds(const GemmArgs& g, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int smem = 2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    auto kern = gemm_glds_kernel<T, WM, WN, TM, TN>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(64 * WM * WN), smem, st, g);
+    return (int)hipGetLastError();
+}
+
 template <typename T, int WM, int WN, int TM, int TN, int AMODE>
 static int launch_cfg(const GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -289,22 +409,37 @@ static int launch_cfg(const GemmArgs& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+static int tune_flag(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static int g_conv_bm256 = -1;   // MOGE_CONV_BM256: 256-row tiles for the narrow-N (Cout <= 64) implicit-GEMM convs
+
 template <typename T, int AMODE>
 static int launch_by_n(const GemmArgs& g, hipStream_t st) {
+    if (g_conv_bm256 < 0) g_conv_bm256 = tune_flag("MOGE_CONV_BM256", 0);
     if (g.N > 64) return launch_cfg<T, 2, 2, 2, 2, AMODE>(g, st);     // 128 x 128
+    if (g_conv_bm256 && g.M >= 4096) {
+        if (g.N > 32) return launch_cfg<T, 4, 1, 2, 2, AMODE>(g, st); // 256 x 64
+        return launch_cfg<T, 4, 1, 2, 1, AMODE>(g, st);               // 256 x 32
+    }
     if (g.N > 32) return launch_cfg<T, 4, 1, 1, 2, AMODE>(g, st);     // 128 x 64
     return launch_cfg<T, 4, 1, 1, 1, AMODE>(g, st);                   // 128 x 32
 }
 
+int g_disable_glds = -1;    // MOGE_DISABLE_GLDS=1 forces the register-staged kernel (A/B hook)
+
 template <typename T>
 int launch_gemm(const GemmArgs& g, int amode, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return -1;
+    if (g_disable_glds < 0) g_disable_glds = tune_flag("MOGE_DISABLE_GLDS", 0);
     if ((g.K % TT<T>::CH) != 0 || (g.N % 4) != 0) return -1;
     if (amode != AMODE_LINEAR && (g.C % TT<T>::CH) != 0) return -1;
     switch (amode) {
-    case AMODE_LINEAR: return launch_by_n<T, AMODE_LINEAR>(g, st);
+    case AMODE_LINEAR:
+        if (g.N > 64 && !g.relu_in && (g.K % (8 * TT<T>::CH)) == 0 && !g_disable_glds) return launch_glds<T, 2, 2, 2, 2>(g, st);
+        return launch_by_n<T, AMODE_LINEAR>(g, st);
     case AMODE_CONV3: return launch_by_n<T, AMODE_CONV3>(g, st);
-    case AMODE_CONV3_UP2: return launch_by_n<T, AMODE_CONV3_UP2>(g, st);
     }
     return -1;
 }

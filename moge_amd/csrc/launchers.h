@@ -18,6 +18,8 @@ template <typename TD>
 int launch_repack(const float* src, void* dst, int n0, int n1, int n2, int n3, long ss0, long ss1, long ss2, long ss3, long ds0, long ds1,
                   long ds2, hipStream_t st);
 
+template <typename T> int launch_pack_phase_conv(const float* w, void* dst, int Cout, int Cin, hipStream_t st);
+
 template <typename T>
 int launch_head_final(int kind, const void* x4, const float* w, const float* bias, float* out, int B, int Hd, int Wd, int C, int H, int W,
                       int remap, hipStream_t st);

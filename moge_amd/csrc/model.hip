@@ -164,7 +164,8 @@ static void build_tables(moge_handle* h) {
             } else {
                 tadd(h, name + S(".resamplers.%d.1.weight", l), (int64_t)co * ci * 9);
                 tadd(h, name + S(".resamplers.%d.1.bias", l), co);
-                padd(h, name + S(".rs%d.w3", l), (int64_t)co * 9 * ci);
+                padd(h, name + S(".rs%d.w3p", l), (int64_t)4 * co * 9 * ci);
+                aadd(h, name + S(".rs%d.bias4", l), 4 * co);
             }
         }
         for (int l = 0; l < MOGE_LEVELS; l++)
@@ -239,6 +240,9 @@ static int build_aux(moge_handle* h, hipStream_t st) {
             const int co = c.dims[l + 1];
             LCHK(launch_repack<float>(M(h, name + S(".resamplers.%d.0.bias", l)), A(h, name + S(".rs%d.biasT", l)), 4, 1, 1, co, 0, 0, 0, 1, co, 0, 0, st));
         }
+        // level 3->4 (bilinear + 3x3 as a 4-phase conv): bias replicated per phase; the neck adds its level-4 input-block bias
+        const float* b4 = name == "neck" ? A(h, "neck.rs3.bias2") : M(h, name + ".resamplers.3.1.bias");
+        LCHK(launch_repack<float>(b4, A(h, name + ".rs3.bias4"), 4, 1, 1, c.dims[4], 0, 0, 0, 1, c.dims[4], 0, 0, st));
         return 0;
     };
     CHK(stack("neck"));
@@ -287,7 +291,7 @@ static int pack_weights(moge_handle* h, hipStream_t st) {
                                       (long)co * ci, ci, 0, st));
                 LCHK(conv3(M(h, name + S(".resamplers.%d.1.weight", l)), Pm<T>(h, name + S(".rs%d.w3", l)), co, co));
             } else {
-                LCHK(conv3(M(h, name + S(".resamplers.%d.1.weight", l)), Pm<T>(h, name + S(".rs%d.w3", l)), co, ci));
+                LCHK(launch_pack_phase_conv<T>(M(h, name + S(".resamplers.%d.1.weight", l)), Pm<T>(h, name + S(".rs%d.w3p", l)), co, ci, st));
             }
         }
         for (int l = 0; l < MOGE_LEVELS; l++)
@@ -410,7 +414,7 @@ static int run_gemm(moge_handle* h, const GemmArgs& g, int amode, int cls, hipSt
 
 template <typename T>
 static int conv3x3(moge_handle* h, const T* in, const T* w, const float* bias, T* out, int B, int Hh, int Ww, int Cin, int Cout, int relu_in,
-                   int act, const T* add, const UVTerm* uv, bool up2, hipStream_t st) {
+                   int act, const T* add, const UVTerm* uv, hipStream_t st) {
     GemmArgs g = gemm_args();
     g.a = in; g.H = Hh; g.W = Ww; g.C = Cin; g.relu_in = relu_in;
     g.w = w; g.ldw = 9 * Cin;
@@ -418,7 +422,20 @@ static int conv3x3(moge_handle* h, const T* in, const T* w, const float* bias, T
     g.epi = EPI_STORE; g.act = act; g.bias = bias; g.out = out; g.ldc = Cout; g.add = add; g.ldadd = Cout;
     g.pixW = Ww; g.pixH = Hh;
     if (uv) g.uv = *uv;
-    return run_gemm<T>(h, g, up2 ? AMODE_CONV3_UP2 : AMODE_CONV3, MOGE_KC_CONV, st);
+    return run_gemm<T>(h, g, AMODE_CONV3, MOGE_KC_CONV, st);
+}
+
+// bilinear x2 + 3x3 conv as a 4-phase 3x3 conv on the low-res map (Hl,Wl), output (B,2Hl,2Wl,Cout); uv given for the HIGH-res grid
+template <typename T>
+static int conv_up2_phase(moge_handle* h, const T* in, const T* w4, const float* bias4, T* out, int B, int Hl, int Wl, int Cin, int Cout,
+                          const UVTerm* uv, hipStream_t st) {
+    GemmArgs g = gemm_args();
+    g.a = in; g.H = Hl; g.W = Wl; g.C = Cin;
+    g.w = w4; g.ldw = 9 * Cin;
+    g.M = B * Hl * Wl; g.N = 4 * Cout; g.K = 9 * Cin;
+    g.epi = EPI_CONVT; g.bias = bias4; g.out = out; g.Cout = Cout; g.pixW = Wl; g.pixH = Hl;
+    if (uv) g.uv = *uv;
+    return run_gemm<T>(h, g, AMODE_CONV3, MOGE_KC_CONV, st);
 }
 
 template <typename T>
@@ -447,9 +464,9 @@ static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* 
     for (int j = 0; j < n; j++) {
         // x = x + conv2(relu(conv1(relu(x))))   (modules.py:47-68 with norms = Identity)
         CHK(conv3x3<T>(h, x, P<T>(h, name + S(".res%d.%d.w1", l, j)), M(h, name + S(".res_blocks.%d.%d.layers.2.bias", l, j)), tmp, B, Hh, Ww, C, C, 1,
-                       ACT_RELU, nullptr, nullptr, false, st));
+                       ACT_RELU, nullptr, nullptr, st));
         CHK(conv3x3<T>(h, tmp, P<T>(h, name + S(".res%d.%d.w2", l, j)), M(h, name + S(".res_blocks.%d.%d.layers.5.bias", l, j)), x, B, Hh, Ww, C, C, 0,
-                       ACT_NONE, x, nullptr, false, st));
+                       ACT_NONE, x, nullptr, st));
     }
     return 0;
 }
@@ -593,10 +610,9 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
             if (l <= 3) {
                 CHK(convT2<T>(h, N[l - 1], P<T>(h, S("neck.rs%d.wT", l - 1)), A(h, S("neck.rs%d.biasT", l - 1)), Sc[0], B, Hh / 2, Ww / 2, ci, co, st));
                 CHK(conv3x3<T>(h, Sc[0], P<T>(h, S("neck.rs%d.w3", l - 1)), A(h, S("neck.rs%d.bias2", l - 1)), N[l], B, Hh, Ww, co, co, 0, ACT_NONE, nullptr,
-                               &uvl, false, st));
+                               &uvl, st));
             } else {
-                CHK(conv3x3<T>(h, N[l - 1], P<T>(h, S("neck.rs%d.w3", l - 1)), A(h, S("neck.rs%d.bias2", l - 1)), N[l], B, Hh, Ww, ci, co, 0, ACT_NONE, nullptr,
-                               &uvl, true, st));
+                CHK(conv_up2_phase<T>(h, N[l - 1], P<T>(h, "neck.rs3.w3p"), A(h, "neck.rs3.bias4"), N[l], B, Hh / 2, Ww / 2, ci, co, &uvl, st));
             }
             CHK(res_blocks<T>(h, "neck", l, c.neck_res_blocks[l], N[l], Sc[1], B, Hh, Ww, co, st));
         }
@@ -616,11 +632,10 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
             if (l <= 3) {
                 CHK(convT2<T>(h, Sc[cur], P<T>(h, name + S(".rs%d.wT", l - 1)), A(h, name + S(".rs%d.biasT", l - 1)), Sc[a], B, Hh / 2, Ww / 2, ci, co, st));
                 CHK(conv3x3<T>(h, Sc[a], P<T>(h, name + S(".rs%d.w3", l - 1)), M(h, name + S(".resamplers.%d.1.bias", l - 1)), Sc[b2], B, Hh, Ww, co, co, 0,
-                               ACT_NONE, nullptr, nullptr, false, st));
+                               ACT_NONE, nullptr, nullptr, st));
                 nxt = b2;
             } else {
-                CHK(conv3x3<T>(h, Sc[cur], P<T>(h, name + S(".rs%d.w3", l - 1)), M(h, name + S(".resamplers.%d.1.bias", l - 1)), Sc[a], B, Hh, Ww, ci, co, 0,
-                               ACT_NONE, nullptr, nullptr, true, st));
+                CHK(conv_up2_phase<T>(h, Sc[cur], P<T>(h, name + ".rs3.w3p"), A(h, name + ".rs3.bias4"), Sc[a], B, Hh / 2, Ww / 2, ci, co, nullptr, st));
                 nxt = a;
             }
             // x = x + in_l(neck_l)   (in place: each element is read and written by the same lane)

@@ -68,18 +68,24 @@ static int t_attention(const float* q, const float* k, const float* v, float* o,
 
 template <typename T>
 static int t_conv3(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int relu_in, int up2, hipStream_t st) {
-    // for up2, (H,W) are the INPUT dims and the output is (2H,2W)
+    // for up2, (H,W) are the INPUT dims and the output is (2H,2W): bilinear x2 + 3x3 as the 4-phase low-res conv
     const int Ho = up2 ? 2 * H : H, Wo = up2 ? 2 * W : W;
-    DevBuf xb, wb, yb;
+    DevBuf xb, wb, yb, bb;
     const size_t nx = (size_t)B * H * W * Cin, ny = (size_t)B * Ho * Wo * Cout;
-    TCHK(xb.alloc(nx * sizeof(T))); TCHK(wb.alloc((size_t)Cout * 9 * Cin * sizeof(T))); TCHK(yb.alloc(ny * sizeof(T)));
+    TCHK(xb.alloc(nx * sizeof(T))); TCHK(wb.alloc((size_t)4 * Cout * 9 * Cin * sizeof(T))); TCHK(yb.alloc(ny * sizeof(T))); TCHK(bb.alloc(4 * Cout * sizeof(float)));
     TL(to_t<T>(x, xb.p, (long)nx, st));
-    TL(launch_repack<T>(w, wb.p, Cout, 9, 1, Cin, (long)Cin * 9, 1, 0, 9, (long)9 * Cin, Cin, 0, st));
     GemmArgs g; memset(&g, 0, sizeof(g));
-    g.a = xb.p; g.H = Ho; g.W = Wo; g.C = Cin; g.relu_in = relu_in;
-    g.w = wb.p; g.ldw = 9 * Cin; g.M = B * Ho * Wo; g.N = Cout; g.K = 9 * Cin;
-    g.epi = EPI_STORE; g.bias = bias; g.out = yb.p; g.ldc = Cout; g.pixW = Wo; g.pixH = Ho;
-    TL(launch_gemm<T>(g, up2 ? AMODE_CONV3_UP2 : AMODE_CONV3, st));
+    g.a = xb.p; g.H = H; g.W = W; g.C = Cin; g.relu_in = relu_in;
+    g.w = wb.p; g.ldw = 9 * Cin; g.M = B * H * W; g.K = 9 * Cin; g.out = yb.p; g.pixW = W; g.pixH = H;
+    if (up2) {
+        TL(launch_pack_phase_conv<T>(w, wb.p, Cout, Cin, st));
+        TL(launch_repack<float>(bias, bb.p, 4, 1, 1, Cout, 0, 0, 0, 1, Cout, 0, 0, st));
+        g.N = 4 * Cout; g.epi = EPI_CONVT; g.bias = (const float*)bb.p; g.Cout = Cout;
+    } else {
+        TL(launch_repack<T>(w, wb.p, Cout, 9, 1, Cin, (long)Cin * 9, 1, 0, 9, (long)9 * Cin, Cin, 0, st));
+        g.N = Cout; g.epi = EPI_STORE; g.bias = bias; g.ldc = Cout;
+    }
+    TL(launch_gemm<T>(g, AMODE_CONV3, st));
     TL(from_t<T>(yb.p, y, (long)ny, st));
     TCHK(hipStreamSynchronize(st));
     return 0;
@@ -131,7 +137,7 @@ int moge_test_attention(int precision, const float* q, const float* k, const flo
 int moge_test_conv3x3(int precision, const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int relu_in,
                       void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    const int up2 = (relu_in >> 1) & 1, relu = relu_in & 1;      // bit 1 of relu_in selects the fused bilinear x2 loader
+    const int up2 = (relu_in >> 1) & 1, relu = relu_in & 1;      // bit 1 of relu_in selects bilinear x2 + 3x3 (4-phase conv)
     return precision == MOGE_FP16 ? t_conv3<f16>(x, w, bias, y, B, H, W, Cin, Cout, relu, up2, st) : t_conv3<float>(x, w, bias, y, B, H, W, Cin, Cout, relu, up2, st);
 }
 
