@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmoge_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "post.hip", "model.hip", "test_api.hip"]
+SOURCES = ["gemm.hip", "gemm_pp.hip", "attention.hip", "elementwise.hip", "post.hip", "model.hip", "test_api.hip"]
 HEADERS = ["common.h", "launchers.h", os.path.join("..", "..", "include", "moge_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
@@ -61,5 +61,23 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_tools(verbose: bool = True) -> str:
+    """tools/kbench: stand-alone kernel bench/checker linked against the in-tree library (GPU box utility)."""
+    lib = build(verbose=verbose)
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tools", "kbench.hip")
+    out = os.path.join(root, "tools", "kbench")
+    if _stale(out, [src, lib]):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", src, "-o", out, "-L" + LIBDIR, "-lmoge_hip", "-Wl,-rpath,$ORIGIN/../moge_amd/lib"]
+        if verbose:
+            print("[moge_amd.build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--tools" in sys.argv:
+        print(build_tools())

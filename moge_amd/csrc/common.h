@@ -135,11 +135,17 @@ struct GemmArgs {
     int Np, Ntok;
     // EPI_QKV: scatter to q,k (B,nh,Ntok,64) and vT (B,nh,64,Npad); q pre-scaled by qscale
     void* q; void* k; void* vT;
+    int v_rowmajor;        // 1: V goes to vT as (B,nh,Ntok,64) like K (attention_pp); 0: transposed (B,nh,64,Npad)
     int nh, Npad, D;
     float qscale;
     // EPI_CONVT: n = (dy*2+dx)*Cout + co -> out[((b*2H+2y+dy)*2W+2x+dx)*Cout+co]
     int Cout;
+    int dbg;               // gemm_pp ablation bits (tools/kbench only): 1 no DMA, 2 no LDS reads, 4 no MFMA, 8 no barriers
 };
 
-// host-side launchers (gemm.hip)
+// host-side launchers (gemm.hip, gemm_pp.hip)
 template <typename T> int launch_gemm(const GemmArgs& g, int amode, hipStream_t st);
+bool gemm_pp_eligible(const GemmArgs& g);
+int launch_gemm_pp(const GemmArgs& g, hipStream_t st);
+// runtime tuning / A-B switches (tests, tools/kbench): see tune.cpp-style table in gemm.hip
+int moge_tune_get(const char* key, int dflt);

@@ -83,6 +83,8 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float
             store4(reinterpret_cast<T*>(g.q) + (bh * g.Ntok + tok) * 64 + d, v[0] * g.qscale, v[1] * g.qscale, v[2] * g.qscale, v[3] * g.qscale);
         } else if (which == 1) {
             store4(reinterpret_cast<T*>(g.k) + (bh * g.Ntok + tok) * 64 + d, v[0], v[1], v[2], v[3]);
+        } else if (g.v_rowmajor) {
+            store4(reinterpret_cast<T*>(g.vT) + (bh * g.Ntok + tok) * 64 + d, v[0], v[1], v[2], v[3]);
         } else {
             T* p = reinterpret_cast<T*>(g.vT) + (bh * 64 + d) * (size_t)g.Npad + tok;
 #pragma unroll
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
 #define GLDS_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define GLDS_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <typename T, int WM, int WN, int TM, int TN>
+template <typename T, int WM, int WN, int TM, int TN, int NSTAGE>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs g) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
-    char* sW = smem + 2 * BM * 128;
+    char* sW = smem + NSTAGE * BM * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
@@ -336,11 +338,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    issue(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; kt++) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
+    auto compute = [&](int buf) {
         const char* cA = sA + buf * BM * 128;
         const char* cW = sW + buf * BN * 128;
 #pragma unroll
@@ -362,7 +360,40 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
 #pragma unroll
                 for (int j = 0; j < TN; j++) mma_step<T>(acc[i][j], wf[j], af[i]);
         }
-        __syncthreads();          // drains the DMA (vmcnt(0)) and orders it against the next slab's reads
+    };
+
+    if constexpr (NSTAGE == 1) {
+        // single LDS buffer, two barriers per slab: latency is hidden by co-resident blocks (32 KiB LDS -> 3-4 blocks/CU)
+        for (int kt = 0; kt < nkt; kt++) {
+            issue(kt, 0);
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
+    } else if constexpr (NSTAGE == 2) {
+        issue(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; kt++) {
+            const int buf = kt & 1;
+            if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
+            compute(buf);
+            __syncthreads();          // drains the DMA (vmcnt(0)) and orders it against the next slab's reads
+        }
+    } else {
+        // 3-slab ring, DMA two slabs ahead, ONE raw barrier per slab and a COUNTED vmcnt so the newest slab's loads stay in
+        // flight across the barrier (a __syncthreads() here would drain them: LDS-DMA counts as a pending LDS write).
+        constexpr int G = A_IT + W_IT;           // DMA instructions per thread per slab
+        issue(0, 0);
+        if (nkt > 1) issue(1, 1);
+        int cur = 0;
+        for (int kt = 0; kt < nkt; kt++) {
+            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();        // slab kt landed for every wave; every wave is done reading slab kt-1
+            if (kt + 2 < nkt) issue(kt + 2, cur == 0 ? 2 : cur - 1);
+            compute(cur);
+            cur = cur == 2 ? 0 : cur + 1;
+        }
     }
 #pragma unroll
     for (int i = 0; i < TM; i++) {
@@ -377,12 +408,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
     }
 }
 
-template <typename T, int WM, int WN, int TM, int TN>
+template <typename T, int WM, int WN, int TM, int TN, int NSTAGE>
 static int launch_glds(const GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int smem = 2 * (BM + BN) * 128;
+    constexpr int smem = NSTAGE * (BM + BN) * 128;
     static bool attr_set = false;
-    auto kern = gemm_glds_kernel<T, WM, WN, TM, TN>;
+    auto kern = gemm_glds_kernel<T, WM, WN, TM, TN, NSTAGE>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
@@ -409,15 +440,26 @@ static int launch_cfg(const GemmArgs& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-static int tune_flag(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
+// ---- runtime tuning switches: environment (MOGE_<KEY>) overridden by moge_tune_set(key, value) -------------------------
+#include <map>
+#include <string>
+#include <type_traits>
+static std::map<std::string, int>& tune_table() { static std::map<std::string, int> t; return t; }
+int moge_tune_get(const char* key, int dflt) {
+    auto& t = tune_table();
+    auto it = t.find(key);
+    if (it != t.end()) return it->second;
+    const std::string env = std::string("MOGE_") + key;
+    const char* e = getenv(env.c_str());
+    const int v = e ? atoi(e) : dflt;
+    t[key] = v;                        // cache: launches look switches up on every call
+    return v;
 }
-static int g_conv_bm256 = -1;   // MOGE_CONV_BM256: 256-row tiles for the narrow-N (Cout <= 64) implicit-GEMM convs
+extern "C" void moge_tune_set(const char* key, int value) { tune_table()[key] = value; }
 
 template <typename T, int AMODE>
 static int launch_by_n(const GemmArgs& g, hipStream_t st) {
-    if (g_conv_bm256 < 0) g_conv_bm256 = tune_flag("MOGE_CONV_BM256", 0);
+    const int g_conv_bm256 = moge_tune_get("CONV_BM256", 0);
     if (g.N > 64) return launch_cfg<T, 2, 2, 2, 2, AMODE>(g, st);     // 128 x 128
     if (g_conv_bm256 && g.M >= 4096) {
         if (g.N > 32) return launch_cfg<T, 4, 1, 2, 2, AMODE>(g, st); // 256 x 64
@@ -427,17 +469,25 @@ static int launch_by_n(const GemmArgs& g, hipStream_t st) {
     return launch_cfg<T, 4, 1, 1, 1, AMODE>(g, st);                   // 128 x 32
 }
 
-int g_disable_glds = -1;    // MOGE_DISABLE_GLDS=1 forces the register-staged kernel (A/B hook)
-
 template <typename T>
 int launch_gemm(const GemmArgs& g, int amode, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return -1;
-    if (g_disable_glds < 0) g_disable_glds = tune_flag("MOGE_DISABLE_GLDS", 0);
+    const int g_disable_glds = moge_tune_get("DISABLE_GLDS", 0);
     if ((g.K % TT<T>::CH) != 0 || (g.N % 4) != 0) return -1;
     if (amode != AMODE_LINEAR && (g.C % TT<T>::CH) != 0) return -1;
     switch (amode) {
     case AMODE_LINEAR:
-        if (g.N > 64 && !g.relu_in && (g.K % (8 * TT<T>::CH)) == 0 && !g_disable_glds) return launch_glds<T, 2, 2, 2, 2>(g, st);
+        if constexpr (std::is_same<T, f16>::value) {
+            if (moge_tune_get("GEMM_PP", 1) && gemm_pp_eligible(g)) return launch_gemm_pp(g, st);
+        }
+        if (g.N > 64 && !g.relu_in && (g.K % (8 * TT<T>::CH)) == 0 && !g_disable_glds) {
+            switch (moge_tune_get("GLDS_VARIANT", 2)) {
+            case 1: return launch_glds<T, 2, 2, 2, 2, 1>(g, st);       // 128x128, single buffer
+            case 2: return launch_glds<T, 2, 2, 2, 2, 2>(g, st);       // 128x128, double buffer
+            case 4: return launch_glds<T, 2, 2, 2, 2, 3>(g, st);       // 128x128, 3-slab ring
+            default: return launch_glds<T, 4, 2, 2, 2, 3>(g, st);      // 256x128, 8 waves, 3-slab ring
+            }
+        }
         return launch_by_n<T, AMODE_LINEAR>(g, st);
     case AMODE_CONV3: return launch_by_n<T, AMODE_CONV3>(g, st);
     }

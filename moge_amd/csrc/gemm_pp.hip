@@ -1,0 +1,523 @@
+// "Ping-pong" MFMA GEMM for the big fp16 linear layers of the MoGe-2 hot path (gfx950 / CDNA4).
+//
+//   C[M,N] = A[M,K] * W[N,K]^T      A: fp16 activations [M][lda], W: fp16 weights [N][ldw], both K-contiguous
+//
+// Serves (f16 mode): ViT qkv / proj / fc1 / fc2 (attention.py:72,79  mlp.py:35,38), the summed output projections
+// (modules.py:128-131), the level-0 1x1 input blocks and the ConvTranspose2d-as-GEMM resamplers (modules.py:162,245).
+// The fp32 parity mode and every shape this kernel does not take stay on gemm.hip.
+//
+// Structure (one workgroup per CU, 8 waves = 2 per SIMD, 256 x BN output tile, BN = 256 or 128):
+//   * K is consumed in PHASES of 32 halves (64 bytes per tile row).  A phase's A and W rows live in one LDS slot
+//     [BM+BN rows][64 B]; four slots form a ring, filled by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip).
+//     One wave-instruction fills 16 rows (1 KiB, lane-linear in LDS); the XOR swizzle that makes ds_read_b128
+//     conflict-free (chunk ^ ((row>>2)&3)) is applied to the per-lane SOURCE chunk and to the read address.
+//   * The two waves of every SIMD are in different wave GROUPS (waves 0-3 / 4-7) that run half a phase apart:
+//     while one group issues its 16 MFMAs (32x32x16, "compute segment"), the other reads its fragments from LDS and
+//     issues the DMA for phase+3 ("load segment"); an s_barrier separates the segments, so each SIMD's matrix pipe
+//     always has exactly one wave feeding it and LDS / DMA latency sits under the partner's MFMAs.
+//   * DMA completion is tracked with COUNTED s_waitcnt vmcnt(N) (two phases stay in flight across the barriers);
+//     raw s_barrier only - __syncthreads() would drain the DMA queue.
+//   * The MFMA is issued "swapped" (A-operand = weight rows) so a lane owns ONE output row and 4 consecutive
+//     columns per register quad.  The epilogue applies bias / activation / LayerScale in registers, transposes the
+//     wave's 128x64 (or 64x64) sub-tile through its private LDS region and writes / read-modify-writes global memory
+//     in full 128-byte row segments (row-per-lane stores cost one cache-line lookup per lane on this chip).
+#include "common.h"
+
+#define PP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define PP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// gelu(x) = x * Phi(x) with Phi(x) = sigmoid(x * P(x^2)); P fitted (weighted minimax, degree 4 in x^2) to
+// logit(Phi(x))/x on |x| <= 5, max abs error of gelu 3.7e-6 over all x (P grows for |x| > 5, so both tails saturate
+// correctly: exp2 -> 0 or +inf).  8 VALU + 2 transcendentals per element instead of erff's ~35.  f16 outputs only.
+__device__ __forceinline__ float gelu_fast(float x) {
+    constexpr float L2E = 1.4426950408889634f;
+    const float x2 = x * x;
+    float p = 2.09755530e-06f * L2E;
+    p = fmaf(p, x2, -5.83663339e-05f * L2E);
+    p = fmaf(p, x2, -2.66659641e-04f * L2E);
+    p = fmaf(p, x2, 7.29729188e-02f * L2E);
+    p = fmaf(p, x2, 1.59563637f * L2E);
+    const float e = __builtin_amdgcn_exp2f(-(p * x));
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// ---- shared epilogue: this wave's (TM*32) x 64 accumulator tile -> global memory ---------------------------------
+// Every wave has passed the final barrier: all LDS reads and all DMA writes of the ring are complete, so each wave may
+// reuse its private 16 KiB (TM = 4) / 8 KiB (TM = 2) region of the ring for the output transpose.
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+
+template <int TM, bool RESID>
+__device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][2], char* smem, int wave, int lane, int mw, int nw) {
+    constexpr int TN = 2;
+    constexpr int WROWS = TM * 32;
+    const int hi = lane >> 5, l31 = lane & 31;
+    char* R = smem + wave * (WROWS * 128);
+    const int rr = lane >> 3, cc = lane & 7;
+
+    if constexpr (RESID) {
+        // x[m][n] += gamma[n] * (acc + bias[n])  on the fp32 residual stream (block.py:111-112, layer_scale.py:27)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int n = nw + j * 32 + 8 * q + 4 * hi;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
+#pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    const int row = i * 32 + l31;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = gm[e] * (acc[i][j][4 * q + e] + b[e]);
+                    *reinterpret_cast<f32x4*>(R + row * 128 + (((2 * q + hi) ^ (row & 7)) << 4)) = v;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < WROWS / 8; it++) {
+                const int row = it * 8 + rr;
+                const int m = mw + row;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
+                if (m < g.M) {
+                    float* p = g.xres + (size_t)m * g.ldc + nw + j * 32 + cc * 4;
+                    f32x4 x = *reinterpret_cast<const f32x4*>(p);
+                    x += v;
+                    *reinterpret_cast<f32x4*>(p) = x;
+                }
+            }
+        }
+    } else {
+        // bias (+ uv rank-2 term) (+ q scale) (+ GELU) in registers, pack to f16, transpose through LDS, 16-byte row stores
+        float scale = 1.f;
+        if (g.epi == EPI_QKV && nw < g.D) scale = g.qscale;
+        float u[TM], vv[TM];
+        if (g.uv.wu) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                int m = mw + i * 32 + l31;
+                m = m < g.M ? m : g.M - 1;
+                const int x = m % g.pixW, y = (m / g.pixW) % g.pixH;
+                u[i] = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, g.pixW, x);
+                vv[i] = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, g.pixH, y);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int n = nw + j * 32 + 8 * q + 4 * hi;
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (g.bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+                f32x4 wu = {0.f, 0.f, 0.f, 0.f}, wv = wu;
+                if (g.uv.wu) {
+                    wu = *reinterpret_cast<const f32x4*>(g.uv.wu + n);
+                    wv = *reinterpret_cast<const f32x4*>(g.uv.wv + n);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    const int row = i * 32 + l31;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = (acc[i][j][4 * q + e] + b[e]) * scale;
+                    if (g.uv.wu) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] += wu[e] * u[i] + wv[e] * vv[i];
+                    }
+                    if (g.act == ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = gelu_fast(v[e]);
+                    } else if (g.act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    const f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                    *reinterpret_cast<f16x4*>(R + row * 128 + ((((j * 4 + q) ^ (row & 7)) << 4) | (hi << 3))) = hv;
+                }
+            }
+        // ---- row base pointers of the three store flavours (all advance by rows of 8 per iteration) -----------------
+        f16* obase;
+        long rstride = 0;                 // EPI_STORE only
+        int t0 = 0, b0 = 0;               // EPI_QKV: token / batch of this lane's first row
+        int px = 0, py = 0, pb = 0;       // EPI_CONVT: low-res pixel of this lane's first row
+        int co0 = 0, dy = 0, dx = 0;
+        const int mfirst = mw + rr;
+        if (g.epi == EPI_QKV) {
+            const int which = nw / g.D;
+            const int head = (nw - which * g.D) >> 6;
+            obase = reinterpret_cast<f16*>(which == 0 ? g.q : (which == 1 ? g.k : g.vT)) + (size_t)head * g.Ntok * 64;
+            b0 = mfirst / g.Ntok;
+            t0 = mfirst - b0 * g.Ntok;
+        } else if (g.epi == EPI_CONVT) {
+            const int qd = nw / g.Cout;
+            co0 = nw - qd * g.Cout; dy = qd >> 1; dx = qd & 1;
+            obase = reinterpret_cast<f16*>(g.out);
+            px = mfirst % g.pixW;
+            const int t = mfirst / g.pixW;
+            py = t % g.pixH; pb = t / g.pixH;
+        } else {
+            obase = reinterpret_cast<f16*>(g.out) + nw;
+            rstride = g.ldc;
+        }
+#pragma unroll
+        for (int it = 0; it < WROWS / 8; it++) {
+            const int row = it * 8 + rr;
+            const int m = mw + row;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
+            f16* p;
+            if (g.epi == EPI_QKV) {
+                p = obase + ((size_t)b0 * g.nh * g.Ntok + t0) * 64 + cc * 8;
+                t0 += 8;
+                if (t0 >= g.Ntok) { t0 -= g.Ntok; b0 += 1; }
+            } else if (g.epi == EPI_CONVT) {
+                p = obase + ((((size_t)pb * 2 * g.pixH + 2 * py + dy) * (2 * g.pixW)) + 2 * px + dx) * g.Cout + co0 + cc * 8;
+                px += 8;
+                if (px >= g.pixW) { px -= g.pixW; py += 1; if (py >= g.pixH) { py = 0; pb += 1; } }
+            } else {
+                p = obase + (size_t)m * rstride + cc * 8;
+            }
+            if (m < g.M) *reinterpret_cast<u32x4*>(p) = v;
+        }
+    }
+}
+
+template <int WM, int WN, int TM, bool RESID>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs g) {
+    constexpr int TN = 2;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static_assert(WM * WN == 8 && BM == 256, "8 waves, 256-row tiles");
+    constexpr int SLOT = (BM + BN) * 64;          // bytes per ring slot (one phase)
+    constexpr int NPW = (BM + BN) / 128;          // DMA pieces (16 rows x 64 B) per wave per phase
+    constexpr int NPA = BM / 128;                 // the first NPA of them are A rows, the rest W rows
+    constexpr int WROWS = TM * 32;                // output rows per wave
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 * SLOT (ring), reused by the epilogue
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                    // wave group: waves w and w+4 share a SIMD
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware bijective remap (block b runs on XCD b % 8): every XCD owns a contiguous range of tile ids, so the
+    // 32 tiles in flight on one XCD share A row-panels / W column-panels through that XCD's L2.
+    const int nbn = g.N / BN;
+    int wg;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int bm = wg / nbn, bn = wg - bm * nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int nph = g.K >> 5;
+
+    // ---- DMA source pointers: piece i of this wave covers ring rows [(wave + 8 i) * 16, +16) -------------------
+    const int prow = lane >> 2;
+    const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);          // logical 16-byte chunk this lane fetches
+    const f16* src[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; i++) {
+        const int r = (wave + 8 * i) * 16 + prow;
+        if (i < NPA) {
+            int m = m0 + r;
+            m = m < g.M ? m : g.M - 1;
+            src[i] = reinterpret_cast<const f16*>(g.a) + (size_t)m * g.lda + lchunk * 8;
+        } else {
+            const int n = n0 + r - BM;
+            src[i] = reinterpret_cast<const f16*>(g.w) + (size_t)n * g.ldw + lchunk * 8;
+        }
+    }
+    auto issue = [&](int ph) {
+        char* dst = smem + (ph & 3) * SLOT + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NPW; i++)
+            __builtin_amdgcn_global_load_lds(PP_GPTR(src[i] + (size_t)ph * 32), PP_LPTR(dst + i * 8192), 16, 0, 0);
+    };
+
+    // ---- fragment read offsets (bytes inside a slot) --------------------------------------------------------------
+    const int sx = (l31 >> 2) & 3;
+    const int a_off = (wm * WROWS + l31) * 64 + ((hi ^ sx) << 4);            // k-step 0; k-step 1 is a_off ^ 32
+    const int w_off = (BM + wn * 64 + l31) * 64 + ((hi ^ sx) << 4);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // ---- prologue: three phases in flight, phase 0 landed for everybody, then stagger the groups ------------------
+    issue(0);
+    if (nph > 1) issue(1);
+    if (nph > 2) issue(2);
+    if (nph > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+    else if (nph > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1 && !(g.dbg & 8)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int dbg = g.dbg;
+    u32x4 af[TM][2], wf[TN][2];
+    for (int ph = 0; ph < nph; ph++) {
+        // ======== load segment ========
+        const char* sl = smem + (ph & 3) * SLOT;
+        if (!(dbg & 2) || ph == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            af[i][0] = *reinterpret_cast<const u32x4*>(sl + a_off + i * 2048);
+            af[i][1] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ 32) + i * 2048);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            wf[j][0] = *reinterpret_cast<const u32x4*>(sl + w_off + j * 2048);
+            wf[j][1] = *reinterpret_cast<const u32x4*>(sl + (w_off ^ 32) + j * 2048);
+        }
+        }
+        // refill the slot phase ph-1 vacated (every wave finished reading it before the barrier that opened this segment)
+        if (dbg & 1) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else if (ph + 3 < nph) {
+            issue(ph + 3);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NPW) : "memory");     // phase ph+1 landed (this wave's pieces)
+        } else if (ph + 2 < nph) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ======== compute segment ========
+        __builtin_amdgcn_s_setprio(1);
+        if (!(dbg & 4))
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) mma_step<f16>(acc[i][j], wf[j][s], af[i][s]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        if (!(grp == 1 && ph == nph - 1) && !(dbg & 8)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // Every wave has passed 2*nph + 1 barriers; all LDS reads and all DMA writes of the ring are complete, so each wave
+    // may now reuse its private 16 KiB (TM = 4) / 8 KiB (TM = 2) region of the ring for the output transpose.
+
+    pp_epilogue<TM, RESID>(g, acc, smem, wave, lane, m0 + wm * WROWS, n0 + wn * 64);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, full-line DMA.  The 64-byte row segments of the kernel above are served by the L2 as half-line
+// requests (measured: the DMA stream saturates the L2 request rate at ~55 % MFMA utilisation), so this variant stages
+// whole K-tiles of 64 halves = 128-byte rows (one L2 line per row) and splits a K-tile's work by OUTPUT rows instead:
+//   phase a: A rows {0-63 of the wave's 128} x W (all 64 columns) x K=64   (16 reads: 8 A + 8 W, 16 MFMAs)
+//   phase b: A rows {64-127}                 x W fragments kept in VGPRs   ( 8 reads,             16 MFMAs)
+// so W and the "lo" A rows of a K-tile are dead after phase a and the "hi" A rows after phase b; with two buffers per
+// operand every DMA piece still has three phases (six barrier intervals) to land.  DMA issue order per wave:
+//   X1(t) = {W pieces 0,1; A_lo pieces 0,1}   X2(t) = {W pieces 2,3; A_hi pieces 0,1}
+//   X1(0) X2(0) X1(1) | L_a(0): X2(1) | L_b(0): X1(2) | L_a(1): X2(2) | ...
+// counted waits: vmcnt(8) after L_a (X2(t) = A_hi(t) landed), vmcnt(6) after L_b (X1(t+1) and the W half of X2(t+1)).
+// LDS: [parity][A 256 rows x 128 B | W 256 rows x 128 B], chunk swizzle c ^ ((row >> 1) & 7).
+// ------------------------------------------------------------------------------------------------------------------------
+template <bool RESID>
+__global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
+    constexpr int TM = 4, TN = 2, WN = 4, BM = 256, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 * 64 KiB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nbn = g.N / BN;
+    int wg;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int bm = wg / nbn, bn = wg - bm * nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int nkt = g.K >> 6;
+    const int dbg = g.dbg;
+
+    // ---- DMA sources.  A piece = 8 rows x 128 B; this wave's pieces start at rows 8*wave (+ region offsets), so the
+    // swizzle term ((row >> 1) & 7) = 4*(wave & 1) + (lane >> 4) is the same for all of them.
+    const int prow = lane >> 3;
+    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) + (lane >> 4));
+    // uniform 64-bit tile bases (SGPRs) + per-lane 32-bit byte offsets: the DMA uses the saddr + voffset form and the
+    // load segment carries no 64-bit VALU address arithmetic
+    const char* baseW = reinterpret_cast<const char*>(g.w) + (size_t)n0 * g.ldw * 2;
+    const char* baseA = reinterpret_cast<const char*>(g.a) + (size_t)m0 * g.lda * 2;
+    unsigned offW[4], offA[4];     // A: 0,1 = lo rows (8w, 128+8w)   2,3 = hi rows (64+8w, 192+8w)
+    const int mlast = g.M - 1 - m0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        offW[k] = (unsigned)(((wave + 8 * k) * 8 + prow) * g.ldw * 2 + lchunk * 16);
+        int arow = (k & 1) * 128 + (k >> 1) * 64 + wave * 8 + prow;
+        arow = arow < mlast ? arow : mlast;
+        offA[k] = (unsigned)(arow * g.lda * 2 + lchunk * 16);
+    }
+    // X1(t): W pieces 0,1 + A lo; X2(t): W pieces 2,3 + A hi   (W first inside X2: the vmcnt(6) count relies on it)
+    auto issue = [&](int t, int second) {
+        char* base = smem + (t & 1) * 65536;
+        const char* gw = uniform_ptr(baseW + (size_t)t * 128);       // keep the K advance on the scalar unit (defeats LSR's
+        const char* ga = uniform_ptr(baseA + (size_t)t * 128);       // per-lane 64-bit pointer induction variables)
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int kw = second * 2 + k;
+            __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[kw]), PP_LPTR(base + 32768 + (wave + 8 * kw) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int ka = second * 2 + k;
+            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + offA[ka]), PP_LPTR(base + (k * 128 + second * 64 + wave * 8) * 128), 16, 0, 0);
+        }
+    };
+
+    const int sx = (l31 >> 1) & 7;
+    const int a_off = (wm * 128 + l31) * 128 + ((hi ^ sx) << 4);             // k-step ks: a_off ^ (ks * 32)
+    const int w_off = 32768 + (wn * 64 + l31) * 128 + ((hi ^ sx) << 4);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    issue(0, 0);
+    issue(0, 1);
+    if (nkt > 1) {
+        issue(1, 0);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1 && !(dbg & 8)) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x4 af[2][4], wf[TN][4];
+    for (int t = 0; t < nkt; t++) {
+        const char* sl = smem + (t & 1) * 65536;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            // ======== load segment ========
+            if (!(dbg & 2) || t == 0) {
+                if (half == 0) {
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ks++) wf[j][ks] = *reinterpret_cast<const u32x4*>(sl + (w_off ^ (ks * 32)) + j * 4096);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 32)) + (half * 2 + i) * 4096);
+            }
+            if (dbg & 1) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            } else if (half == 0) {
+                if (t + 1 < nkt) {
+                    issue(t + 1, 1);
+                    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
+            } else {
+                if (t + 2 < nkt) {
+                    issue(t + 2, 0);
+                    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                } else if (t + 1 < nkt) {
+                    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
+            }
+            if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // ======== compute segment ========
+            __builtin_amdgcn_s_setprio(1);
+            if (!(dbg & 4))
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) mma_step<f16>(acc[half * 2 + i][j], wf[j][ks], af[i][ks]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            if (!(grp == 1 && half == 1 && t == nkt - 1) && !(dbg & 8)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    pp_epilogue<TM, RESID>(g, acc, smem, wave, lane, m0 + wm * 128, n0 + wn * 64);
+}
+
+template <bool RESID>
+static int launch_pp128(const GemmArgs& g, hipStream_t st) {
+    constexpr int smem = 2 * 65536;
+    static bool attr_set = false;
+    auto kern = gemm_pp128_kernel<RESID>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long nbm = (g.M + 255) / 256, nbn = g.N / 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(512), smem, st, g);
+    return (int)hipGetLastError();
+}
+
+template <int WM, int WN, int TM, bool RESID>
+static int launch_pp_cfg(const GemmArgs& g, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * 64;
+    constexpr int smem = 4 * (BM + BN) * 64;
+    static bool attr_set = false;
+    auto kern = gemm_pp_kernel<WM, WN, TM, RESID>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(512), smem, st, g);
+    return (int)hipGetLastError();
+}
+
+// Shapes / epilogues the ping-pong kernel takes (f16, LINEAR mode only).  bn256 = prefer the 256-wide tile.
+bool gemm_pp_eligible(const GemmArgs& g) {
+    if (g.relu_in || g.add) return false;
+    if (g.K < 64 || (g.K & 31) || (g.N & 127) || g.M < 256) return false;
+    if ((g.lda & 7) || (g.ldw & 7)) return false;
+    switch (g.epi) {
+    case EPI_STORE: return (g.ldc & 7) == 0 && (!g.uv.wu || g.bias);
+    case EPI_RESID: return g.bias && g.gamma && (g.ldc & 3) == 0;
+    case EPI_QKV: return g.v_rowmajor && g.D % 128 == 0 && g.Ntok >= 128 && g.N == 3 * g.D && g.bias;
+    case EPI_CONVT: return g.Cout % 64 == 0 && g.pixW >= 8 && !g.uv.wu;
+    default: return false;
+    }
+}
+
+int launch_gemm_pp(const GemmArgs& g0, hipStream_t st) {
+    GemmArgs g = g0;
+    g.dbg = moge_tune_get("PP_DBG", 0);
+    const bool wide = (g.N % 256) == 0 && !(g.epi == EPI_QKV && (g.D % 256) != 0);
+    if (wide && (g.K & 63) == 0 && moge_tune_get("PP_ROW128", 1))
+        return g.epi == EPI_RESID ? launch_pp128<true>(g, st) : launch_pp128<false>(g, st);
+    if (g.epi == EPI_RESID) return wide ? launch_pp_cfg<2, 4, 4, true>(g, st) : launch_pp_cfg<4, 2, 2, true>(g, st);
+    return wide ? launch_pp_cfg<2, 4, 4, false>(g, st) : launch_pp_cfg<4, 2, 2, false>(g, st);
+}

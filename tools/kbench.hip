@@ -1,0 +1,234 @@
+// Stand-alone kernel bench / checker for libmoge_hip.so (no Python, no torch: a fresh GPU box runs it in seconds).
+//   kbench gemm [filter]     time launch_gemm<f16> variants on the hot-path shapes and check sampled rows against a
+//                            naive fp32 device reference
+//   kbench attn              time / check the attention kernels
+// Variants are selected through moge_tune_set() (same switches as the MOGE_* environment variables).
+#include "../moge_amd/csrc/launchers.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <cmath>
+
+extern "C" void moge_tune_set(const char* key, int value);
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d: %s\n", #x, __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
+
+__device__ __forceinline__ unsigned hash_u32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__global__ void fill_f16(f16* p, size_t n, unsigned seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned h = hash_u32((unsigned)i * 2654435761U + seed);
+        p[i] = (f16)(((h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale);
+    }
+}
+__global__ void fill_f32(float* p, size_t n, unsigned seed, float scale, float offset) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned h = hash_u32((unsigned)i * 2654435761U + seed);
+        p[i] = ((h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale + offset;
+    }
+}
+
+// ref[r][n] = sum_k A[rows[r]][k] * W[n][k] + bias[n]   (fp32 accumulate)
+__global__ void ref_gemm(const f16* A, int lda, const f16* W, int ldw, const float* bias, const int* rows, int nrows, int N, int K, float* ref) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (n >= N || r >= nrows) return;
+    const f16* a = A + (size_t)rows[r] * lda;
+    const f16* w = W + (size_t)n * ldw;
+    double acc = 0.0;
+    for (int k = 0; k < K; k++) acc += (double)((float)a[k] * (float)w[k]);
+    ref[(size_t)r * N + n] = (float)acc + (bias ? bias[n] : 0.f);
+}
+
+struct CheckArgs {
+    GemmArgs g;
+    const int* rows; int nrows;
+    const float* ref;          // [nrows][N] acc + bias
+    const float* x0;           // RESID: residual before the call, full [M][ldc]
+    float* maxratio; int* nbad;
+};
+__device__ float atomicMaxF(float* addr, float v) {
+    int* ai = (int*)addr;
+    int old = *ai;
+    while (v > __int_as_float(old)) {
+        const int assumed = old;
+        old = atomicCAS(ai, assumed, __float_as_int(v));
+        if (old == assumed) break;
+    }
+    return __int_as_float(old);
+}
+__global__ void check_out(CheckArgs c) {
+    const GemmArgs& g = c.g;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (n >= g.N || r >= c.nrows) return;
+    const int m = c.rows[r];
+    float v = c.ref[(size_t)r * g.N + n];
+    float got, tol;
+    if (g.epi == EPI_RESID) {
+        const float e = c.x0[(size_t)m * g.ldc + n] + g.gamma[n] * v;
+        got = g.xres[(size_t)m * g.ldc + n];
+        tol = 2e-5f * fabsf(e) + 3e-4f;
+        v = e;
+    } else {
+        if (g.uv.wu) {
+            const int x = m % g.pixW, y = (m / g.pixW) % g.pixH;
+            v += g.uv.wu[n] * linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, g.pixW, x) + g.uv.wv[n] * linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, g.pixH, y);
+        }
+        size_t idx;
+        const f16* base = (const f16*)g.out;
+        if (g.epi == EPI_QKV) {
+            const int which = n / g.D, rem = n - which * g.D, hd = rem >> 6, d = rem & 63;
+            const int b = m / g.Ntok, tok = m - b * g.Ntok;
+            if (which == 0) v *= g.qscale;
+            base = (const f16*)(which == 0 ? g.q : which == 1 ? g.k : g.vT);
+            if (which == 2 && !g.v_rowmajor) idx = ((size_t)(b * g.nh + hd) * 64 + d) * g.Npad + tok;
+            else idx = ((size_t)(b * g.nh + hd) * g.Ntok + tok) * 64 + d;
+        } else if (g.epi == EPI_CONVT) {
+            const int qd = n / g.Cout, co = n - qd * g.Cout, dy = qd >> 1, dx = qd & 1;
+            const int x = m % g.pixW, t = m / g.pixW, y = t % g.pixH, b = t / g.pixH;
+            idx = (((size_t)b * 2 * g.pixH + 2 * y + dy) * (2 * g.pixW) + 2 * x + dx) * g.Cout + co;
+        } else {
+            idx = (size_t)m * g.ldc + n;
+        }
+        if (g.act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        else if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
+        got = (float)base[idx];
+        tol = fabsf(v) * (1.0f / 1024.0f) + 3e-5f;
+    }
+    const float ratio = fabsf(got - v) / tol;
+    if (!(ratio <= 1.0f)) atomicAdd(c.nbad, 1);
+    atomicMaxF(c.maxratio, ratio == ratio ? ratio : 1e30f);
+}
+
+struct Shape { const char* name; int M, N, K, epi, act; int D, nh, Ntok; int Cout, pixW, pixH; int uv; };
+
+static double time_launches(const GemmArgs& g, int iters, hipStream_t st) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; i++) { int rc = launch_gemm<f16>(g, AMODE_LINEAR, st); if (rc) { fprintf(stderr, "launch rc %d\n", rc); exit(3); } }
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; i++) launch_gemm<f16>(g, AMODE_LINEAR, st);
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    return ms / iters;
+}
+
+static int bench_gemm(const char* filter, int iters) {
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    const int B = 32, Ntok = 3601;
+    const Shape shapes[] = {
+        {"qkv", B * Ntok, 3072, 1024, EPI_QKV, ACT_NONE, 1024, 16, Ntok, 0, 0, 0, 0},
+        {"proj", B * Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
+        {"fc1", B * Ntok, 4096, 1024, EPI_STORE, ACT_GELU, 0, 0, 0, 0, 0, 0, 0},
+        {"fc2", B * Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
+        {"outproj", B * 3600, 1024, 4096, EPI_STORE, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
+        {"neck.in0(uv)", B * 3600, 1024, 1024, EPI_STORE, ACT_NONE, 0, 0, 0, 0, 60, 60, 1},
+        {"convT0", B * 3600, 1024, 1024, EPI_CONVT, ACT_NONE, 0, 0, 0, 256, 60, 60, 0},
+        {"convT1", B * 14400, 512, 256, EPI_CONVT, ACT_NONE, 0, 0, 0, 128, 120, 120, 0},
+        {"convT2", B * 57600, 256, 128, EPI_CONVT, ACT_NONE, 0, 0, 0, 64, 240, 240, 0},
+        {"vitb.qkv", 8 * Ntok, 2304, 768, EPI_QKV, ACT_NONE, 768, 12, Ntok, 0, 0, 0, 0},
+        {"vits.qkv", 8 * Ntok, 1152, 384, EPI_QKV, ACT_NONE, 384, 6, Ntok, 0, 0, 0, 0},
+        {"vits.fc2", 8 * Ntok, 384, 1536, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
+        {"tailM", 700, 1024, 1024, EPI_STORE, ACT_GELU, 0, 0, 0, 0, 0, 0, 0},
+    };
+    struct Variant { const char* name; int pp, glds, dbg, row128; };
+    std::vector<Variant> variants = {{"old-glds2", 0, 2, 0, 0}, {"pp64", 1, 2, 0, 0}, {"pp128", 1, 2, 0, 1}};
+    if (getenv("KB_ABLATE")) {
+        variants = {{"pp128", 1, 2, 0, 1}, {"pp128-nodma", 1, 2, 1, 1}, {"pp128-nolds", 1, 2, 2, 1}, {"pp128-nomfma", 1, 2, 4, 1},
+                    {"pp128-nobar", 1, 2, 8, 1}, {"pp128-mfmaonly", 1, 2, 11, 1}};
+    }
+    int fails = 0;
+    for (const Shape& s : shapes) {
+        if (filter && !strstr(s.name, filter)) continue;
+        const size_t M = s.M, N = s.N, K = s.K;
+        f16 *A, *W, *out, *out2 = nullptr, *out3 = nullptr;
+        float *bias, *gamma, *x = nullptr, *x0 = nullptr, *wu, *wv;
+        CK(hipMalloc(&A, M * K * 2)); CK(hipMalloc(&W, N * K * 2)); CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&gamma, N * 4));
+        CK(hipMalloc(&wu, N * 4)); CK(hipMalloc(&wv, N * 4));
+        size_t out_elems = M * N;
+        if (s.epi == EPI_CONVT) out_elems = M * N;       // 4*M pixels x Cout
+        CK(hipMalloc(&out, out_elems * 2 + 4096));
+        fill_f16<<<2048, 256, 0, st>>>(A, M * K, 1u, 1.0f);
+        fill_f16<<<2048, 256, 0, st>>>(W, N * K, 2u, 1.0f);
+        fill_f32<<<64, 256, 0, st>>>(bias, N, 3u, 1.0f, 0.f);
+        fill_f32<<<64, 256, 0, st>>>(gamma, N, 4u, 0.5f, 1.0f);
+        fill_f32<<<64, 256, 0, st>>>(wu, N, 5u, 1.0f, 0.f);
+        fill_f32<<<64, 256, 0, st>>>(wv, N, 6u, 1.0f, 0.f);
+        if (s.epi == EPI_RESID) {
+            CK(hipMalloc(&x, M * N * 4)); CK(hipMalloc(&x0, M * N * 4));
+            fill_f32<<<2048, 256, 0, st>>>(x0, M * N, 7u, 2.0f, 0.f);
+        }
+        GemmArgs g; memset(&g, 0, sizeof(g));
+        g.a = A; g.lda = (int)K; g.w = W; g.ldw = (int)K; g.M = (int)M; g.N = (int)N; g.K = (int)K;
+        g.epi = s.epi; g.act = s.act; g.bias = bias; g.out = out; g.ldc = (int)N;
+        if (s.epi == EPI_RESID) { g.xres = x; g.gamma = gamma; }
+        if (s.epi == EPI_QKV) {
+            const size_t per = M * s.D;
+            g.q = out; g.k = out + per; g.vT = out + 2 * per; g.v_rowmajor = 1;
+            g.nh = s.nh; g.D = s.D; g.Ntok = s.Ntok; g.Npad = (s.Ntok + 63) / 64 * 64; g.qscale = 0.125f * 1.4426950408889634f;
+        }
+        if (s.epi == EPI_CONVT) { g.Cout = s.Cout; g.pixW = s.pixW; g.pixH = s.pixH; }
+        if (s.uv) {
+            g.pixW = s.pixW; g.pixH = s.pixH;
+            g.uv.wu = wu; g.uv.wv = wv; g.uv.u0 = -0.7f; g.uv.u1 = 0.7f; g.uv.ustep = 1.4f / (s.pixW - 1); g.uv.v0 = -0.6f; g.uv.v1 = 0.6f; g.uv.vstep = 1.2f / (s.pixH - 1);
+        }
+        // sampled rows: first 300, a middle band straddling a batch boundary, the last 300
+        std::vector<int> rows;
+        for (int i = 0; i < 300 && i < (int)M; i++) rows.push_back(i);
+        for (int i = 0; i < 300; i++) { int m = 3601 * 7 - 150 + i; if (m >= 300 && m < (int)M - 300) rows.push_back(m); }
+        for (int i = 0; i < 300; i++) { int m = (int)M - 300 + i; if (m >= 300) rows.push_back(m); }
+        int* drows; float* ref; float* dmax; int* dbad;
+        CK(hipMalloc(&drows, rows.size() * 4)); CK(hipMalloc(&ref, rows.size() * N * 4)); CK(hipMalloc(&dmax, 4)); CK(hipMalloc(&dbad, 4));
+        CK(hipMemcpyAsync(drows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+        ref_gemm<<<dim3((unsigned)((N + 255) / 256), (unsigned)rows.size()), 256, 0, st>>>(A, (int)K, W, (int)K, bias, drows, (int)rows.size(), (int)N, (int)K, ref);
+        CK(hipStreamSynchronize(st));
+        for (const Variant& v : variants) {
+            moge_tune_set("GEMM_PP", v.pp);
+            moge_tune_set("GLDS_VARIANT", v.glds);
+            moge_tune_set("PP_DBG", v.dbg);
+            moge_tune_set("PP_ROW128", v.row128);
+            // correctness: one launch on fresh buffers
+            CK(hipMemsetAsync(out, 0, out_elems * 2, st));
+            if (x) CK(hipMemcpyAsync(x, x0, M * N * 4, hipMemcpyDeviceToDevice, st));
+            int rc = launch_gemm<f16>(g, AMODE_LINEAR, st);
+            if (rc) { printf("%-14s %-10s launch failed rc=%d\n", s.name, v.name, rc); fails++; continue; }
+            CK(hipMemsetAsync(dmax, 0, 4, st)); CK(hipMemsetAsync(dbad, 0, 4, st));
+            CheckArgs c; c.g = g; c.rows = drows; c.nrows = (int)rows.size(); c.ref = ref; c.x0 = x0; c.maxratio = dmax; c.nbad = dbad;
+            check_out<<<dim3((unsigned)((N + 255) / 256), (unsigned)rows.size()), 256, 0, st>>>(c);
+            float hmax; int hbad;
+            CK(hipMemcpyAsync(&hmax, dmax, 4, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hbad, dbad, 4, hipMemcpyDeviceToHost, st));
+            CK(hipStreamSynchronize(st));
+            const double ms = time_launches(g, iters, st);
+            const double tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12;
+            printf("%-14s M=%-7zu N=%-5zu K=%-5zu %-10s %8.3f ms %8.1f TF/s   check: max err/tol %.3f, bad %d / %zu %s\n", s.name, M, N, K, v.name, ms, tf,
+                   hmax, hbad, rows.size() * N, hbad ? "FAIL" : "ok");
+            fflush(stdout);
+            if (hbad && !v.dbg) fails++;
+        }
+        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(gamma)); CK(hipFree(out)); CK(hipFree(wu)); CK(hipFree(wv));
+        if (x) { CK(hipFree(x)); CK(hipFree(x0)); }
+        CK(hipFree(drows)); CK(hipFree(ref)); CK(hipFree(dmax)); CK(hipFree(dbad));
+        (void)out2; (void)out3;
+    }
+    return fails;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: kbench gemm|attn [filter] [iters]\n"); return 1; }
+    CK(hipSetDevice(0));
+    const char* filter = argc > 2 && strcmp(argv[2], "-") ? argv[2] : nullptr;
+    const int iters = argc > 3 ? atoi(argv[3]) : 10;
+    if (!strcmp(argv[1], "gemm")) return bench_gemm(filter, iters) ? 4 : 0;
+    fprintf(stderr, "unknown bench %s\n", argv[1]);
+    return 1;
+}
