@@ -1,0 +1,262 @@
+// Flash attention, fp16 throughput path (attention.py:70-81: softmax(q k^T / 8) v, head_dim 64, no mask) for gfx950.
+// The fp32 parity mode stays on attention.hip.
+//
+// Inputs from the QKV GEMM epilogue (EPI_QKV, v_rowmajor): q, k, v as (B, nh, N, 64) fp16, q pre-multiplied by
+// log2(e)/8.  Output (B, N, nh*64) fp16.
+//
+// What differs from attention.hip (measured there: 52 % of wave cycles issuing VALU, MFMA pipe 30 % busy):
+//   * The softmax works against a DEFERRED running max m: the accumulator of the S^T = K Q^T MFMA chain is initialised
+//     with -m (a 16-register splat that only changes when m does), so the MFMA result is already s - m and the
+//     per-score VALU work is ONE v_exp_f32, ONE v_add (row sum) and half a convert: no max tree, no subtract, no
+//     accumulator zeroing, no O rescale.  m is raised (exactly, with the usual alpha rescale of O and l) only on the
+//     first tile and when some lane's tile sum reaches 2^14, i.e. before any P could overflow fp16; P <= 2^14 relative to
+//     a stale m is as accurate in fp16 as P <= 1 (same 11-bit significand), O and l are fp32.
+//   * K and V tiles arrive by LDS-DMA (global_load_lds_dwordx4) into a 3-stage ring: one raw s_barrier per 64-key tile,
+//     counted vmcnt, the next two tiles in flight during the MFMAs.
+//   * V stays row-major (key, d): the PV MFMA's A-operand (V^T rows) is read with ds_read_b64_tr_b16 (hardware
+//     transpose), so the QKV epilogue writes V like K in full 128-byte rows instead of 2-byte transposed scatters.
+// Both products are issued "swapped" (S^T = K Q^T, O^T = V^T P^T) so the query is the lane index and the softmax state is
+// per lane; K rows enter the first MFMA in a bit-2/3-swapped order so that its accumulator registers are directly the
+// second MFMA's B-operand (see attention.hip).
+#include "common.h"
+
+#define AP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define AP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 tr_pair(const char* p0, const char* p1) {
+    // two transposed 4-key reads -> one 8-key (16-byte) MFMA operand
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(u32x4, v);
+}
+
+__device__ __forceinline__ u32x4 pack8(const f32x16& p, int s) {
+    f16x8 h;
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = (f16)p[8 * s + i];
+    return __builtin_bit_cast(u32x4, h);
+}
+
+constexpr int AP_STAGE = 16384;          // K tile 8 KiB + V tile 8 KiB
+constexpr float AP_PSUM_LIMIT = 16384.f;
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_pp_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
+                                                          f16* __restrict__ out, int Ntok, int nh) {
+    constexpr int NPW = 16 / NW;                // DMA pieces (8 rows x 128 B) per wave per tile: K pieces then V pieces
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * AP_STAGE
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y;
+    const int b = bh / nh, head = bh - b * nh;
+    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+    const int qrow = q0 + l31;
+    const int qld = qrow < Ntok ? qrow : Ntok - 1;
+
+    // ---- Q fragments (B-operand of S^T = K Q^T): lane = query, 8 d per half and k-step --------------------------------
+    const f16* qp = q + ((size_t)bh * Ntok + qld) * 64;
+    u32x4 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const u32x4*>(qp + (2 * s + hi) * 8);
+
+    // ---- DMA sources: piece p of a tile = rows 8p..8p+7 of K (p < 8) or V (p >= 8) ------------------------------------
+    const char* kbase = reinterpret_cast<const char*>(k + (size_t)bh * Ntok * 64);
+    const char* vbase = reinterpret_cast<const char*>(v + (size_t)bh * Ntok * 64);
+    const int prow = lane >> 3, pch = lane & 7;
+    int drow[NPW];               // tile row this lane fetches in piece i
+    unsigned dcol[NPW];          // byte offset of the (un-swizzled) source chunk inside the row
+    bool dIsV[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; i++) {
+        const int p = wave + NW * i;                     // 0..15
+        dIsV[i] = p >= 8;
+        const int row = (p & 7) * 8 + prow;
+        drow[i] = row;
+        // K: chunk ^ ((row >> 1) & 7) (conflict-free ds_read_b128);  V: chunk ^ (((key >> 1) & 1) << 2) (conflict-free tr reads)
+        const int lch = dIsV[i] ? (pch ^ (((row >> 1) & 1) << 2)) : (pch ^ ((row >> 1) & 7));
+        dcol[i] = (unsigned)lch * 16;
+    }
+    auto issue = [&](int t) {
+        char* st = smem + (t % 3) * AP_STAGE;
+#pragma unroll
+        for (int i = 0; i < NPW; i++) {
+            const int p = wave + NW * i;
+            int key = t * 64 + drow[i];
+            key = key < Ntok ? key : Ntok - 1;           // clamped rows are masked (K) / multiplied by P = 0 (V)
+            const char* src = (dIsV[i] ? vbase : kbase) + (size_t)key * 128 + dcol[i];
+            __builtin_amdgcn_global_load_lds(AP_GPTR(src), AP_LPTR(st + p * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- LDS read addresses (bytes inside a stage) -----------------------------------------------------------------------
+    // K fragment (h, s): row = h*32 + perm(l31), chunk 2s+hi;  perm swaps bits 2/3 (accumulator regs == next B-operand)
+    const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    int kaddr[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) kaddr[s] = krow * 128 + (((2 * s + hi) ^ ((krow >> 1) & 7)) << 4);
+    // V^T fragment (dt, h, s) = two transposed reads of 4 keys x 16 d per 16-lane group:
+    //   supplier lane i (of its group): key (i>>2), d-offset (i&3)*4 inside the group's 16 d's;  group g = lane>>4: d-block (g&1)*16, keys +8*(g>>1)
+    const int li = lane & 15;
+    const int vsw = ((li >> 3) & 1) << 2;                                    // ((key >> 1) & 1) << 2 with key = (li >> 2) + multiples of 4
+    const int vrow = 8 * hi + (li >> 2);
+    const int vch = (((lane >> 4) & 1) << 1) | ((li & 3) >> 1);              // 16-byte chunk inside the 32-d half-row (dt selects the half)
+    int vaddr[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++) vaddr[dt] = 8192 + vrow * 128 + ((((dt << 2) | vch) ^ vsw) << 4) + (li & 1) * 8;
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[i][r] = 0.f;
+    f32x16 negm;
+#pragma unroll
+    for (int r = 0; r < 16; r++) negm[r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int ntiles = (Ntok + 63) >> 6;
+    issue(0);
+    if (ntiles > 1) issue(1);
+
+    int stage = 0;                                // t % 3
+    for (int t = 0; t < ntiles; t++) {
+        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // tile t landed for every wave; every wave is done reading tile t-1
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntiles) issue(t + 2);
+        const int so = stage * AP_STAGE;
+        stage = stage == 2 ? 0 : stage + 1;
+        const char* ka[4];
+        const char* va[2];
+#pragma unroll
+        for (int s = 0; s < 4; s++) ka[s] = smem + (kaddr[s] + so);
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) va[dt] = smem + (vaddr[dt] + so);
+        const bool last = t == ntiles - 1;
+        const bool exact = (t == 0) | last;       // tiles that always take the exact path (first: m unknown; last: key mask)
+
+        f32x16 sc[2];
+        float psum = 0.f;
+        if (!exact) {
+            // ---- fast path: S^T - m = K Q^T + (-m);  P = exp2(.) ------------------------------------------------------
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                sc[h] = negm;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const u32x4 kf = *reinterpret_cast<const u32x4*>(ka[s] + h * 4096);
+                    mma_step<f16>(sc[h], kf, qf[s]);
+                }
+            }
+            float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                sc[0][r] = __builtin_amdgcn_exp2f(sc[0][r]);
+                sc[1][r] = __builtin_amdgcn_exp2f(sc[1][r]);
+                ps0 += sc[0][r];
+                ps1 += sc[1][r];
+            }
+            psum = ps0 + ps1;
+        }
+        if (exact || __any(!(psum < AP_PSUM_LIMIT))) {
+            // ---- exact path: raise m to the true running max, rescale O and l (first / last tile; rare otherwise) ------
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) sc[h][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const u32x4 kf = *reinterpret_cast<const u32x4*>(ka[s] + h * 4096);
+                    mma_step<f16>(sc[h], kf, qf[s]);
+                }
+            }
+            if (last) {
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int i = acc_row(r, hi);
+                        const int key = t * 64 + h * 32 + ((i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1));
+                        if (key >= Ntok) sc[h][r] = -1e30f;
+                    }
+            }
+            float mx = sc[0][0];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) mx = fmaxf(mx, sc[h][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[i][r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; r++) negm[r] = -m_new;
+            psum = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    sc[h][r] = __builtin_amdgcn_exp2f(sc[h][r] - m_new);
+                    psum += sc[h][r];
+                }
+        }
+        l_run += psum;
+        // ---- O^T += V^T P^T ---------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const u32x4 pf = pack8(sc[h], s);
+                const int koff = (h * 32 + 16 * s) * 128;
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++) {
+                    const u32x4 vf = tr_pair(va[dt] + koff, va[dt] + koff + 4 * 128);
+                    mma_step<f16>(o[dt], vf, pf);
+                }
+            }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    if (qrow < Ntok) {
+        f16* op = out + ((size_t)b * Ntok + qrow) * ((size_t)nh * 64) + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++)
+                store4(op + dt * 32 + 8 * g4 + 4 * hi, o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv, o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+    }
+}
+
+template <int NW>
+static int launch_attn_pp_cfg(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
+    constexpr int smem = 3 * AP_STAGE;
+    static bool attr_set = false;
+    auto kern = attn_pp_kernel<NW>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((Ntok + NW * 32 - 1) / (NW * 32), B * nh);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
+    return (int)hipGetLastError();
+}
+
+// q, k, v: (B, nh, Ntok, 64) fp16 (q pre-scaled by log2(e)/8); out: (B, Ntok, nh*64) fp16
+int launch_attention_pp(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
+    if (Ntok < 1) return -1;
+    if (moge_tune_get("ATTN_NW", 4) == 8) return launch_attn_pp_cfg<8>(q, k, v, out, B, nh, Ntok, st);
+    return launch_attn_pp_cfg<4>(q, k, v, out, B, nh, Ntok, st);
+}

@@ -4,6 +4,9 @@
 
 template <typename T> int launch_attention(const void* q, const void* k, const void* vT, void* out, int B, int nh, int Ntok, int Npad, hipStream_t st);
 
+// fp16 throughput path (attention_pp.hip): q, k, v all (B, nh, Ntok, 64)
+int launch_attention_pp(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st);
+
 template <typename TIn, typename TOut>
 int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out, const float* mean,
                       const float* std_, hipStream_t st);

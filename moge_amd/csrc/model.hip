@@ -8,6 +8,7 @@
 #include "../../include/moge_hip.h"
 
 #include <cmath>
+#include <type_traits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -522,7 +523,9 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
         g.epi = EPI_PATCH; g.bias = M(h, bb + "patch_embed.proj.bias"); g.xres = x; g.pos = pos; g.Np = Np; g.Ntok = Ntok;
         CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st, KPATCH));
     }
-    HIPCHK(hipMemsetAsync(vT, 0, (size_t)B * D * Npad * sizeof(T), st));      // zero the key padding of V^T
+    // fp16 throughput path: V row-major + attention_pp (LDS-DMA, transposed LDS reads); fp32 parity path: V^T + attention.hip
+    const bool attn_pp = std::is_same<T, f16>::value && moge_tune_get("ATTN_PP", 1) != 0;
+    if (!attn_pp) HIPCHK(hipMemsetAsync(vT, 0, (size_t)B * D * Npad * sizeof(T), st));      // zero the key padding of V^T
 
     // ---- ViT blocks (block.py:110-112) -----------------------------------------------------------------------------
     int tap_k = 0;
@@ -537,13 +540,14 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
             g.a = xn; g.lda = D; g.w = P<T>(h, S("blk%d.qkv", i)); g.ldw = D;
             g.M = (int)BN; g.N = 3 * D; g.K = D;
             g.epi = EPI_QKV; g.bias = M(h, p + "attn.qkv.bias"); g.q = qb; g.k = kb; g.vT = vT;
-            g.nh = nh; g.Npad = Npad; g.D = D; g.Ntok = Ntok;
+            g.nh = nh; g.Npad = Npad; g.D = D; g.Ntok = Ntok; g.v_rowmajor = attn_pp ? 1 : 0;
             g.qscale = 0.125f * 1.4426950408889634f;       // 1/sqrt(64) * log2(e): attention works in exp2
             CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
         }
         {
             ProfScope ps(h, st, MOGE_KC_ATTN, 4.0 * B * nh * (double)Ntok * Ntok * 64, (double)BN * D * 4 * sizeof(T));
-            LCHK(launch_attention<T>(qb, kb, vT, attn, B, nh, Ntok, Npad, st));
+            if (attn_pp) LCHK(launch_attention_pp(qb, kb, vT, attn, B, nh, Ntok, st));
+            else LCHK(launch_attention<T>(qb, kb, vT, attn, B, nh, Ntok, Npad, st));
         }
         {
             GemmArgs g = gemm_args();

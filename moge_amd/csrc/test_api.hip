@@ -3,6 +3,7 @@
 #include "launchers.h"
 #include "../../include/moge_hip.h"
 #include <vector>
+#include <type_traits>
 #include <cstring>
 #include <cstdio>
 
@@ -60,6 +61,15 @@ static int t_attention(const float* q, const float* k, const float* v, float* o,
     TL(to_t<T>(k, kb.p, (long)n, st));
     // v (B*nh, N, 64) -> vT (B*nh, 64, Npad)
     TL(launch_repack<T>(v, vb.p, B * nh, 64, 1, N, (long)N * 64, 1, 0, 64, (long)64 * Npad, Npad, 0, st));
+    if (std::is_same<T, f16>::value && moge_tune_get("ATTN_PP", 1)) {
+        DevBuf vr;                                   // row-major V for the fp16 throughput kernel
+        TCHK(vr.alloc(n * sizeof(T)));
+        TL(to_t<T>(v, vr.p, (long)n, st));
+        TL(launch_attention_pp(qb.p, kb.p, vr.p, ob.p, B, nh, N, st));
+        TL(from_t<T>(ob.p, o, (long)n, st));
+        TCHK(hipStreamSynchronize(st));
+        return 0;
+    }
     TL(launch_attention<T>(qb.p, kb.p, vb.p, ob.p, B, nh, N, Npad, st));
     TL(from_t<T>(ob.p, o, (long)n, st));
     TCHK(hipStreamSynchronize(st));
