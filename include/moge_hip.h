@@ -159,6 +159,10 @@ int moge_profile_read(moge_handle* h, moge_profile* out, int reset);   /* synchr
  * Layout is the library's own (token-major / NHWC); *numel receives the element count. */
 int moge_debug_tap(moge_handle* h, const char* name, float* dst, int64_t dst_capacity, int64_t* numel, void* stream);
 
+/* Runtime tuning / A-B switches (same keys as the MOGE_<KEY> environment variables; tests and tools only):
+ *   GEMM_PP, PP_ROW128, ATTN_PP, ATTN_NW, BATCH_SPLIT, GLDS_VARIANT, ...   The library's defaults are the tuned ones. */
+void moge_tune_set(const char* key, int value);
+
 /* ---- per-kernel test entry points (stage-level parity; tests/ only) -------------------------------- */
 /* C[M,N] = A[M,K] * W[N,K]^T + bias, fp32 in/out on device; computed in `precision`. act: 0 none 1 relu 2 gelu */
 int moge_test_gemm(int precision, const float* A, const float* W, const float* bias, float* C, int M, int N, int K,

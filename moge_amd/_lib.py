@@ -69,6 +69,7 @@ def _load() -> C.CDLL:
         "moge_profile_enable": (C.c_int, [vp, i32]),
         "moge_profile_read": (C.c_int, [vp, C.POINTER(Profile), i32]),
         "moge_debug_tap": (C.c_int, [vp, C.c_char_p, vp, i64, C.POINTER(i64), vp]),
+        "moge_tune_set": (None, [C.c_char_p, i32]),
         "moge_test_gemm": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, vp]),
         "moge_test_layernorm": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, vp]),
         "moge_test_attention": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, vp]),
@@ -90,7 +91,7 @@ def _load() -> C.CDLL:
 lib = _load()
 EXPORTS = ["moge_abi_version", "moge_last_error", "moge_create", "moge_destroy", "moge_load_weights", "moge_alloc_master",
            "moge_master_blob", "moge_master_ready", "moge_set_precision", "moge_workspace_bytes", "moge_forward", "moge_infer",
-           "moge_postprocess", "moge_sync", "moge_profile_enable", "moge_profile_read", "moge_debug_tap", "moge_test_gemm",
+           "moge_postprocess", "moge_sync", "moge_profile_enable", "moge_profile_read", "moge_debug_tap", "moge_tune_set", "moge_test_gemm",
            "moge_test_layernorm", "moge_test_attention", "moge_test_conv3x3", "moge_test_convt2x2", "moge_test_preprocess",
            "moge_test_posembed", "moge_test_recover"]
 
@@ -102,6 +103,11 @@ def check(code: int) -> None:
     if code == ERR_NONFINITE:
         raise ValueError(msg or "Residuals are not finite in the initial point.")      # what scipy raises in the reference
     raise MogeError(f"libmoge_hip error {code}: {msg}")
+
+
+def tune(key: str, value: int) -> None:
+    """A/B switch of the library (tests / tools): same keys as the MOGE_<KEY> environment variables."""
+    lib.moge_tune_set(key.encode(), int(value))
 
 
 def stream_ptr(device=None) -> int:

@@ -177,49 +177,72 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                         T* __restrict__ out, float* __restrict__ cls_out, long rowsN, int D, int ldo,
                                                         int coloff, int tap_mode, int Ntok) {
+    // One wave per row, LN_RPW consecutive rows per wave: a lane owns columns i*256 + 4*lane .. +3 (16-byte loads: a wave
+    // instruction moves 1 KiB of the fp32 row, 8-byte stores of the storage type), weight / bias stay in registers.
+    constexpr int LN_RPW = 4;
     const int lane = threadIdx.x & 63;
-    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
-    if (row >= rowsN) return;
-    const int nit = D >> 7;                       // 128 columns per pass (float2 per lane)
-    const float* xr = x + row * (long)D;
-    f32x2 v[8];
-    float s = 0.f;
+    const long row0 = (blockIdx.x * 4L + (threadIdx.x >> 6)) * LN_RPW;
+    if (row0 >= rowsN) return;
+    const int nit = (D + 255) >> 8;
+    f32x4 ww[4], bb[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-        if (i < nit) { v[i] = *reinterpret_cast<const f32x2*>(xr + i * 128 + lane * 2); s += v[i][0] + v[i][1]; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        if (i < nit) { const float a = v[i][0] - mean, c = v[i][1] - mean; q += a * a + c * c; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rstd = rsqrtf(q / (float)D + 1e-6f);
-    T* op = nullptr; float* cp = nullptr;
-    if (tap_mode) {
-        const long b = row / Ntok; const int t = (int)(row - b * Ntok);
-        if (t == 0) { if (!cls_out) return; cp = cls_out + b * D; }
-        else op = out + (b * (Ntok - 1) + t - 1) * (long)ldo + coloff;
-    } else {
-        op = out + row * (long)ldo + coloff;
+    for (int i = 0; i < 4; i++) {
+        const int col = i * 256 + lane * 4;
+        if (i < nit && col < D) { ww[i] = *reinterpret_cast<const f32x4*>(w + col); bb[i] = *reinterpret_cast<const f32x4*>(bias + col); }
     }
+    const float invD = 1.f / (float)D;
+    for (int r = 0; r < LN_RPW; r++) {
+        const long row = row0 + r;
+        if (row >= rowsN) break;
+        const float* xr = x + row * (long)D;
+        f32x4 v[4];
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-        if (i < nit) {
-            const int col = i * 128 + lane * 2;
-            const f32x2 ww = *reinterpret_cast<const f32x2*>(w + col), bb = *reinterpret_cast<const f32x2*>(bias + col);
-            const float y0 = (v[i][0] - mean) * rstd * ww[0] + bb[0], y1 = (v[i][1] - mean) * rstd * ww[1] + bb[1];
-            if (cp) { cp[col] = y0; cp[col + 1] = y1; }
-            else { op[col] = (T)y0; op[col + 1] = (T)y1; }
+        for (int i = 0; i < 4; i++) {
+            const int col = i * 256 + lane * 4;
+            if (i < nit && col < D) { v[i] = *reinterpret_cast<const f32x4*>(xr + col); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int col = i * 256 + lane * 4;
+            if (i < nit && col < D) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const float a = v[i][e] - mean; q += a * a; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q * invD + 1e-6f);
+        T* op = nullptr; float* cp = nullptr;
+        if (tap_mode) {
+            const long b = row / Ntok; const int t = (int)(row - b * Ntok);
+            if (t == 0) { if (!cls_out) continue; cp = cls_out + b * D; }
+            else op = out + (b * (Ntok - 1) + t - 1) * (long)ldo + coloff;
+        } else {
+            op = out + row * (long)ldo + coloff;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int col = i * 256 + lane * 4;
+            if (i < nit && col < D) {
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) y[e] = (v[i][e] - mean) * rstd * ww[i][e] + bb[i][e];
+                if (cp) *reinterpret_cast<f32x4*>(cp + col) = f32x4{y[0], y[1], y[2], y[3]};
+                else store4(op + col, y[0], y[1], y[2], y[3]);
+            }
+        }
+    }
 }
 template <typename T>
 int launch_layernorm(const float* x, const float* w, const float* b, void* out, float* cls_out, long rowsN, int D, int ldo, int coloff,
                      int tap_mode, int Ntok, hipStream_t st) {
-    if (D % 128 != 0 || D > 1024) return -1;
-    hipLaunchKernelGGL(layernorm_kernel<T>, dim3((unsigned)((rowsN + 3) / 4)), dim3(256), 0, st, x, w, b, (T*)out, cls_out, rowsN, D, ldo, coloff,
+    if (D % 4 != 0 || D > 1024 || (ldo & 3) || (coloff & 3)) return -1;
+    hipLaunchKernelGGL(layernorm_kernel<T>, dim3((unsigned)((rowsN + 15) / 16)), dim3(256), 0, st, x, w, b, (T*)out, cls_out, rowsN, D, ldo, coloff,
                        tap_mode, Ntok);
     return (int)hipGetLastError();
 }

@@ -68,6 +68,10 @@ struct moge_handle {
     struct PosEntry { int rows, cols; float* ptr; };
     std::vector<PosEntry> pos_cache;
     int* d_status = nullptr;
+    // batch-split execution: two internal streams run the two halves of a batch concurrently (tails of one half's kernels
+    // and its HBM-bound kernels overlap the other half's MFMA kernels); joined on the caller's stream before post-processing
+    hipStream_t split_st[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     float img_mean[3] = {0.485f, 0.456f, 0.406f}, img_std[3] = {0.229f, 0.224f, 0.225f};   // refreshed from the checkpoint buffers
     // profiler
     bool prof_on = false;
@@ -314,8 +318,9 @@ static int pack_weights(moge_handle* h, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------------------
 struct Plan {
     size_t total = 0;
+    size_t base = 0;          // byte offset of this plan inside the workspace arena (batch-split mode places two plans side by side)
     size_t patches, x, xn, q, k, vT, attn, hidden, tapcat, cls, mlp1, mlp2, metric, feat, neck[MOGE_LEVELS], scratch[3];
-    size_t maskprob, focal, shift, intr, pts_tmp, nrm_tmp;
+    size_t maskprob, focal, shift, intr, pts_tmp, nrm_tmp, post_end;
     int B, H, W, rows, cols, Np, Ntok, Npad;
     size_t scratch_elems;
 };
@@ -331,6 +336,16 @@ static Plan make_plan(const moge_config& c, int prec, int B, int H, int W, int r
     p.B = B; p.H = H; p.W = W; p.rows = rows; p.cols = cols;
     p.Np = rows * cols; p.Ntok = p.Np + 1; p.Npad = (p.Ntok + 63) / 64 * 64;
     const size_t BN = (size_t)B * p.Ntok, BP = (size_t)B * p.Np;
+    // caller-visible post-processing buffers first (batch-split mode keeps these from the full-batch plan)
+    const size_t px = (size_t)B * H * W;
+    p.maskprob = take(p, px * 4);
+    p.pts_tmp = take(p, px * 12);
+    p.nrm_tmp = take(p, px * 12);
+    p.focal = take(p, (size_t)B * 4);
+    p.shift = take(p, (size_t)B * 4);
+    p.intr = take(p, (size_t)B * 36);
+    p.metric = take(p, (size_t)B * 4);
+    p.post_end = p.total;
     p.patches = take(p, BP * KPATCH_PAD * s);
     p.x = take(p, BN * D * 4);
     p.xn = take(p, BN * D * s);
@@ -343,7 +358,6 @@ static Plan make_plan(const moge_config& c, int prec, int B, int H, int W, int r
     p.cls = take(p, (size_t)B * D * 4);
     p.mlp1 = take(p, (size_t)B * (c.scale_hidden > 0 ? c.scale_hidden : 1) * 4);
     p.mlp2 = take(p, (size_t)B * (c.scale_hidden > 0 ? c.scale_hidden : 1) * 4);
-    p.metric = take(p, (size_t)B * 4);
     p.feat = take(p, BP * c.dims[0] * s);
     size_t mx = 0;
     for (int l = 0; l < MOGE_LEVELS; l++) {
@@ -353,15 +367,9 @@ static Plan make_plan(const moge_config& c, int prec, int B, int H, int W, int r
     }
     p.scratch_elems = mx;
     for (int i = 0; i < 3; i++) p.scratch[i] = take(p, mx * s);
-    const size_t px = (size_t)B * H * W;
-    p.maskprob = take(p, px * 4);
-    p.pts_tmp = take(p, px * 12);
-    p.nrm_tmp = take(p, px * 12);
-    p.focal = take(p, (size_t)B * 4);
-    p.shift = take(p, (size_t)B * 4);
-    p.intr = take(p, (size_t)B * 36);
     return p;
 }
+static size_t forward_ws_bytes(moge_handle* h, const Plan& pl);
 static int ensure_ws(moge_handle* h, size_t bytes) {
     if (bytes <= h->ws_bytes) return 0;
     if (h->ws) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
@@ -490,7 +498,7 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     const int D = c.embed_dim, nh = c.num_heads, L = c.depth, c0 = c.dims[0];
     const int B = pl.B, rows = pl.rows, cols = pl.cols, Np = pl.Np, Ntok = pl.Ntok, Npad = pl.Npad;
     const double aspect = (double)pl.W / (double)pl.H;
-    char* ws = h->ws;
+    char* ws = h->ws + pl.base;
     T* patches = (T*)(ws + pl.patches);
     float* x = (float*)(ws + pl.x);
     T* xn = (T*)(ws + pl.xn);
@@ -706,6 +714,8 @@ void moge_destroy(moge_handle* h) {
     if (h->ws) hipFree(h->ws);
     for (auto& e : h->pos_cache) hipFree(e.ptr);
     if (h->d_status) hipFree(h->d_status);
+    for (int i = 0; i < 2; i++) { if (h->split_st[i]) hipStreamDestroy(h->split_st[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
     for (auto& r : h->prof_pending) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (auto e : h->ev_pool) hipEventDestroy(e);
     delete h;
@@ -772,7 +782,7 @@ int moge_set_precision(moge_handle* h, int precision, void* stream) {
 
 int moge_workspace_bytes(moge_handle* h, int B, int H, int W, int token_rows, int token_cols, size_t* bytes) {
     if (!h || !bytes) return fail(MOGE_ERR_INVALID, "null argument");
-    *bytes = make_plan(h->cfg, h->prec, B, H, W, token_rows, token_cols).total;
+    *bytes = forward_ws_bytes(h, make_plan(h->cfg, h->prec, B, H, W, token_rows, token_cols));
     return 0;
 }
 
@@ -785,11 +795,64 @@ static int check_call(moge_handle* h, const void* image, int B, int H, int W, in
     return 0;
 }
 
+static bool use_split(moge_handle* h, int B) { return B >= 8 && !h->prof_on && moge_tune_get("BATCH_SPLIT", 1) != 0; }
+// workspace bytes a forward over plan pl needs (callers size the arena BEFORE taking pointers into it)
+static size_t forward_ws_bytes(moge_handle* h, const Plan& pl) {
+    if (!use_split(h, pl.B)) return pl.total;
+    size_t off = pl.post_end;
+    off += make_plan(h->cfg, h->prec, pl.B / 2, pl.H, pl.W, pl.rows, pl.cols).total;
+    off += make_plan(h->cfg, h->prec, pl.B - pl.B / 2, pl.H, pl.W, pl.rows, pl.cols).total;
+    return off > pl.total ? off : pl.total;
+}
+
 static int forward_dispatch(moge_handle* h, const void* image, int img_dtype, const Plan& pl, float* pts, float* nrm, float* mp, float* metric, hipStream_t st) {
     if (!h->pk_ready[h->prec]) CHK(moge_set_precision(h, h->prec, st));
-    CHK(ensure_ws(h, pl.total));
-    if (h->prec == MOGE_FP16) return forward_impl<f16>(h, image, img_dtype, pl, pts, nrm, mp, metric, st);
-    return forward_impl<float>(h, image, img_dtype, pl, pts, nrm, mp, metric, st);
+    const int B = pl.B;
+    const bool split = use_split(h, B);
+    if (!split) {
+        CHK(ensure_ws(h, pl.total));
+        if (h->prec == MOGE_FP16) return forward_impl<f16>(h, image, img_dtype, pl, pts, nrm, mp, metric, st);
+        return forward_impl<float>(h, image, img_dtype, pl, pts, nrm, mp, metric, st);
+    }
+    // ---- two half batches on two internal streams ----------------------------------------------------------------------
+    if (!h->split_st[0]) {
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(hipStreamCreateWithFlags(&h->split_st[i], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        }
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    }
+    const int Bs[2] = {B / 2, B - B / 2};
+    Plan sub[2];
+    size_t off = pl.post_end;                      // keep the caller-visible post buffers (mask prob, focal, ...) of the full plan
+    for (int i = 0; i < 2; i++) {
+        sub[i] = make_plan(h->cfg, h->prec, Bs[i], pl.H, pl.W, pl.rows, pl.cols);
+        sub[i].base = off;
+        off += sub[i].total;
+    }
+    CHK(ensure_ws(h, off));
+    const float* pos;
+    CHK(get_pos(h, pl.rows, pl.cols, st, &pos));   // fill the position-embedding cache before forking
+    HIPCHK(hipEventRecord(h->ev_fork, st));
+    const size_t px = (size_t)pl.H * pl.W;
+    const size_t img_elem = img_dtype ? 2 : 4;
+    for (int i = 0; i < 2; i++) {
+        const size_t b0 = i == 0 ? 0 : (size_t)Bs[0];
+        HIPCHK(hipStreamWaitEvent(h->split_st[i], h->ev_fork, 0));
+        const void* img_i = (const char*)image + b0 * 3 * px * img_elem;
+        float* pts_i = pts ? pts + b0 * px * 3 : nullptr;
+        float* nrm_i = nrm ? nrm + b0 * px * 3 : nullptr;
+        float* mp_i = mp ? mp + b0 * px : nullptr;
+        float* met_i = metric ? metric + b0 : nullptr;
+        int rc;
+        if (h->prec == MOGE_FP16) rc = forward_impl<f16>(h, img_i, img_dtype, sub[i], pts_i, nrm_i, mp_i, met_i, h->split_st[i]);
+        else rc = forward_impl<float>(h, img_i, img_dtype, sub[i], pts_i, nrm_i, mp_i, met_i, h->split_st[i]);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(h->ev_join[i], h->split_st[i]));
+    }
+    for (int i = 0; i < 2; i++) HIPCHK(hipStreamWaitEvent(st, h->ev_join[i], 0));
+    h->last.valid = false;                          // debug taps address one contiguous batch: not available in split mode
+    return 0;
 }
 
 int moge_forward(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int rows, int cols, const moge_outputs* out, void* stream) {
@@ -827,7 +890,7 @@ int moge_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, i
     if (!out->points || !out->depth) return fail(MOGE_ERR_INVALID, "points and depth output buffers are required");
     hipStream_t st = (hipStream_t)stream;
     Plan pl = make_plan(c, h->prec, B, H, W, rows, cols);
-    CHK(ensure_ws(h, pl.total));
+    CHK(ensure_ws(h, forward_ws_bytes(h, pl)));
     float* mp = (c.heads & MOGE_HEAD_MASK) ? (out->mask_prob ? out->mask_prob : (float*)(h->ws + pl.maskprob)) : nullptr;
     float* nrm = (c.heads & MOGE_HEAD_NORMAL) ? out->normal : nullptr;
     float* metric = (c.heads & MOGE_HEAD_SCALE) ? (out->metric_scale ? out->metric_scale : (float*)(h->ws + pl.metric)) : nullptr;

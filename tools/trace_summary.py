@@ -1,0 +1,19 @@
+"""Aggregate a rocprofv3 --kernel-trace CSV by (kernel, grid, workgroup): calls, total/avg time.
+usage: python tools/trace_summary.py <kernel_trace.csv> [top_n]"""
+import csv, sys, collections, re
+rows = list(csv.DictReader(open(sys.argv[1])))
+top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+agg = collections.defaultdict(lambda: [0, 0.0])
+for r in rows:
+    name = re.sub(r"\(.*", "", r["Kernel_Name"])
+    name = re.sub(r"^void ", "", name)[:60]
+    gs = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
+    wg = int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", 1)) or 1)
+    k = (name, gs // max(wg, 1), wg)
+    agg[k][0] += 1
+    agg[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+tot = sum(v[1] for v in agg.values())
+print(f"total kernel time {tot/1e3:.2f} ms over {len(rows)} dispatches")
+print("kernel,blocks,wg,calls,total_ms,avg_us,pct")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+    print(f"{k[0]},{k[1]},{k[2]},{v[0]},{v[1]/1e3:.3f},{v[1]/v[0]:.1f},{100*v[1]/tot:.1f}")
