@@ -140,6 +140,8 @@ struct GemmArgs {
     float qscale;
     // EPI_CONVT: n = (dy*2+dx)*Cout + co -> out[((b*2H+2y+dy)*2W+2x+dx)*Cout+co]
     int Cout;
+    unsigned long long* dbg_ts;   // gemm_pp128: optional s_memtime stamps of one block (tools/kbench)
+    int stagger;           // gemm_pp128: number of start-phase classes (0/1 = off)
     int dbg;               // gemm_pp ablation bits (tools/kbench only): 1 no DMA, 2 no LDS reads, 4 no MFMA, 8 no barriers
 };
 

@@ -41,25 +41,32 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-// ---- shared epilogue: this wave's (TM*32) x 64 accumulator tile -> global memory ---------------------------------
-// Every wave has passed the final barrier: all LDS reads and all DMA writes of the ring are complete, so each wave may
-// reuse its private 16 KiB (TM = 4) / 8 KiB (TM = 2) region of the ring for the output transpose.
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (const char*)(((unsigned long long)hi << 32) | lo);
 }
 
-template <int TM, bool RESID>
+// ---- shared epilogue: this wave's (TM*32) x 64 accumulator tile -> global memory ---------------------------------
+// Every wave has passed the final barrier: all LDS reads and all DMA writes of the ring are complete, so each wave may
+// reuse its private 16 KiB (TM = 4) / 8 KiB (TM = 2) region of the ring for the output transpose.
+// The flavour is a COMPILE-TIME parameter: with run-time switches inside the 128-accumulator loops the compiler emitted
+// ~1000 register copies and ~100 branches per wave (measured 13-45k cycles per tile against a 43k-cycle K=1024 main loop).
+enum { EPK_RESID = 0, EPK_STORE = 1, EPK_GELU = 2, EPK_QKV = 3, EPK_CONVT = 4, EPK_UV = 5, EPK_RELU = 6 };
+
+template <int TM, int EPK>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][2], char* smem, int wave, int lane, int mw, int nw) {
     constexpr int TN = 2;
     constexpr int WROWS = TM * 32;
     const int hi = lane >> 5, l31 = lane & 31;
     char* R = smem + wave * (WROWS * 128);
     const int rr = lane >> 3, cc = lane & 7;
+    const int M = g.M;
 
-    if constexpr (RESID) {
+    if constexpr (EPK == EPK_RESID) {
         // x[m][n] += gamma[n] * (acc + bias[n])  on the fp32 residual stream (block.py:111-112, layer_scale.py:27)
+        float* const xres = g.xres;
+        const long ldc = g.ldc;
 #pragma unroll
         for (int j = 0; j < TN; j++) {
 #pragma unroll
@@ -67,52 +74,57 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM]
                 const int n = nw + j * 32 + 8 * q + 4 * hi;
                 const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
                 const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
+                const f32x4 gb = gm * b;
 #pragma unroll
                 for (int i = 0; i < TM; i++) {
                     const int row = i * 32 + l31;
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = gm[e] * (acc[i][j][4 * q + e] + b[e]);
+                    for (int e = 0; e < 4; e++) v[e] = fmaf(gm[e], acc[i][j][4 * q + e], gb[e]);
                     *reinterpret_cast<f32x4*>(R + row * 128 + (((2 * q + hi) ^ (row & 7)) << 4)) = v;
                 }
+            }
+            // read-modify-write in full 128-byte row segments; all loads of a pass are issued before the first add
+            f32x4 xv[WROWS / 8];
+#pragma unroll
+            for (int it = 0; it < WROWS / 8; it++) {
+                const int m = mw + it * 8 + rr;
+                const int mc = m < M ? m : M - 1;
+                xv[it] = *reinterpret_cast<const f32x4*>(xres + (size_t)mc * ldc + nw + j * 32 + cc * 4);
             }
 #pragma unroll
             for (int it = 0; it < WROWS / 8; it++) {
                 const int row = it * 8 + rr;
                 const int m = mw + row;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
-                if (m < g.M) {
-                    float* p = g.xres + (size_t)m * g.ldc + nw + j * 32 + cc * 4;
-                    f32x4 x = *reinterpret_cast<const f32x4*>(p);
-                    x += v;
-                    *reinterpret_cast<f32x4*>(p) = x;
-                }
+                if (m < M) *reinterpret_cast<f32x4*>(xres + (size_t)m * ldc + nw + j * 32 + cc * 4) = xv[it] + v;
             }
         }
     } else {
-        // bias (+ uv rank-2 term) (+ q scale) (+ GELU) in registers, pack to f16, transpose through LDS, 16-byte row stores
+        // bias (+ uv rank-2 term) (+ q scale) (+ activation) in registers, pack to f16, transpose through LDS, 16-byte row stores
         float scale = 1.f;
-        if (g.epi == EPI_QKV && nw < g.D) scale = g.qscale;
+        if constexpr (EPK == EPK_QKV) scale = nw < g.D ? g.qscale : 1.f;
         float u[TM], vv[TM];
-        if (g.uv.wu) {
+        if constexpr (EPK == EPK_UV) {
 #pragma unroll
             for (int i = 0; i < TM; i++) {
                 int m = mw + i * 32 + l31;
-                m = m < g.M ? m : g.M - 1;
+                m = m < M ? m : M - 1;
                 const int x = m % g.pixW, y = (m / g.pixW) % g.pixH;
                 u[i] = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, g.pixW, x);
                 vv[i] = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, g.pixH, y);
             }
         }
+        const bool has_bias = g.bias != nullptr;
 #pragma unroll
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int n = nw + j * 32 + 8 * q + 4 * hi;
                 f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (g.bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+                if (has_bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
                 f32x4 wu = {0.f, 0.f, 0.f, 0.f}, wv = wu;
-                if (g.uv.wu) {
+                if constexpr (EPK == EPK_UV) {
                     wu = *reinterpret_cast<const f32x4*>(g.uv.wu + n);
                     wv = *reinterpret_cast<const f32x4*>(g.uv.wv + n);
                 }
@@ -121,69 +133,68 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM]
                     const int row = i * 32 + l31;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = (acc[i][j][4 * q + e] + b[e]) * scale;
-                    if (g.uv.wu) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] += wu[e] * u[i] + wv[e] * vv[i];
-                    }
-                    if (g.act == ACT_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = gelu_fast(v[e]);
-                    } else if (g.act == ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 4; e++) {
+                        v[e] = acc[i][j][4 * q + e] + b[e];
+                        if constexpr (EPK == EPK_QKV) v[e] *= scale;
+                        if constexpr (EPK == EPK_UV) v[e] += wu[e] * u[i] + wv[e] * vv[i];
+                        if constexpr (EPK == EPK_GELU) v[e] = gelu_fast(v[e]);
+                        if constexpr (EPK == EPK_RELU) v[e] = fmaxf(v[e], 0.f);
                     }
                     const f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                     *reinterpret_cast<f16x4*>(R + row * 128 + ((((j * 4 + q) ^ (row & 7)) << 4) | (hi << 3))) = hv;
                 }
             }
         // ---- row base pointers of the three store flavours (all advance by rows of 8 per iteration) -----------------
-        f16* obase;
-        long rstride = 0;                 // EPI_STORE only
-        int t0 = 0, b0 = 0;               // EPI_QKV: token / batch of this lane's first row
-        int px = 0, py = 0, pb = 0;       // EPI_CONVT: low-res pixel of this lane's first row
-        int co0 = 0, dy = 0, dx = 0;
         const int mfirst = mw + rr;
-        if (g.epi == EPI_QKV) {
+        if constexpr (EPK == EPK_QKV) {
             const int which = nw / g.D;
             const int head = (nw - which * g.D) >> 6;
-            obase = reinterpret_cast<f16*>(which == 0 ? g.q : (which == 1 ? g.k : g.vT)) + (size_t)head * g.Ntok * 64;
-            b0 = mfirst / g.Ntok;
-            t0 = mfirst - b0 * g.Ntok;
-        } else if (g.epi == EPI_CONVT) {
-            const int qd = nw / g.Cout;
-            co0 = nw - qd * g.Cout; dy = qd >> 1; dx = qd & 1;
-            obase = reinterpret_cast<f16*>(g.out);
-            px = mfirst % g.pixW;
-            const int t = mfirst / g.pixW;
-            py = t % g.pixH; pb = t / g.pixH;
-        } else {
-            obase = reinterpret_cast<f16*>(g.out) + nw;
-            rstride = g.ldc;
-        }
+            const int Ntok = g.Ntok;
+            f16* obase = reinterpret_cast<f16*>(which == 0 ? g.q : (which == 1 ? g.k : g.vT)) + (size_t)head * Ntok * 64 + cc * 8;
+            const size_t bstride = (size_t)g.nh * Ntok * 64;
+            int b0 = mfirst / Ntok;
+            int t0 = mfirst - b0 * Ntok;
 #pragma unroll
-        for (int it = 0; it < WROWS / 8; it++) {
-            const int row = it * 8 + rr;
-            const int m = mw + row;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
-            f16* p;
-            if (g.epi == EPI_QKV) {
-                p = obase + ((size_t)b0 * g.nh * g.Ntok + t0) * 64 + cc * 8;
+            for (int it = 0; it < WROWS / 8; it++) {
+                const int row = it * 8 + rr;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
+                f16* p = obase + (size_t)b0 * bstride + (size_t)t0 * 64;
                 t0 += 8;
-                if (t0 >= g.Ntok) { t0 -= g.Ntok; b0 += 1; }
-            } else if (g.epi == EPI_CONVT) {
-                p = obase + ((((size_t)pb * 2 * g.pixH + 2 * py + dy) * (2 * g.pixW)) + 2 * px + dx) * g.Cout + co0 + cc * 8;
-                px += 8;
-                if (px >= g.pixW) { px -= g.pixW; py += 1; if (py >= g.pixH) { py = 0; pb += 1; } }
-            } else {
-                p = obase + (size_t)m * rstride + cc * 8;
+                if (t0 >= Ntok) { t0 -= Ntok; b0 += 1; }
+                if (mw + row < M) *reinterpret_cast<u32x4*>(p) = v;
             }
-            if (m < g.M) *reinterpret_cast<u32x4*>(p) = v;
+        } else if constexpr (EPK == EPK_CONVT) {
+            const int Cout = g.Cout, pixW = g.pixW, pixH = g.pixH;
+            const int qd = nw / Cout;
+            const int co0 = nw - qd * Cout, dy = qd >> 1, dx = qd & 1;
+            f16* obase = reinterpret_cast<f16*>(g.out) + co0 + cc * 8;
+            int px = mfirst % pixW;
+            const int t = mfirst / pixW;
+            int py = t % pixH, pb = t / pixH;
+#pragma unroll
+            for (int it = 0; it < WROWS / 8; it++) {
+                const int row = it * 8 + rr;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
+                f16* p = obase + ((((size_t)pb * 2 * pixH + 2 * py + dy) * (2 * pixW)) + 2 * px + dx) * Cout;
+                px += 8;
+                if (px >= pixW) { px -= pixW; py += 1; if (py >= pixH) { py = 0; pb += 1; } }
+                if (mw + row < M) *reinterpret_cast<u32x4*>(p) = v;
+            }
+        } else {
+            f16* obase = reinterpret_cast<f16*>(g.out) + nw + cc * 8;
+            const long ldc = g.ldc;
+#pragma unroll
+            for (int it = 0; it < WROWS / 8; it++) {
+                const int row = it * 8 + rr;
+                const int m = mw + row;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
+                if (m < M) *reinterpret_cast<u32x4*>(obase + (size_t)m * ldc) = v;
+            }
         }
     }
 }
 
-template <int WM, int WN, int TM, bool RESID>
+template <int WM, int WN, int TM, int EPK>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs g) {
     constexpr int TN = 2;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs g) {
     // Every wave has passed 2*nph + 1 barriers; all LDS reads and all DMA writes of the ring are complete, so each wave
     // may now reuse its private 16 KiB (TM = 4) / 8 KiB (TM = 2) region of the ring for the output transpose.
 
-    pp_epilogue<TM, RESID>(g, acc, smem, wave, lane, m0 + wm * WROWS, n0 + wn * 64);
+    pp_epilogue<TM, EPK>(g, acc, smem, wave, lane, m0 + wm * WROWS, n0 + wn * 64);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs g) {
 // counted waits: vmcnt(8) after L_a (X2(t) = A_hi(t) landed), vmcnt(6) after L_b (X1(t+1) and the W half of X2(t+1)).
 // LDS: [parity][A 256 rows x 128 B | W 256 rows x 128 B], chunk swizzle c ^ ((row >> 1) & 7).
 // ------------------------------------------------------------------------------------------------------------------------
-template <bool RESID>
+template <int EPK>
 __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
     constexpr int TM = 4, TN = 2, WN = 4, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 * 64 KiB
@@ -347,6 +358,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
     const int m0 = bm * BM, n0 = bn * BN;
     const int nkt = g.K >> 6;
     const int dbg = g.dbg;
+    unsigned long long* ts = (g.dbg_ts && blockIdx.x == 777 && lane == 0) ? g.dbg_ts + wave * 8 : nullptr;
+    if (ts) ts[0] = __builtin_amdgcn_s_memtime();
+    // Phase stagger: every CU's first block starts delayed by a fraction of a tile's main-loop time, so that the epilogue
+    // store / read-modify-write bursts of the CUs (all tiles take the same time) do not hit HBM at the same instant.
+    if (g.stagger > 1 && blockIdx.x < 256) {
+        const int cls = (blockIdx.x >> 3) % g.stagger;
+        const int units = (cls * nkt * 2) / (5 * g.stagger);        // x 8128 cycles (main loop ~ 3300 cycles per K-tile)
+        for (int i = 0; i < units; i++) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- DMA sources.  A piece = 8 rows x 128 B; this wave's pieces start at rows 8*wave (+ region offsets), so the
     // swizzle term ((row >> 1) & 7) = 4*(wave & 1) + (lane >> 4) is the same for all of them.
@@ -407,6 +427,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
+    if (ts) ts[1] = __builtin_amdgcn_s_memtime();
     u32x4 af[2][4], wf[TN][4];
     for (int t = 0; t < nkt; t++) {
         const char* sl = smem + (t & 1) * 65536;
@@ -464,14 +485,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    pp_epilogue<TM, RESID>(g, acc, smem, wave, lane, m0 + wm * 128, n0 + wn * 64);
+    if (ts) ts[2] = __builtin_amdgcn_s_memtime();
+    if (dbg & 32) {          // ablation: no epilogue (keep the accumulators alive)
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    pp_epilogue<TM, EPK>(g, acc, smem, wave, lane, m0 + wm * 128, n0 + wn * 64);
+    if (ts) {
+        ts[3] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[4] = __builtin_amdgcn_s_memtime();
+    }
 }
 
-template <bool RESID>
+template <int EPK>
 static int launch_pp128(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = 2 * 65536;
     static bool attr_set = false;
-    auto kern = gemm_pp128_kernel<RESID>;
+    auto kern = gemm_pp128_kernel<EPK>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
@@ -482,12 +516,12 @@ static int launch_pp128(const GemmArgs& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-template <int WM, int WN, int TM, bool RESID>
+template <int WM, int WN, int TM, int EPK>
 static int launch_pp_cfg(const GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * 64;
     constexpr int smem = 4 * (BM + BN) * 64;
     static bool attr_set = false;
-    auto kern = gemm_pp_kernel<WM, WN, TM, RESID>;
+    auto kern = gemm_pp_kernel<WM, WN, TM, EPK>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
@@ -512,12 +546,37 @@ bool gemm_pp_eligible(const GemmArgs& g) {
     }
 }
 
+static int epilogue_kind(const GemmArgs& g) {
+    switch (g.epi) {
+    case EPI_RESID: return EPK_RESID;
+    case EPI_QKV: return EPK_QKV;
+    case EPI_CONVT: return EPK_CONVT;
+    default: break;
+    }
+    if (g.uv.wu) return EPK_UV;
+    if (g.act == ACT_GELU) return EPK_GELU;
+    if (g.act == ACT_RELU) return EPK_RELU;
+    return EPK_STORE;
+}
+
+template <int EPK>
+static int launch_pp_any(const GemmArgs& g, bool wide, hipStream_t st) {
+    if (wide && (g.K & 63) == 0 && moge_tune_get("PP_ROW128", 1)) return launch_pp128<EPK>(g, st);
+    return wide ? launch_pp_cfg<2, 4, 4, EPK>(g, st) : launch_pp_cfg<4, 2, 2, EPK>(g, st);
+}
+
 int launch_gemm_pp(const GemmArgs& g0, hipStream_t st) {
     GemmArgs g = g0;
     g.dbg = moge_tune_get("PP_DBG", 0);
+    g.stagger = moge_tune_get("PP_STAGGER", 0);
     const bool wide = (g.N % 256) == 0 && !(g.epi == EPI_QKV && (g.D % 256) != 0);
-    if (wide && (g.K & 63) == 0 && moge_tune_get("PP_ROW128", 1))
-        return g.epi == EPI_RESID ? launch_pp128<true>(g, st) : launch_pp128<false>(g, st);
-    if (g.epi == EPI_RESID) return wide ? launch_pp_cfg<2, 4, 4, true>(g, st) : launch_pp_cfg<4, 2, 2, true>(g, st);
-    return wide ? launch_pp_cfg<2, 4, 4, false>(g, st) : launch_pp_cfg<4, 2, 2, false>(g, st);
+    switch (epilogue_kind(g)) {
+    case EPK_RESID: return launch_pp_any<EPK_RESID>(g, wide, st);
+    case EPK_QKV: return launch_pp_any<EPK_QKV>(g, wide, st);
+    case EPK_CONVT: return launch_pp_any<EPK_CONVT>(g, wide, st);
+    case EPK_UV: return launch_pp_any<EPK_UV>(g, wide, st);
+    case EPK_GELU: return launch_pp_any<EPK_GELU>(g, wide, st);
+    case EPK_RELU: return launch_pp_any<EPK_RELU>(g, wide, st);
+    default: return launch_pp_any<EPK_STORE>(g, wide, st);
+    }
 }

@@ -141,10 +141,11 @@ static int bench_gemm(const char* filter, int iters) {
         {"vits.fc2", 8 * Ntok, 384, 1536, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"tailM", 700, 1024, 1024, EPI_STORE, ACT_GELU, 0, 0, 0, 0, 0, 0, 0},
     };
-    struct Variant { const char* name; int pp, glds, dbg, row128; };
+    struct Variant { const char* name; int pp, glds, dbg, row128, stagger; };
     std::vector<Variant> variants = {{"old-glds2", 0, 2, 0, 0}, {"pp64", 1, 2, 0, 0}, {"pp128", 1, 2, 0, 1}};
+    if (getenv("KB_STAGGER")) variants = {{"pp128", 1, 2, 0, 1, 0}, {"pp128-stg2", 1, 2, 0, 1, 2}, {"pp128-stg4", 1, 2, 0, 1, 4}, {"pp128-stg8", 1, 2, 0, 1, 8}};
     if (getenv("KB_ABLATE")) {
-        variants = {{"pp128", 1, 2, 0, 1}, {"pp128-nodma", 1, 2, 1, 1}, {"pp128-nolds", 1, 2, 2, 1}, {"pp128-nomfma", 1, 2, 4, 1},
+        variants = {{"pp128", 1, 2, 0, 1}, {"pp128-noact", 1, 2, 16, 1}, {"pp128-noepi", 1, 2, 32, 1}, {"pp128-nodma", 1, 2, 1, 1}, {"pp128-nolds", 1, 2, 2, 1}, {"pp128-nomfma", 1, 2, 4, 1},
                     {"pp128-nobar", 1, 2, 8, 1}, {"pp128-mfmaonly", 1, 2, 11, 1}};
     }
     int fails = 0;
@@ -197,6 +198,7 @@ static int bench_gemm(const char* filter, int iters) {
             moge_tune_set("GLDS_VARIANT", v.glds);
             moge_tune_set("PP_DBG", v.dbg);
             moge_tune_set("PP_ROW128", v.row128);
+            moge_tune_set("PP_STAGGER", v.stagger);
             // correctness: one launch on fresh buffers
             CK(hipMemsetAsync(out, 0, out_elems * 2, st));
             if (x) CK(hipMemcpyAsync(x, x0, M * N * 4, hipMemcpyDeviceToDevice, st));
@@ -208,6 +210,16 @@ static int bench_gemm(const char* filter, int iters) {
             float hmax; int hbad;
             CK(hipMemcpyAsync(&hmax, dmax, 4, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hbad, dbad, 4, hipMemcpyDeviceToHost, st));
             CK(hipStreamSynchronize(st));
+            if (getenv("KB_TS") && v.pp && v.row128) {
+                unsigned long long* dts; CK(hipMalloc(&dts, 64 * 8)); CK(hipMemsetAsync(dts, 0, 64 * 8, st));
+                GemmArgs g2 = g; g2.dbg_ts = dts;
+                launch_gemm<f16>(g2, AMODE_LINEAR, st);
+                unsigned long long hts[64]; CK(hipMemcpyAsync(hts, dts, 64 * 8, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+                for (int w = 0; w < 8; w += 4)
+                    printf("   ts wave %d: prologue %llu  mainloop %llu  epilogue-issue %llu  store-drain %llu  (memtime ticks)\n", w, hts[w * 8 + 1] - hts[w * 8],
+                           hts[w * 8 + 2] - hts[w * 8 + 1], hts[w * 8 + 3] - hts[w * 8 + 2], hts[w * 8 + 4] - hts[w * 8 + 3]);
+                CK(hipFree(dts));
+            }
             const double ms = time_launches(g, iters, st);
             const double tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12;
             printf("%-14s M=%-7zu N=%-5zu K=%-5zu %-10s %8.3f ms %8.1f TF/s   check: max err/tol %.3f, bad %d / %zu %s\n", s.name, M, N, K, v.name, ms, tf,
