@@ -87,6 +87,13 @@ template <int CPR> __device__ __forceinline__ int swz(int row, int c);
 template <> __device__ __forceinline__ int swz<8>(int row, int c) { return c ^ ((row >> 1) & 7); }
 template <> __device__ __forceinline__ int swz<16>(int row, int c) { return c ^ (row & 15); }
 
+// force a wave-uniform pointer onto the scalar unit (defeats per-lane 64-bit pointer induction variables in DMA loops)
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // torch.linspace(start, end, steps) element i in fp32 (ATen: symmetric evaluation around the middle)
@@ -149,5 +156,7 @@ struct GemmArgs {
 template <typename T> int launch_gemm(const GemmArgs& g, int amode, hipStream_t st);
 bool gemm_pp_eligible(const GemmArgs& g);
 int launch_gemm_pp(const GemmArgs& g, hipStream_t st);
+bool conv_pp_eligible(const GemmArgs& g);
+int launch_conv_pp(const GemmArgs& g, hipStream_t st);
 // runtime tuning / A-B switches (tests, tools/kbench): see tune.cpp-style table in gemm.hip
 int moge_tune_get(const char* key, int dflt);

@@ -489,7 +489,11 @@ int launch_gemm(const GemmArgs& g, int amode, hipStream_t st) {
             }
         }
         return launch_by_n<T, AMODE_LINEAR>(g, st);
-    case AMODE_CONV3: return launch_by_n<T, AMODE_CONV3>(g, st);
+    case AMODE_CONV3:
+        if constexpr (std::is_same<T, f16>::value) {
+            if (moge_tune_get("CONV_PP", 1) && conv_pp_eligible(g)) return launch_conv_pp(g, st);
+        }
+        return launch_by_n<T, AMODE_CONV3>(g, st);
     }
     return -1;
 }

@@ -41,12 +41,6 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-__device__ __forceinline__ const char* uniform_ptr(const char* p) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (const char*)(((unsigned long long)hi << 32) | lo);
-}
-
 // ---- shared epilogue: this wave's (TM*32) x 64 accumulator tile -> global memory ---------------------------------
 // Every wave has passed the final barrier: all LDS reads and all DMA writes of the ring are complete, so each wave may
 // reuse its private 16 KiB (TM = 4) / 8 KiB (TM = 2) region of the ring for the output transpose.

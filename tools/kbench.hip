@@ -357,6 +357,88 @@ static int bench_attn(int iters) {
     return fails;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 convolutions: conv_pp (halo kernel) against the implicit-GEMM kernel of gemm.hip (itself checked against torch in tests/)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void cmp_f16(const f16* a, const f16* b, size_t n, float* maxratio, int* nbad) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = (float)a[i], y = (float)b[i];
+        const float tol = fabsf(y) * (1.0f / 400.0f) + 2e-3f;
+        const float r = fabsf(x - y) / tol;
+        if (!(r <= 1.0f)) atomicAdd(nbad, 1);
+        atomicMaxF(maxratio, r == r ? r : 1e30f);
+    }
+}
+static int bench_conv(const char* filter, int iters) {
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    struct Case { const char* name; int B, H, W, C, Cout; int convt, relu_in, act, add, uv; };
+    const Case cases[] = {
+        {"L3 res1 64->64 480", 32, 480, 480, 64, 64, 0, 1, ACT_RELU, 0, 0},
+        {"L3 res2 +add", 32, 480, 480, 64, 64, 0, 0, ACT_NONE, 1, 0},
+        {"L3 rs uv", 32, 480, 480, 64, 64, 0, 0, ACT_NONE, 0, 1},
+        {"up2 64->4x32 480", 32, 480, 480, 64, 32, 1, 0, ACT_NONE, 0, 0},
+        {"up2 uv", 32, 480, 480, 64, 32, 1, 0, ACT_NONE, 0, 1},
+        {"L2 128->128 240", 32, 240, 240, 128, 128, 0, 1, ACT_RELU, 0, 0},
+        {"L1 256->256 120", 32, 120, 120, 256, 256, 0, 0, ACT_NONE, 1, 0},
+        {"odd 64->64 50x37", 3, 50, 37, 64, 64, 0, 1, ACT_RELU, 0, 1},
+        {"odd 64->64 add 17x70", 3, 17, 70, 64, 64, 0, 0, ACT_NONE, 1, 1},
+        {"odd 128->128 21x40", 2, 21, 40, 128, 128, 0, 0, ACT_NONE, 0, 1},
+        {"odd up2 64 19x33", 2, 19, 33, 64, 32, 1, 0, ACT_NONE, 0, 1},
+        {"odd up2 128->4x64", 2, 19, 33, 128, 64, 1, 0, ACT_NONE, 0, 0},
+    };
+    int fails = 0;
+    for (const Case& c : cases) {
+        if (filter && !strstr(c.name, filter)) continue;
+        const size_t px = (size_t)c.B * c.H * c.W;
+        const int N = c.convt ? 4 * c.Cout : c.Cout, K = 9 * c.C;
+        const size_t n_in = px * c.C, n_out = px * N, n_w = (size_t)N * K;
+        f16 *in, *w, *out0, *out1, *add; float *bias, *wu, *wv, *dmax; int* dbad;
+        CK(hipMalloc(&in, n_in * 2)); CK(hipMalloc(&w, n_w * 2)); CK(hipMalloc(&out0, n_out * 2)); CK(hipMalloc(&out1, n_out * 2)); CK(hipMalloc(&add, n_out * 2));
+        CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&wu, N * 4)); CK(hipMalloc(&wv, N * 4)); CK(hipMalloc(&dmax, 4)); CK(hipMalloc(&dbad, 4));
+        fill_f16<<<2048, 256, 0, st>>>(in, n_in, 21u, 1.0f);
+        fill_f16<<<2048, 256, 0, st>>>(w, n_w, 22u, 0.06f);
+        fill_f16<<<2048, 256, 0, st>>>(add, n_out, 23u, 1.0f);
+        fill_f32<<<64, 256, 0, st>>>(bias, N, 24u, 0.5f, 0.f);
+        fill_f32<<<64, 256, 0, st>>>(wu, N, 25u, 1.0f, 0.f);
+        fill_f32<<<64, 256, 0, st>>>(wv, N, 26u, 1.0f, 0.f);
+        GemmArgs g; memset(&g, 0, sizeof(g));
+        g.a = in; g.H = c.H; g.W = c.W; g.C = c.C; g.relu_in = c.relu_in; g.w = w; g.ldw = K; g.M = (int)px; g.N = N; g.K = K;
+        g.epi = c.convt ? EPI_CONVT : EPI_STORE; g.act = c.act; g.bias = bias; g.ldc = N; g.ldadd = N; g.pixW = c.W; g.pixH = c.H; g.Cout = c.Cout;
+        if (c.add) g.add = add;
+        if (c.uv) { g.uv.wu = wu; g.uv.wv = wv; g.uv.u0 = -0.7f; g.uv.u1 = 0.7f; g.uv.v0 = -0.6f; g.uv.v1 = 0.6f;
+                    const int uw = c.convt ? 2 * c.W : c.W, uh = c.convt ? 2 * c.H : c.H; g.uv.ustep = 1.4f / (uw - 1); g.uv.vstep = 1.2f / (uh - 1); }
+        double ms[2] = {0, 0};
+        for (int v = 0; v < 2; v++) {
+            moge_tune_set("CONV_PP", v);
+            g.out = v ? out1 : out0;
+            CK(hipMemsetAsync(g.out, 0, n_out * 2, st));
+            int rc = launch_gemm<f16>(g, AMODE_CONV3, st);
+            if (rc) { printf("%s launch rc=%d\n", c.name, rc); fails++; break; }
+            CK(hipStreamSynchronize(st));
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            launch_gemm<f16>(g, AMODE_CONV3, st);
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; i++) launch_gemm<f16>(g, AMODE_CONV3, st);
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1)); ms[v] = t / iters;
+        }
+        CK(hipMemsetAsync(dmax, 0, 4, st)); CK(hipMemsetAsync(dbad, 0, 4, st));
+        cmp_f16<<<2048, 256, 0, st>>>(out1, out0, n_out, dmax, dbad);
+        float hmax; int hbad;
+        CK(hipMemcpyAsync(&hmax, dmax, 4, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hbad, dbad, 4, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+        const double fl = 2.0 * px * N * K;
+        printf("conv %-22s gemm.hip %8.3f ms %7.1f TF/s | conv_pp %8.3f ms %7.1f TF/s | max diff/tol %.3f, bad %d / %zu %s\n", c.name, ms[0], fl / ms[0] / 1e9,
+               ms[1], fl / ms[1] / 1e9, hmax, hbad, n_out, hbad ? "FAIL" : "ok");
+        fflush(stdout);
+        if (hbad) fails++;
+        CK(hipFree(in)); CK(hipFree(w)); CK(hipFree(out0)); CK(hipFree(out1)); CK(hipFree(add)); CK(hipFree(bias)); CK(hipFree(wu)); CK(hipFree(wv)); CK(hipFree(dmax)); CK(hipFree(dbad));
+    }
+    moge_tune_set("CONV_PP", 1);
+    return fails;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: kbench gemm|attn [filter] [iters]\n"); return 1; }
     CK(hipSetDevice(0));
@@ -364,6 +446,7 @@ int main(int argc, char** argv) {
     const int iters = argc > 3 ? atoi(argv[3]) : 10;
     if (!strcmp(argv[1], "gemm")) return bench_gemm(filter, iters) ? 4 : 0;
     if (!strcmp(argv[1], "attn")) return bench_attn(iters) ? 4 : 0;
+    if (!strcmp(argv[1], "conv")) return bench_conv(filter, iters) ? 4 : 0;
     fprintf(stderr, "unknown bench %s\n", argv[1]);
     return 1;
 }
