@@ -26,7 +26,10 @@ def H():
 
 @pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("M,N,K,act", [(300, 256, 192, 0), (129, 64, 72, 1), (77, 32, 40, 0), (1000, 1152, 384, 2), (128, 128, 64, 0),
-                                       (4097, 384, 1536, 0), (515, 96, 288, 0)])
+                                       (4097, 384, 1536, 0), (515, 96, 288, 0),
+                                       # shapes the fp16 ping-pong kernels take (gemm_pp.hip): 256x256 full-line tiles, K tails of
+                                       # the 64-byte-row variant, M tails, GELU / ReLU epilogues
+                                       (700, 1024, 1024, 2), (513, 512, 64, 0), (1111, 256, 96, 1), (2049, 768, 3072, 0)])
 def test_gemm(H, prec, M, N, K, act):
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
@@ -71,7 +74,11 @@ def test_attention_online_softmax_rescale(H):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("B,Hh,Ww,Cin,Cout,relu", [(2, 13, 17, 32, 32, False), (1, 9, 20, 64, 128, True), (1, 31, 5, 32, 64, True), (1, 8, 8, 128, 256, False)])
+@pytest.mark.parametrize("B,Hh,Ww,Cin,Cout,relu", [(2, 13, 17, 32, 32, False), (1, 9, 20, 64, 128, True), (1, 31, 5, 32, 64, True), (1, 8, 8, 128, 256, False),
+                                                   # conv_pp.hip (fp16 halo kernel): 64-wide / 128-wide tiles, 1 and several Cin chunks,
+                                                   # partial 16x16 tiles on every border
+                                                   (2, 20, 33, 64, 64, True), (1, 37, 18, 128, 64, False), (1, 16, 16, 256, 128, True),
+                                                   (3, 7, 50, 192, 256, False)])
 def test_conv3x3(H, prec, B, Hh, Ww, Cin, Cout, relu):
     g = torch.Generator().manual_seed(Cin + Cout)
     x = torch.randn(B, Cin, Hh, Ww, generator=g)
@@ -84,11 +91,12 @@ def test_conv3x3(H, prec, B, Hh, Ww, Cin, Cout, relu):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
-def test_conv3x3_fused_bilinear_up2(H, prec):
+@pytest.mark.parametrize("Cin,Cout,Hh,Ww", [(64, 32, 11, 7), (64, 32, 19, 33), (128, 64, 9, 21)])
+def test_conv3x3_fused_bilinear_up2(H, prec, Cin, Cout, Hh, Ww):
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(2, 64, 11, 7, generator=g)
-    w = torch.randn(32, 64, 3, 3, generator=g) / 24
-    b = torch.randn(32, generator=g)
+    x = torch.randn(2, Cin, Hh, Ww, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g)
     up = F.interpolate(x.cuda(), scale_factor=2, mode="bilinear", align_corners=False)
     ref = F.conv2d(F.pad(up, (1, 1, 1, 1), mode="replicate"), w.cuda(), b.cuda()).permute(0, 2, 3, 1)
     assert relmax(H.conv3x3(prec, x.permute(0, 2, 3, 1), w, b, up2=True), ref) < TOL[prec]

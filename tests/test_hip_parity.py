@@ -90,6 +90,22 @@ def test_fp16_mode_within_reference_fp16_band(MoGeModel, name, tmp_path_factory)
         compare({k: v.cpu().numpy() for k, v in o.items()}, g, 3e-2, mask_frac=5e-3)
 
 
+def test_fp16_mode_vits_real_image_vs_reference_golden(MoGeModel, tmp_path_factory):
+    """ViT-S decoder dims (256/128/64/32) on the 518x518 example image: the only golden case whose shapes reach every fp16
+    throughput kernel (gemm_pp 128/256-wide tiles, attention_pp, conv_pp 64/128-wide with 1..4 Cin chunks, pixel-shuffle
+    resampler).  Judged against the REAL reference's fp32 output with the fp16 band."""
+    case, cfg, sd, x, gold, meta = load_case("vits_house518")
+    model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory)
+    kw = dict(case["kwargs"]); kw["use_fp16"] = True
+    st = case.get("stride", 1)
+    g = {k[6:]: v for k, v in gold.items() if k.startswith("infer.")}
+    try:
+        out_h = model.half().infer(x, **kw)
+    finally:
+        model.float()
+    compare({k: subsample(k, v.cpu().numpy(), st) for k, v in out_h.items()}, g, 3e-2, mask_frac=5e-3)
+
+
 def test_stage_taps_match_oracle(MoGeModel, tmp_path_factory):
     """Stage boundaries of one forward (fp32 mode): LayerNorm'ed ViT taps, cls token, encoder features, every neck level."""
     from oracle import moge_oracle as O
