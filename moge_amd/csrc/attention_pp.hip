@@ -145,22 +145,29 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_pp_kernel(const
         f32x16 sc[2];
         float psum = 0.f;
         if (!exact) {
-            // ---- fast path: S^T - m = K Q^T + (-m);  P = exp2(.) ------------------------------------------------------
+            // ---- fast path: S^T - m = K Q^T + (-m);  P = exp2(.)  (all eight K fragments are requested before the first
+            // MFMA: read -> wait -> MFMA pairs expose the LDS latency eight times per tile)
+            u32x4 kf[2][4];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                sc[h] = negm;
+            for (int h = 0; h < 2; h++)
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const u32x4 kf = *reinterpret_cast<const u32x4*>(ka[s] + h * 4096);
-                    mma_step<f16>(sc[h], kf, qf[s]);
-                }
+                for (int s = 0; s < 4; s++) kf[h][s] = *reinterpret_cast<const u32x4*>(ka[s] + h * 4096);
+            sc[0] = negm;
+            sc[1] = negm;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                mma_step<f16>(sc[0], kf[0][s], qf[s]);
+                mma_step<f16>(sc[1], kf[1][s], qf[s]);
             }
             float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 sc[0][r] = __builtin_amdgcn_exp2f(sc[0][r]);
-                sc[1][r] = __builtin_amdgcn_exp2f(sc[1][r]);
                 ps0 += sc[0][r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                sc[1][r] = __builtin_amdgcn_exp2f(sc[1][r]);
                 ps1 += sc[1][r];
             }
             psum = ps0 + ps1;
@@ -213,19 +220,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_pp_kernel(const
                 }
         }
         l_run += psum;
-        // ---- O^T += V^T P^T ---------------------------------------------------------------------------------------------
+        // ---- O^T += V^T P^T  (the four V^T operands of a 32-key half are requested together) ---------------------------------
 #pragma unroll
-        for (int h = 0; h < 2; h++)
+        for (int h = 0; h < 2; h++) {
+            u32x4 vf[2][2];
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++) {
+                    const int koff = (h * 32 + 16 * s) * 128;
+                    vf[s][dt] = tr_pair(va[dt] + koff, va[dt] + koff + 4 * 128);
+                }
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 const u32x4 pf = pack8(sc[h], s);
-                const int koff = (h * 32 + 16 * s) * 128;
 #pragma unroll
-                for (int dt = 0; dt < 2; dt++) {
-                    const u32x4 vf = tr_pair(va[dt] + koff, va[dt] + koff + 4 * 128);
-                    mma_step<f16>(o[dt], vf, pf);
-                }
+                for (int dt = 0; dt < 2; dt++) mma_step<f16>(o[dt], vf[s][dt], pf);
             }
+        }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
