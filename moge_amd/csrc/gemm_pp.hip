@@ -348,7 +348,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
-    const int bm = wg / nbn, bn = wg - bm * nbn;
+    // tile order: column groups of 4 tiles, rows fastest inside a group -> the 32 tiles an XCD has in flight are 8 row panels
+    // x 4 column panels, and the group's W panels (4 x 256 rows x K) stay in that XCD's 4 MiB L2 while it walks down the rows
+    int bm, bn;
+    {
+        const int nbm = (g.M + BM - 1) / BM;
+        const int grp_cols = 4, per_grp = nbm * grp_cols;
+        const int cg = wg / per_grp, rem = wg - cg * per_grp;
+        const int cols = min(grp_cols, nbn - cg * grp_cols);
+        bm = rem / cols;
+        bn = cg * grp_cols + (rem - bm * cols);
+    }
     const int m0 = bm * BM, n0 = bn * BN;
     const int nkt = g.K >> 6;
     const int dbg = g.dbg;

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): rocprofv3 evidence for the bench command of this round, written under gpurun_out/prof_<tag>/.
+#   tools/profile_round.sh <tag>
+# pass 1: --kernel-trace --stats (per-kernel durations);  pass 2/3: --pmc FETCH_SIZE / WRITE_SIZE (separate passes, no trace domains)
+tag=${1:-r01}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+out=$root/gpurun_out/prof_$tag
+rm -rf $out; mkdir -p $out
+cd $root
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile"
+export MOGE_BATCH_SPLIT=0     # one stream: a kernel's trace interval then contains only that kernel
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o tr -- $CMD > $out/trace.log 2>&1
+python3 tools/trace_summary.py $out/trace/tr_kernel_trace.csv 60 > $out/kernels_by_grid.csv
+cp $out/trace/tr_kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o pmc -- $CMD > $out/pmc_$c.log 2>&1
+  python3 tools/pmc_summary.py $out/pmc_$c > $out/pmc_$c.csv
+done
+grep -h '"metric"' $out/trace.log | tail -1 > $out/bench_under_rocprof.json
+rm -rf $out/trace $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE     # keep the summaries only (raw CSVs are tens of MB)
+ls -la $out
