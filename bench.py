@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
     ap.add_argument("--config", default=WORKLOAD_CONFIG)
     ap.add_argument("--num-tokens", type=int, default=None)
+    ap.add_argument("--shape", default=f"{IMG}x{IMG}", help="HxW of the synthetic images; 'mixed' = half 518x1036, half 1036x518 "
+                                                           "(BASELINE configs[4]: two same-shape sub-batches per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="disable the per-kernel HIP-event profiler")
     args = ap.parse_args()
@@ -82,7 +84,12 @@ def main():
 
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    x = torch.rand(B, 3, IMG, IMG, generator=g).to(dev)
+    if args.shape == "mixed":
+        xs = [torch.rand(B // 2, 3, 518, 1036, generator=g).to(dev), torch.rand(B - B // 2, 3, 1036, 518, generator=g).to(dev)]
+    else:
+        hh, ww = (int(v) for v in args.shape.lower().split("x"))
+        xs = [torch.rand(B, 3, hh, ww, generator=g).to(dev)]
+    x = xs[0]
     kw = {} if args.num_tokens is None else {"num_tokens": args.num_tokens}
     num_tokens = args.num_tokens or int(model.num_tokens_range[0] + (9 / 9) * (model.num_tokens_range[1] - model.num_tokens_range[0]))
 
@@ -91,12 +98,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def step():
+        o = None
+        for xi in xs:               # one step = one infer() per same-shape sub-batch (the reference cannot mix shapes in a tensor)
+            o = model.infer(xi, **kw)
+        return o
+
     for _ in range(args.warmup):
-        model.infer(x, **kw)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = model.infer(x, **kw)
+        out = step()
     barrier()
     elapsed = time.perf_counter() - t0
     # per-kernel-class HIP-event profile: the SAME K steps again with events around every launch (on the launch stream).
@@ -107,12 +120,12 @@ def main():
     if not args.no_profile:
         model.profile(True)
         model.profile_read(reset=True)
-        model.infer(x, **kw)
+        step()
         model.profile_read(reset=True)
         barrier()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            model.infer(x, **kw)
+            step()
         barrier()
         prof_ms_per_step = (time.perf_counter() - t1) / args.steps * 1e3
         prof = model.profile_read(reset=True)
@@ -137,10 +150,10 @@ def main():
             lat.append((time.perf_counter() - t1) * 1e3)
         lat = sorted(lat[2:])
         res = {
-            "metric": "images/sec (MoGeModel.infer, moge-2-vitl 518x518 fp16)", "value": round(value, 3), "unit": "images/s",
+            "metric": f"images/sec (MoGeModel.infer, {args.config} {args.shape} fp16)", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{args.config} infer(): batch {B}/GPU x 3x{IMG}x{IMG} torch.rand, num_tokens {num_tokens}, "
+            "config": {"workload": f"{args.config} infer(): batch {B}/GPU x 3x{args.shape} torch.rand, num_tokens {num_tokens}, "
                                    f"fp16 weights, synthetic checkpoint (seed 0), inputs resident in HBM, outputs left on device",
                        "global_batch": world * B, "parallelism": f"dp{world} (independent shards, one-time RCCL weight broadcast)"},
             "p50_latency_ms_batch1": round(lat[len(lat) // 2], 3),

@@ -15,6 +15,9 @@
 //     counted vmcnt, the next two tiles in flight during the MFMAs.
 //   * V stays row-major (key, d): the PV MFMA's A-operand (V^T rows) is read with ds_read_b64_tr_b16 (hardware
 //     transpose), so the QKV epilogue writes V like K in full 128-byte rows instead of 2-byte transposed scatters.
+// (A barrier-alternated variant - 8 waves, one group in a 16-MFMA segment while the other runs the softmax / LDS segment, as
+// gemm_pp.hip does - was measured at 657-727 TF/s against 885 TF/s for this free-running 3-waves-per-SIMD kernel: the VALU
+// issue of the softmax segment is starved by the partner's back-to-back MFMAs, so the extra occupancy wins here.)
 // Both products are issued "swapped" (S^T = K Q^T, O^T = V^T P^T) so the query is the lane index and the softmax state is
 // per lane; K rows enter the first MFMA in a bit-2/3-swapped order so that its accumulator registers are directly the
 // second MFMA's B-operand (see attention.hip).
@@ -69,28 +72,39 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_pp_kernel(const
     const char* kbase = reinterpret_cast<const char*>(k + (size_t)bh * Ntok * 64);
     const char* vbase = reinterpret_cast<const char*>(v + (size_t)bh * Ntok * 64);
     const int prow = lane >> 3, pch = lane & 7;
-    int drow[NPW];               // tile row this lane fetches in piece i
-    unsigned dcol[NPW];          // byte offset of the (un-swizzled) source chunk inside the row
-    bool dIsV[NPW];
+    // piece i of this wave: K rows (p < 8) or V rows (p >= 8), 8 rows x 128 B; per-lane byte offset inside the 64-key tile is a
+    // constant, the tile advance stays on the scalar unit.  Only the last tile clamps its key index (rows >= Ntok repeat row
+    // Ntok-1: masked for K, multiplied by P = 0 for V).
+    int drow[NPW];
+    unsigned doff[NPW];
 #pragma unroll
     for (int i = 0; i < NPW; i++) {
         const int p = wave + NW * i;                     // 0..15
-        dIsV[i] = p >= 8;
         const int row = (p & 7) * 8 + prow;
         drow[i] = row;
         // K: chunk ^ ((row >> 1) & 7) (conflict-free ds_read_b128);  V: chunk ^ (((key >> 1) & 1) << 2) (conflict-free tr reads)
-        const int lch = dIsV[i] ? (pch ^ (((row >> 1) & 1) << 2)) : (pch ^ ((row >> 1) & 7));
-        dcol[i] = (unsigned)lch * 16;
+        const int lch = p >= 8 ? (pch ^ (((row >> 1) & 1) << 2)) : (pch ^ ((row >> 1) & 7));
+        doff[i] = (unsigned)(row * 128 + lch * 16);
     }
+    const int ntiles = (Ntok + 63) >> 6;
     auto issue = [&](int t) {
         char* st = smem + (t % 3) * AP_STAGE;
+        const char* kt = uniform_ptr(kbase + (size_t)t * 8192);
+        const char* vt = uniform_ptr(vbase + (size_t)t * 8192);
+        if (t < ntiles - 1) {
 #pragma unroll
-        for (int i = 0; i < NPW; i++) {
-            const int p = wave + NW * i;
-            int key = t * 64 + drow[i];
-            key = key < Ntok ? key : Ntok - 1;           // clamped rows are masked (K) / multiplied by P = 0 (V)
-            const char* src = (dIsV[i] ? vbase : kbase) + (size_t)key * 128 + dcol[i];
-            __builtin_amdgcn_global_load_lds(AP_GPTR(src), AP_LPTR(st + p * 1024), 16, 0, 0);
+            for (int i = 0; i < NPW; i++) {
+                const int p = wave + NW * i;
+                __builtin_amdgcn_global_load_lds(AP_GPTR((p >= 8 ? vt : kt) + doff[i]), AP_LPTR(st + p * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPW; i++) {
+                const int p = wave + NW * i;
+                const int over = t * 64 + drow[i] - (Ntok - 1);              // rows past the end step back to the last valid row
+                const unsigned off = doff[i] - (over > 0 ? (unsigned)over * 128u : 0u);
+                __builtin_amdgcn_global_load_lds(AP_GPTR((p >= 8 ? vt : kt) + off), AP_LPTR(st + p * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -120,7 +134,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_pp_kernel(const
     for (int r = 0; r < 16; r++) negm[r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
 
-    const int ntiles = (Ntok + 63) >> 6;
     issue(0);
     if (ntiles > 1) issue(1);
 

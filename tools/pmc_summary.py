@@ -17,7 +17,14 @@ for r in rows:
         if t:
             agg[k]["_us"] += (int(t["End_Timestamp"]) - int(t["Start_Timestamp"])) / 1e3
 names = sorted({r["Counter_Name"] for r in rows})
-print("kernel,blocks,calls,avg_us," + ",".join(names))
+derive = "SQ_VALU_MFMA_BUSY_CYCLES" in names and "GRBM_GUI_ACTIVE" in names
+# MFMA utilisation at the clock the kernel actually ran at: busy cycles / (cycles per XCD-summed GUI_ACTIVE / 8 XCDs * 1024 SIMDs);
+# effective clock = GUI_ACTIVE / 8 / duration
+print("kernel,blocks,calls,avg_us," + ",".join(names) + (",mfma_util,clock_ghz" if derive else ""))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["_us"])[:40]:
     n = cnt[k]
-    print(f"{k[0]},{k[1]},{n},{v['_us'] / n:.1f}," + ",".join(f"{v[c] / n:.4g}" for c in names))
+    extra = ""
+    if derive and v["GRBM_GUI_ACTIVE"] > 0:
+        cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+        extra = f",{v['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024):.3f},{cyc / (v['_us'] * 1e3):.2f}"
+    print(f"{k[0]},{k[1]},{n},{v['_us'] / n:.1f}," + ",".join(f"{v[c] / n:.4g}" for c in names) + extra)
