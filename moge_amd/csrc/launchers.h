@@ -24,8 +24,8 @@ int launch_repack(const float* src, void* dst, int n0, int n1, int n2, int n3, l
 template <typename T> int launch_pack_phase_conv(const float* w, void* dst, int Cout, int Cin, hipStream_t st);
 
 template <typename T>
-int launch_head_final(int kind, const void* x4, const float* w, const float* bias, float* out, int B, int Hd, int Wd, int C, int H, int W,
-                      int remap, hipStream_t st);
+int launch_head_final(int kind, const void* x4, const float* w, const float* bias, const void* n4, const float* w2, float* out, int B, int Hd,
+                      int Wd, int C, int H, int W, int remap, hipStream_t st);
 int launch_mlp_layer(const float* in, const float* W, const float* bias, float* out, int B, int K, int N, int act, hipStream_t st);
 int launch_recover(const float* points, const float* mask_prob, const uint8_t* mask_u8, const float* fov_deg, const float* focal_in, int B,
                    int H, int W, float* focal, float* shift, float* intrinsics, int* status, hipStream_t st);

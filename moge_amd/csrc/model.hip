@@ -185,6 +185,8 @@ static void build_tables(moge_handle* h) {
         if (cout > 0) {
             tadd(h, name + ".output_blocks.4.weight", (int64_t)cout * c.dims[4]);
             tadd(h, name + ".output_blocks.4.bias", cout);
+            aadd(h, name + ".out4.w2", (int64_t)cout * c.dims[4]);      // output conv o level-4 input block (fp16 path, see head_final_kernel)
+            aadd(h, name + ".out4.b2", cout);
         }
     };
     stack("neck", true, c.neck_res_blocks, 0);
@@ -252,7 +254,31 @@ static int build_aux(moge_handle* h, hipStream_t st) {
     };
     CHK(stack("neck"));
     for (int k = 0; k < 3; k++)
-        if (c.heads & HEAD_BITS[k]) CHK(stack(HEAD_NAMES[k]));
+        if (c.heads & HEAD_BITS[k]) {
+            CHK(stack(HEAD_NAMES[k]));
+            // W2 = Wout . Win,  b2 = bout + Wout . bin   (level 4: out(x + in_4(n4)) = Wout x + W2 n4 + b2)
+            const std::string name = HEAD_NAMES[k];
+            const int c4 = c.dims[4], co = HEAD_COUT[k];
+            std::vector<float> wout((size_t)co * c4), win((size_t)c4 * c4), bin(c4), bout(co), w2((size_t)co * c4), b2(co);
+            HIPCHK(hipMemcpyAsync(wout.data(), M(h, name + ".output_blocks.4.weight"), wout.size() * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(bout.data(), M(h, name + ".output_blocks.4.bias"), bout.size() * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(win.data(), M(h, name + ".input_blocks.4.weight"), win.size() * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(bin.data(), M(h, name + ".input_blocks.4.bias"), bin.size() * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int o = 0; o < co; o++) {
+                double bb = bout[o];
+                for (int m = 0; m < c4; m++) bb += (double)wout[(size_t)o * c4 + m] * bin[m];
+                b2[o] = (float)bb;
+                for (int j = 0; j < c4; j++) {
+                    double a = 0.0;
+                    for (int m = 0; m < c4; m++) a += (double)wout[(size_t)o * c4 + m] * win[(size_t)m * c4 + j];
+                    w2[(size_t)o * c4 + j] = (float)a;
+                }
+            }
+            HIPCHK(hipMemcpyAsync(A(h, name + ".out4.w2"), w2.data(), w2.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(A(h, name + ".out4.b2"), b2.data(), b2.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
     h->aux_ready = true;
     return 0;
 }
@@ -631,6 +657,7 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     }
     // ---- heads -------------------------------------------------------------------------------------------------------
     float* outs[3] = {o_points, o_normal, o_maskprob};
+    const bool fuse_l4 = std::is_same<T, f16>::value && c.head_res_blocks[MOGE_LEVELS - 1] == 0 && moge_tune_get("FUSE_L4", 1) != 0;
     for (int k = 0; k < 3; k++) {
         if (!(c.heads & HEAD_BITS[k]) || !outs[k]) continue;
         const std::string name = HEAD_NAMES[k];
@@ -650,16 +677,22 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
                 CHK(conv_up2_phase<T>(h, Sc[cur], P<T>(h, name + ".rs3.w3p"), A(h, name + ".rs3.bias4"), Sc[a], B, Hh / 2, Ww / 2, ci, co, nullptr, st));
                 nxt = a;
             }
-            // x = x + in_l(neck_l)   (in place: each element is read and written by the same lane)
-            CHK(conv1x1<T>(h, N[l], P<T>(h, name + S(".in%d.w", l)), M(h, name + S(".input_blocks.%d.bias", l)), Sc[nxt], (long)B * Hh * Ww, co, co, Sc[nxt],
-                           nullptr, Ww, Hh, st));
+            // x = x + in_l(neck_l)   (in place: each element is read and written by the same lane); at the last level of the fp16
+            // path the input block is folded into the output conv of head_final_kernel (no residual blocks in between)
+            if (!(l == MOGE_LEVELS - 1 && fuse_l4))
+                CHK(conv1x1<T>(h, N[l], P<T>(h, name + S(".in%d.w", l)), M(h, name + S(".input_blocks.%d.bias", l)), Sc[nxt], (long)B * Hh * Ww, co, co, Sc[nxt],
+                               nullptr, Ww, Hh, st));
             cur = nxt;
             CHK(res_blocks<T>(h, name, l, c.head_res_blocks[l], Sc[cur], Sc[(cur + 1) % 3], B, Hh, Ww, co, st));
         }
         {
             ProfScope ps(h, st, MOGE_KC_POST, 0, (double)B * (rows << 4) * (cols << 4) * c.dims[4] * sizeof(T));
-            LCHK(launch_head_final<T>(k, Sc[cur], M(h, name + ".output_blocks.4.weight"), M(h, name + ".output_blocks.4.bias"), outs[k], B, rows << 4,
-                                      cols << 4, c.dims[4], pl.H, pl.W, c.remap_output, st));
+            if (fuse_l4)
+                LCHK(launch_head_final<T>(k, Sc[cur], M(h, name + ".output_blocks.4.weight"), A(h, name + ".out4.b2"), N[4], A(h, name + ".out4.w2"), outs[k], B,
+                                          rows << 4, cols << 4, c.dims[4], pl.H, pl.W, c.remap_output, st));
+            else
+                LCHK(launch_head_final<T>(k, Sc[cur], M(h, name + ".output_blocks.4.weight"), M(h, name + ".output_blocks.4.bias"), nullptr, nullptr, outs[k], B,
+                                          rows << 4, cols << 4, c.dims[4], pl.H, pl.W, c.remap_output, st));
         }
     }
     // remember buffers for debug taps

@@ -9,15 +9,20 @@
 //   finalize   : z += shift, mask &= z>0, depth, re-projection, metric scale, masking (v2.py:267-289), one pass.
 #include "common.h"
 #include "../../include/moge_hip.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------------------
 template <typename T, int KIND>   // KIND 0 points, 1 normal, 2 mask
 __global__ __launch_bounds__(256) void head_final_kernel(const T* __restrict__ x4, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         const T* __restrict__ n4, const float* __restrict__ w2,
                                                          float* __restrict__ out, int B, int Hd, int Wd, int C, int H, int W, int remap) {
+    // optional second input n4 (same shape as x4) with its own 1x1 weights w2: the level-4 input block of the head
+    // (x + in_4(neck_4), modules.py:245) pre-composed with the output conv - both are linear and commute with the bilinear
+    // resize, so the 32-channel sum never has to be materialised at 16x the token resolution
     constexpr int CH = TT<T>::CH;
     constexpr int CO = KIND == 2 ? 1 : 3;
-    __shared__ float sw[3 * 64];
-    for (int i = threadIdx.x; i < CO * C; i += 256) sw[i] = w[i];
+    __shared__ float sw[2 * 3 * 64];
+    for (int i = threadIdx.x; i < CO * C; i += 256) { sw[i] = w[i]; sw[CO * C + i] = n4 ? w2[i] : 0.f; }
     __syncthreads();
     const long total = (long)B * H * W;
     const float sy_scale = (float)Hd / (float)H, sx_scale = (float)Wd / (float)W;
@@ -59,6 +64,27 @@ __global__ __launch_bounds__(256) void head_final_kernel(const T* __restrict__ x
 #pragma unroll
                 for (int i = 0; i < CH; i++) o[j] += sw[j * C + c0 + i] * f[i];
         }
+        if (n4) {
+            const size_t d = n4 - x4;            // same indexing in the second tensor
+            for (int c0 = 0; c0 < C; c0 += CH) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(p00 + d + c0), bq = *reinterpret_cast<const u32x4*>(p01 + d + c0);
+                const u32x4 cq = *reinterpret_cast<const u32x4*>(p10 + d + c0), dq = *reinterpret_cast<const u32x4*>(p11 + d + c0);
+                float f[CH];
+                if constexpr (CH == 8) {
+                    const f16x8 va = __builtin_bit_cast(f16x8, a), vb = __builtin_bit_cast(f16x8, bq), vc = __builtin_bit_cast(f16x8, cq), vd = __builtin_bit_cast(f16x8, dq);
+#pragma unroll
+                    for (int i = 0; i < CH; i++) f[i] = w00 * (float)va[i] + w01 * (float)vb[i] + w10 * (float)vc[i] + w11 * (float)vd[i];
+                } else {
+                    const f32x4 va = __builtin_bit_cast(f32x4, a), vb = __builtin_bit_cast(f32x4, bq), vc = __builtin_bit_cast(f32x4, cq), vd = __builtin_bit_cast(f32x4, dq);
+#pragma unroll
+                    for (int i = 0; i < CH; i++) f[i] = w00 * va[i] + w01 * vb[i] + w10 * vc[i] + w11 * vd[i];
+                }
+#pragma unroll
+                for (int j = 0; j < CO; j++)
+#pragma unroll
+                    for (int i = 0; i < CH; i++) o[j] += sw[CO * C + j * C + c0 + i] * f[i];
+            }
+        }
         if (KIND == 0) {
             float x = o[0], y = o[1], z = o[2];
             if (remap == MOGE_REMAP_EXP) { z = expf(z); x *= z; y *= z; }
@@ -73,20 +99,121 @@ __global__ __launch_bounds__(256) void head_final_kernel(const T* __restrict__ x
         }
     }
 }
+// fp16, C == 32 fast path: FOUR lanes per output pixel (8 channels = one 16-byte load per lane and tap, a lane quad reads a
+// pixel's 64 contiguous bytes), partial 1x1 products reduced over the quad with two DPP-class shuffles.
+template <int KIND>
+__global__ __launch_bounds__(256) void head_final32_kernel(const f16* __restrict__ x4, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           const f16* __restrict__ n4, const float* __restrict__ w2,
+                                                           float* __restrict__ out, int B, int Hd, int Wd, int H, int W, int remap) {
+    constexpr int C = 32, CO = KIND == 2 ? 1 : 3;
+    const int sub = threadIdx.x & 3;
+    float wr[CO][8], wr2[CO][8];
+#pragma unroll
+    for (int j = 0; j < CO; j++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) { wr[j][i] = w[j * C + sub * 8 + i]; wr2[j][i] = n4 ? w2[j * C + sub * 8 + i] : 0.f; }
+    const long total = (long)B * H * W;
+    const float sy_scale = (float)Hd / (float)H, sx_scale = (float)Wd / (float)W;
+    for (long idx = (blockIdx.x * 256L + threadIdx.x) >> 2; idx < total; idx += (long)gridDim.x * 64) {
+        const int ox = idx % W;
+        const long t = idx / W;
+        const int oy = t % H, b = t / H;
+        float sy = sy_scale * (oy + 0.5f) - 0.5f, sx = sx_scale * (ox + 0.5f) - 0.5f;
+        sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx;
+        int y0 = (int)sy, x0 = (int)sx;
+        y0 = y0 < Hd - 1 ? y0 : Hd - 1; x0 = x0 < Wd - 1 ? x0 : Wd - 1;
+        const int y1 = y0 + 1 < Hd ? y0 + 1 : Hd - 1, x1 = x0 + 1 < Wd ? x0 + 1 : Wd - 1;
+        float ly = sy - y0, lx = sx - x0;
+        ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
+        const float wt[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
+        const size_t base = (size_t)b * Hd * Wd * C + sub * 8;
+        const size_t off[4] = {base + ((size_t)y0 * Wd + x0) * C, base + ((size_t)y0 * Wd + x1) * C, base + ((size_t)y1 * Wd + x0) * C,
+                               base + ((size_t)y1 * Wd + x1) * C};
+        u32x4 qa[4], qb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) qa[k] = *reinterpret_cast<const u32x4*>(x4 + off[k]);
+        if (n4) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) qb[k] = *reinterpret_cast<const u32x4*>(n4 + off[k]);
+        }
+        float o[CO];
+#pragma unroll
+        for (int j = 0; j < CO; j++) o[j] = 0.f;
+        {
+            float f[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) f[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const f16x8 v = __builtin_bit_cast(f16x8, qa[k]);
+#pragma unroll
+                for (int i = 0; i < 8; i++) f[i] += wt[k] * (float)v[i];
+            }
+#pragma unroll
+            for (int j = 0; j < CO; j++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[j] += wr[j][i] * f[i];
+        }
+        if (n4) {
+            float f[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) f[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const f16x8 v = __builtin_bit_cast(f16x8, qb[k]);
+#pragma unroll
+                for (int i = 0; i < 8; i++) f[i] += wt[k] * (float)v[i];
+            }
+#pragma unroll
+            for (int j = 0; j < CO; j++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[j] += wr2[j][i] * f[i];
+        }
+#pragma unroll
+        for (int j = 0; j < CO; j++) {
+            o[j] += __shfl_xor(o[j], 1);
+            o[j] += __shfl_xor(o[j], 2);
+            o[j] += bias[j];
+        }
+        if (sub != 0) continue;
+        if (KIND == 0) {
+            float x = o[0], y = o[1], z = o[2];
+            if (remap == MOGE_REMAP_EXP) { z = expf(z); x *= z; y *= z; }
+            else if (remap == MOGE_REMAP_SINH) { x = sinhf(x); y = sinhf(y); z = sinhf(z); }
+            else if (remap == MOGE_REMAP_SINH_EXP) { x = sinhf(x); y = sinhf(y); z = expf(z); }
+            out[idx * 3] = x; out[idx * 3 + 1] = y; out[idx * 3 + 2] = z;
+        } else if (KIND == 1) {
+            const float nrm = fmaxf(sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]), 1e-12f);
+            out[idx * 3] = o[0] / nrm; out[idx * 3 + 1] = o[1] / nrm; out[idx * 3 + 2] = o[2] / nrm;
+        } else {
+            out[idx] = 1.f / (1.f + expf(-o[0]));
+        }
+    }
+}
+
 template <typename T>
-int launch_head_final(int kind, const void* x4, const float* w, const float* bias, float* out, int B, int Hd, int Wd, int C, int H, int W,
-                      int remap, hipStream_t st) {
+int launch_head_final(int kind, const void* x4, const float* w, const float* bias, const void* n4, const float* w2, float* out, int B, int Hd,
+                      int Wd, int C, int H, int W, int remap, hipStream_t st) {
     if (C > 64 || C % TT<T>::CH != 0) return -1;
     const long total = (long)B * H * W;
+    if (std::is_same<T, f16>::value && C == 32) {
+        long nb = (total * 4 + 255) / 256;
+        const int blocks4 = (int)(nb > 65536 ? 65536 : nb);
+        const f16* xa = (const f16*)x4; const f16* xb = (const f16*)n4;
+        if (kind == 0) hipLaunchKernelGGL((head_final32_kernel<0>), dim3(blocks4), dim3(256), 0, st, xa, w, bias, xb, w2, out, B, Hd, Wd, H, W, remap);
+        else if (kind == 1) hipLaunchKernelGGL((head_final32_kernel<1>), dim3(blocks4), dim3(256), 0, st, xa, w, bias, xb, w2, out, B, Hd, Wd, H, W, remap);
+        else hipLaunchKernelGGL((head_final32_kernel<2>), dim3(blocks4), dim3(256), 0, st, xa, w, bias, xb, w2, out, B, Hd, Wd, H, W, remap);
+        return (int)hipGetLastError();
+    }
     int blocks = (int)((total + 255) / 256);
     if (blocks > 32768) blocks = 32768;
-    if (kind == 0) hipLaunchKernelGGL((head_final_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const T*)x4, w, bias, out, B, Hd, Wd, C, H, W, remap);
-    else if (kind == 1) hipLaunchKernelGGL((head_final_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const T*)x4, w, bias, out, B, Hd, Wd, C, H, W, remap);
-    else hipLaunchKernelGGL((head_final_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const T*)x4, w, bias, out, B, Hd, Wd, C, H, W, remap);
+    if (kind == 0) hipLaunchKernelGGL((head_final_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const T*)x4, w, bias, (const T*)n4, w2, out, B, Hd, Wd, C, H, W, remap);
+    else if (kind == 1) hipLaunchKernelGGL((head_final_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const T*)x4, w, bias, (const T*)n4, w2, out, B, Hd, Wd, C, H, W, remap);
+    else hipLaunchKernelGGL((head_final_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const T*)x4, w, bias, (const T*)n4, w2, out, B, Hd, Wd, C, H, W, remap);
     return (int)hipGetLastError();
 }
-template int launch_head_final<f16>(int, const void*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
-template int launch_head_final<float>(int, const void*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+template int launch_head_final<f16>(int, const void*, const float*, const float*, const void*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+template int launch_head_final<float>(int, const void*, const float*, const float*, const void*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------------------
 // out[b][n] = f(sum_k in[b][k]*W[n][k] + bias[n]); one wave per output, fp32.  act: 0 none, 1 relu, 2 exp
