@@ -478,7 +478,13 @@ int launch_gemm(const GemmArgs& g, int amode, hipStream_t st) {
     switch (amode) {
     case AMODE_LINEAR:
         if constexpr (std::is_same<T, f16>::value) {
-            if (moge_tune_get("GEMM_PP", 1) && gemm_pp_eligible(g)) return launch_gemm_pp(g, st);
+            if (moge_tune_get("GEMM_PP", 1) && gemm_pp_eligible(g)) {
+                // latency regime (batch 1): fewer than half a wave of 256x256 tiles leaves most CUs idle; the 128x128 kernel
+                // below has 4x the workgroups (measured at M = 3601: proj 24 vs 33 us, fc2 56 vs 90 us)
+                const long tiles = ((long)(g.M + 255) / 256) * ((g.N + 255) / 256);
+                const bool small = tiles < moge_tune_get("PP_MIN_TILES", 128) && g.N > 64 && (g.K % (8 * TT<T>::CH)) == 0;
+                if (!small) return launch_gemm_pp(g, st);
+            }
         }
         if (g.N > 64 && !g.relu_in && (g.K % (8 * TT<T>::CH)) == 0 && !g_disable_glds) {
             switch (moge_tune_get("GLDS_VARIANT", 2)) {

@@ -140,6 +140,12 @@ static int bench_gemm(const char* filter, int iters) {
         {"vits.qkv", 8 * Ntok, 1152, 384, EPI_QKV, ACT_NONE, 384, 6, Ntok, 0, 0, 0, 0},
         {"vits.fc2", 8 * Ntok, 384, 1536, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"tailM", 700, 1024, 1024, EPI_STORE, ACT_GELU, 0, 0, 0, 0, 0, 0, 0},
+        {"b1.qkv", Ntok, 3072, 1024, EPI_QKV, ACT_NONE, 1024, 16, Ntok, 0, 0, 0, 0},
+        {"b1.proj", Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
+        {"b1.fc1", Ntok, 4096, 1024, EPI_STORE, ACT_GELU, 0, 0, 0, 0, 0, 0, 0},
+        {"b1.fc2", Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
+        {"b4.proj", 4 * Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
+        {"b4.fc2", 4 * Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
     };
     struct Variant { const char* name; int pp, glds, dbg, row128, stagger; };
     std::vector<Variant> variants = {{"old-glds2", 0, 2, 0, 0}, {"pp64", 1, 2, 0, 0}, {"pp128", 1, 2, 0, 1}};
