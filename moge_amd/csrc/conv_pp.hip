@@ -13,7 +13,11 @@
 //   * the 8 waves run as two groups half a step apart (one computing 16 or 8 MFMAs while the other reads its fragments),
 //     exactly like gemm_pp.hip; the epilogue transposes through LDS and stores 16 bytes per lane in full pixel rows.
 // Options: ReLU on the input (applied to the fragments after the LDS read), bias, uv rank-2 term, ReLU, residual add
-// (in place allowed), and the pixel-shuffle store of the 4-phase "bilinear x2 + 3x3" resampler (EPI_CONVT).
+// (in place allowed), the pixel-shuffle store of the 4-phase "bilinear x2 + 3x3" resampler (EPI_CONVT), and a fused 1x1
+// SIDE INPUT: out += W2 . a2 (same pixel, C2 = Cin channels) - the head's `x + in_l(neck_l)` (modules.py:245) runs as extra
+// K-steps (centre tap of a2's halo) instead of a separate HBM-bound pass over the level's activations.
+// Tile width TW = 16, or 32 for the 64-channel layers (64 px x 64 ch per wave: 16 fragment reads per 16 MFMAs instead of 12
+// per 8 - that configuration is LDS-read bound).
 #include "common.h"
 
 #define CP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -21,11 +25,13 @@
 
 namespace {
 
-constexpr int HALO_W = 18;                       // 16 + 2
-constexpr int HALO_PX = HALO_W * HALO_W;         // 324
-constexpr int HALO_PIECES = 41;                  // ceil(324 / 8) pieces of 8 pixels x 128 B
-constexpr int HALO_BYTES = HALO_PIECES * 1024;   // 41984
-constexpr int HPW = 6;                           // halo pieces per wave (8 waves x 6 >= 41; surplus pieces repeat piece 40)
+template <int TW> struct Halo {
+    static constexpr int W = TW + 2;                     // halo row width in pixels
+    static constexpr int PX = 18 * W;                    // 16 + 2 rows
+    static constexpr int PIECES = (PX + 7) / 8;          // DMA pieces of 8 pixels x 128 B (TW 16: 41, TW 32: 77)
+    static constexpr int BYTES = PIECES * 1024;
+    static constexpr int HPW = (PIECES + 7) / 8;         // pieces per wave; surplus pieces repeat the last one
+};
 
 __device__ __forceinline__ u32x4 relu8(u32x4 v) {
     f16x8 h = __builtin_bit_cast(f16x8, v);
@@ -36,12 +42,14 @@ __device__ __forceinline__ u32x4 relu8(u32x4 v) {
 
 template <int N> __device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
-// BN = 128: waves 4 (pixels) x 2 (channels), 64 px x 64 ch per wave;  BN = 64: waves 8 x 1, 32 px x 64 ch per wave
-// NH = halo buffers (1 when Cin == 64: a single chunk);  EPI: bit 0 = uv term, bit 1 = pixel-shuffle (EPI_CONVT) store
-template <int BN, int NH, int EPI>
-__global__ __launch_bounds__(512, (BN == 64 && NH == 1) ? 4 : 2) void conv_pp_kernel(const GemmArgs g) {
+// BN = 128: waves 4 (pixels) x 2 (channels);  BN = 64: waves 8 x 1.  A wave owns TM = TW*16/32/WM tiles of 32 pixels x 64 channels.
+// NH = halo buffers (1: Cin == 64 and no side input);  EPI: bit 0 = uv term, bit 1 = pixel-shuffle (EPI_CONVT) store
+template <int BN, int TW, int NH, int EPI>
+__global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) void conv_pp_kernel(const GemmArgs g) {
     constexpr bool CONVT = (EPI & 2) != 0, HAS_UV = (EPI & 1) != 0;
-    constexpr int WN = BN / 64, WM = 8 / WN, TM = 8 / WM, TN = 2;       // TM 32-pixel tiles per wave
+    constexpr int WN = BN / 64, WM = 8 / WN, TM = TW * 16 / 32 / WM, TN = 2;
+    constexpr int HALO_W = Halo<TW>::W, HALO_PX = Halo<TW>::PX, HALO_PIECES = Halo<TW>::PIECES, HALO_BYTES = Halo<TW>::BYTES, HPW = Halo<TW>::HPW;
+    constexpr int LOG_TW = TW == 16 ? 4 : 5;
     constexpr int NWP = BN / 64;                                         // weight pieces (8 rows x 128 B) per wave per K-step
     constexpr int WSLOT = BN * 128;
     constexpr int LDS_W = NH * HALO_BYTES;                                // weight ring behind the two halo buffers
@@ -55,7 +63,7 @@ __global__ __launch_bounds__(512, (BN == 64 && NH == 1) ? 4 : 2) void conv_pp_ke
     const int wm = wave / WN, wn = wave % WN;
 
     const int H = g.H, W = g.W, C = g.C;
-    const int tx_n = (W + 15) >> 4, ty_n = (H + 15) >> 4;
+    const int tx_n = (W + TW - 1) / TW, ty_n = (H + 15) >> 4;
     const int nbn = g.N / BN;
     int wg;
     {
@@ -67,12 +75,15 @@ __global__ __launch_bounds__(512, (BN == 64 && NH == 1) ? 4 : 2) void conv_pp_ke
     const int tx = t % tx_n; t /= tx_n;
     const int ty = t % ty_n;
     const int b = t / ty_n;
-    const int y0 = ty * 16, x0 = tx * 16, n0 = bn * BN;
+    const int y0 = ty * 16, x0 = tx * TW, n0 = bn * BN;
     const int nchunks = NH == 1 ? 1 : (C >> 6);        // NH == 1: Cin == 64, straight-line 9-step K loop
-    const int nkt = nchunks * 9;
+    const int nside = (NH > 1 && g.a2) ? (C >> 6) : 0;  // fused 1x1 side input: one centre-tap K-step per 64 channels of a2
+    const int nkt1 = nchunks * 9;
+    const int nkt = nkt1 + nside;
 
     // ---- DMA sources ----------------------------------------------------------------------------------------------
     const char* in_b = reinterpret_cast<const char*>(g.a) + (size_t)b * H * W * C * 2;
+    const char* in2_b = reinterpret_cast<const char*>(g.a2) + (size_t)b * H * W * C * 2;      // side input: same NHWC shape
     const int prow = lane >> 3, pch = lane & 7;
     unsigned hoff[HPW];                 // byte offset of this lane's source chunk for halo piece i (chunk 0 of Cin)
 #pragma unroll
@@ -89,15 +100,17 @@ __global__ __launch_bounds__(512, (BN == 64 && NH == 1) ? 4 : 2) void conv_pp_ke
         hoff[i] = (unsigned)(((yy * W + xx) * C) * 2 + ((pch ^ sw) << 4));
     }
     const char* w_b = reinterpret_cast<const char*>(g.w) + (size_t)n0 * g.ldw * 2;
-    unsigned woff[NWP];
+    const char* w2_b = reinterpret_cast<const char*>(g.w2) + (size_t)n0 * C * 2;               // [N][C] 1x1 weights of the side input
+    int wrow[NWP];                      // weight-tile row and swizzled chunk offset of this lane in piece i
+    unsigned wsw[NWP];
 #pragma unroll
     for (int i = 0; i < NWP; i++) {
-        const int row = (wave + 8 * i) * 8 + prow;
-        woff[i] = (unsigned)(row * g.ldw * 2 + ((pch ^ ((row >> 1) & 7)) << 4));
+        wrow[i] = (wave + 8 * i) * 8 + prow;
+        wsw[i] = (unsigned)((pch ^ ((wrow[i] >> 1) & 7)) << 4);
     }
-    auto issue_halo = [&](int c) {
+    auto issue_halo = [&](int c) {               // chunk c of the conv input, or chunk c - nchunks of the side input
         char* dst = smem + (c & (NH - 1)) * HALO_BYTES;
-        const char* src = uniform_ptr(in_b + (size_t)c * 128);
+        const char* src = uniform_ptr(c < nchunks ? in_b + (size_t)c * 128 : in2_b + (size_t)(c - nchunks) * 128);
 #pragma unroll
         for (int i = 0; i < HPW; i++) {
             int piece = wave + 8 * i;
@@ -105,13 +118,17 @@ __global__ __launch_bounds__(512, (BN == 64 && NH == 1) ? 4 : 2) void conv_pp_ke
             __builtin_amdgcn_global_load_lds(CP_GPTR(src + hoff[i]), CP_LPTR(dst + piece * 1024), 16, 0, 0);
         }
     };
-    auto issue_w = [&](int kt) {                 // K-step kt = chunk * 9 + tap  ->  weight columns (tap * C + chunk * 64)
-        const int c = kt / 9, tap = kt - c * 9;
+    auto issue_w = [&](int kt) {                 // K-step kt = chunk * 9 + tap  ->  weight columns (tap * C + chunk * 64); side steps follow
         char* dst = smem + LDS_W + (kt & 3) * WSLOT;
-        const char* src = uniform_ptr(w_b + ((size_t)tap * C + c * 64) * 2);
+        const bool side = kt >= nkt1;
+        const int c = kt / 9, tap = kt - c * 9;
+        const char* src = uniform_ptr(side ? w2_b + (size_t)(kt - nkt1) * 128 : w_b + ((size_t)tap * C + c * 64) * 2);
+        const int rowb = side ? C * 2 : g.ldw * 2;                   // row pitch of the side weights [N][C] / conv weights [N][9C]
 #pragma unroll
-        for (int i = 0; i < NWP; i++)
-            __builtin_amdgcn_global_load_lds(CP_GPTR(src + woff[i]), CP_LPTR(dst + (wave + 8 * i) * 1024), 16, 0, 0);
+        for (int i = 0; i < NWP; i++) {
+            const unsigned off = (unsigned)(wrow[i] * rowb) + wsw[i];
+            __builtin_amdgcn_global_load_lds(CP_GPTR(src + off), CP_LPTR(dst + (wave + 8 * i) * 1024), 16, 0, 0);
+        }
     };
 
     // ---- fragment addressing ---------------------------------------------------------------------------------------
@@ -120,7 +137,7 @@ __global__ __launch_bounds__(512, (BN == 64 && NH == 1) ? 4 : 2) void conv_pp_ke
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int mp = wm * WROWS + i * 32 + l31;
-        hp0[i] = ((mp >> 4) + 1) * HALO_W + (mp & 15) + 1;
+        hp0[i] = ((mp >> LOG_TW) + 1) * HALO_W + (mp & (TW - 1)) + 1;
     }
     const int sxw = (l31 >> 1) & 7;
     const int w_off = (wn * 64 + l31) * 128 + ((hi ^ sxw) << 4);          // weight row (wn*64 + j*32 + l31); k-step ks: ^ (ks * 32)
@@ -145,88 +162,96 @@ __global__ __launch_bounds__(512, (BN == 64 && NH == 1) ? 4 : 2) void conv_pp_ke
     __builtin_amdgcn_sched_barrier(0);
 
     const int relu_in = g.relu_in;
-    int kt = 0;
+    const int ntot = nchunks + nside;                // halo images consumed: conv chunks, then side chunks
+    // one K-step: fragments of (halo image, tap), weights of step kt; DMA for step kt+3 (+ the next halo image at the first step of
+    // an image); counted wait; barrier; 16 / 8 MFMAs; barrier.  halo_age: steps since the last halo issue (its 6-10 pieces may
+    // still be in flight during the issuing step and the one after).
+    int kt = 0, halo_age = 2;
+    auto kstep = [&](const char* halo, int dy, int dx, bool first_of_image, int image, bool relu) {
+        const char* wsl = smem + LDS_W + (kt & 3) * WSLOT;
+        u32x4 af[TM][4], wf[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int hp = hp0[i] + dy * HALO_W + dx;
+            const int a0 = hp * 128 + ((hi ^ ((hp >> 1) & 7)) << 4);
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) af[i][ks] = *reinterpret_cast<const u32x4*>(halo + (a0 ^ (ks * 32)));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) wf[j][ks] = *reinterpret_cast<const u32x4*>(wsl + (w_off ^ (ks * 32)) + j * 4096);
+        // DMA: the next halo image (the other halo buffer was last read one barrier ago), weights 3 steps ahead
+        const bool halo_now = NH > 1 && first_of_image && image + 1 < ntot;
+        if (halo_now) { issue_halo(image + 1); halo_age = 0; }
+        const int ahead = nkt - 2 - kt;                    // how many of W(kt+2), W(kt+3) exist
+        if (ahead >= 2) issue_w(kt + 3);
+        if (halo_now && image >= nchunks) {
+            // a side image is consumed in ONE step: the halo just issued is read by the very next step, so it must land now
+            // (only the weight pieces issued after it may stay in flight); costs one DMA latency per additional side chunk
+            if (ahead >= 2) wait_vm_lgkm<NWP>();
+            else wait_vm_lgkm<0>();
+        } else if (NH > 1 && halo_age <= 1) {
+            if (ahead >= 2) wait_vm_lgkm<2 * NWP + HPW>();
+            else if (ahead == 1) wait_vm_lgkm<NWP + HPW>();
+            else wait_vm_lgkm<HPW>();
+        } else {
+            if (ahead >= 2) wait_vm_lgkm<2 * NWP>();
+            else if (ahead == 1) wait_vm_lgkm<NWP>();
+            else wait_vm_lgkm<0>();
+        }
+        halo_age++;
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) af[i][ks] = relu8(af[i][ks]);
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) mma_step<f16>(acc[i][j], wf[j][ks], af[i][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        if (!(grp == 1 && kt == nkt - 1)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        kt++;
+    };
     for (int c = 0; c < nchunks; c++) {
         const char* halo = smem + (c & (NH - 1)) * HALO_BYTES;
-        const bool more_halo = NH > 1 && c + 1 < nchunks;
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++, kt++) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            // ======== load segment ========
-            const char* wsl = smem + LDS_W + (kt & 3) * WSLOT;
-            u32x4 af[TM][4], wf[TN][4];
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                const int hp = hp0[i] + dy * HALO_W + dx;
-                const int a0 = hp * 128 + ((hi ^ ((hp >> 1) & 7)) << 4);
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) af[i][ks] = *reinterpret_cast<const u32x4*>(halo + (a0 ^ (ks * 32)));
-            }
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) wf[j][ks] = *reinterpret_cast<const u32x4*>(wsl + (w_off ^ (ks * 32)) + j * 4096);
-            // DMA: next chunk's halo (first tap of a chunk; the other halo buffer was last read one barrier ago), weights 3 steps ahead
-            const bool halo_now = tap == 0 && more_halo;
-            if (halo_now) issue_halo(c + 1);
-            const int ahead = nkt - 2 - kt;                    // how many of W(kt+2), W(kt+3) exist
-            if (ahead >= 2) issue_w(kt + 3);
-            const bool halo_pending = (tap <= 1) && more_halo; // halo pieces issued at tap 0 may still be in flight through tap 1
-            if (halo_pending) {
-                if (ahead >= 2) wait_vm_lgkm<2 * NWP + HPW>();
-                else if (ahead == 1) wait_vm_lgkm<NWP + HPW>();
-                else wait_vm_lgkm<HPW>();
-            } else {
-                if (ahead >= 2) wait_vm_lgkm<2 * NWP>();
-                else if (ahead == 1) wait_vm_lgkm<NWP>();
-                else wait_vm_lgkm<0>();
-            }
-            if (relu_in) {
-#pragma unroll
-                for (int i = 0; i < TM; i++)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ks++) af[i][ks] = relu8(af[i][ks]);
-            }
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            // ======== compute segment ========
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++)
-#pragma unroll
-                for (int i = 0; i < TM; i++)
-#pragma unroll
-                    for (int j = 0; j < TN; j++) mma_step<f16>(acc[i][j], wf[j][ks], af[i][ks]);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" ::: "memory");
-            if (!(grp == 1 && kt == nkt - 1)) __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int tap = 0; tap < 9; tap++) kstep(halo, tap / 3 - 1, tap % 3 - 1, tap == 0, c, relu_in != 0);
     }
+    for (int c2 = 0; c2 < nside; c2++) kstep(smem + ((nchunks + c2) & (NH - 1)) * HALO_BYTES, 0, 0, true, nchunks + c2, false);
 
     // ---- epilogue: bias / uv / ReLU in registers, transpose through LDS, (residual add,) 16-byte pixel-row stores -------------
     char* R = smem + wave * (WROWS * 128);
     const int rr = lane >> 3, cc = lane & 7;
     const int nw = n0 + wn * 64;
-    float u[TM][2], vv[TM][2];
+    float u0[TM], u1[TM], v0[TM], v1[TM];          // separate arrays: a [TM][2] array indexed by the parity goes to scratch
     if constexpr (HAS_UV) {
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int mp = wm * WROWS + i * 32 + l31;
-            int y = y0 + (mp >> 4), x = x0 + (mp & 15);
+            int y = y0 + (mp >> LOG_TW), x = x0 + (mp & (TW - 1));
             y = y < H ? y : H - 1; x = x < W ? x : W - 1;
             if constexpr (CONVT) {
-#pragma unroll
-                for (int d = 0; d < 2; d++) {     // high-res coordinates of the two output parities
-                    u[i][d] = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, 2 * W, 2 * x + d);
-                    vv[i][d] = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, 2 * H, 2 * y + d);
-                }
+                // high-res coordinates of the two output parities
+                u0[i] = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, 2 * W, 2 * x);
+                u1[i] = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, 2 * W, 2 * x + 1);
+                v0[i] = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, 2 * H, 2 * y);
+                v1[i] = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, 2 * H, 2 * y + 1);
             } else {
-                u[i][0] = u[i][1] = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, W, x);
-                vv[i][0] = vv[i][1] = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, H, y);
+                u0[i] = u1[i] = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, W, x);
+                v0[i] = v1[i] = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, H, y);
             }
         }
     }
@@ -254,8 +279,8 @@ __global__ __launch_bounds__(512, (BN == 64 && NH == 1) ? 4 : 2) void conv_pp_ke
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * q + e] + bv[e];
                 if constexpr (HAS_UV) {
-                    const float uu = pdx ? u[i][1] : u[i][0];
-                    const float vq = pdy ? vv[i][1] : vv[i][0];
+                    const float uu = pdx ? u1[i] : u0[i];
+                    const float vq = pdy ? v1[i] : v0[i];
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] += wu[e] * uu + wv[e] * vq;
                 }
@@ -271,7 +296,7 @@ __global__ __launch_bounds__(512, (BN == 64 && NH == 1) ? 4 : 2) void conv_pp_ke
     for (int it = 0; it < WROWS / 8; it++) {
         const int row = it * 8 + rr;
         const int mp = wm * WROWS + row;
-        const int y = y0 + (mp >> 4), x = x0 + (mp & 15);
+        const int y = y0 + (mp >> LOG_TW), x = x0 + (mp & (TW - 1));
         u32x4 v = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
         if (y < H && x < W) {
             if constexpr (CONVT) {
@@ -294,18 +319,18 @@ __global__ __launch_bounds__(512, (BN == 64 && NH == 1) ? 4 : 2) void conv_pp_ke
     }
 }
 
-template <int BN, int NH, int EPI>
+template <int BN, int TW, int NH, int EPI>
 int launch_conv_cfg(const GemmArgs& g, hipStream_t st) {
-    constexpr int smem = NH * HALO_BYTES + 4 * BN * 128;
+    constexpr int smem = NH * Halo<TW>::BYTES + 4 * BN * 128;
     static bool attr_set = false;
-    auto kern = conv_pp_kernel<BN, NH, EPI>;
+    auto kern = conv_pp_kernel<BN, TW, NH, EPI>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const long B = (long)g.M / ((long)g.H * g.W);
-    const long tiles = B * ((g.H + 15) / 16) * ((g.W + 15) / 16) * (g.N / BN);
+    const long tiles = B * ((g.H + 15) / 16) * ((g.W + TW - 1) / TW) * (g.N / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), smem, st, g);
     return (int)hipGetLastError();
 }
@@ -318,24 +343,30 @@ bool conv_pp_eligible(const GemmArgs& g) {
     if (g.N != 64 && (g.N & 127)) return false;
     if (g.H < 1 || g.W < 1 || (long)g.M % ((long)g.H * g.W) != 0) return false;
     if ((long)g.H * g.W * g.C * 2 >= (1L << 31)) return false;                     // 32-bit halo offsets
+    if (g.a2 && (!g.w2 || g.epi != EPI_STORE)) return false;
     if (g.epi == EPI_STORE)        // (the residual add is applied after the activation here: never combined by the decoder)
         return (g.ldc & 7) == 0 && (!g.add || ((g.ldadd & 7) == 0 && g.act == ACT_NONE)) && (!g.uv.wu || g.bias) && g.act != ACT_GELU;
     if (g.epi == EPI_CONVT) return !g.add && g.act == ACT_NONE && (g.Cout == 32 || (g.Cout & 63) == 0) && g.N == 4 * g.Cout;
     return false;
 }
 
-template <int BN, int NH>
+template <int BN, int TW, int NH>
 static int launch_conv_epi(const GemmArgs& g, hipStream_t st) {
     const int e = (g.uv.wu ? 1 : 0) | (g.epi == EPI_CONVT ? 2 : 0);
     switch (e) {
-    case 0: return launch_conv_cfg<BN, NH, 0>(g, st);
-    case 1: return launch_conv_cfg<BN, NH, 1>(g, st);
-    case 2: return launch_conv_cfg<BN, NH, 2>(g, st);
-    default: return launch_conv_cfg<BN, NH, 3>(g, st);
+    case 0: return launch_conv_cfg<BN, TW, NH, 0>(g, st);
+    case 1: return launch_conv_cfg<BN, TW, NH, 1>(g, st);
+    case 2: return launch_conv_cfg<BN, TW, NH, 2>(g, st);
+    default: return launch_conv_cfg<BN, TW, NH, 3>(g, st);
     }
 }
 
 int launch_conv_pp(const GemmArgs& g, hipStream_t st) {
-    if (g.N == 64) return g.C == 64 ? launch_conv_epi<64, 1>(g, st) : launch_conv_epi<64, 2>(g, st);
-    return g.C == 64 ? launch_conv_epi<128, 1>(g, st) : launch_conv_epi<128, 2>(g, st);
+    const bool one_image = g.C == 64 && !g.a2;           // a single halo image: one buffer
+    if (g.N == 64) {
+        // 32-pixel-wide tiles (64 px x 64 ch per wave) when the image is wide enough to fill them
+        if (one_image && g.W >= 32 && moge_tune_get("CONV_TW32", 0)) return launch_conv_epi<64, 32, 1>(g, st);
+        return one_image ? launch_conv_epi<64, 16, 1>(g, st) : launch_conv_epi<64, 16, 2>(g, st);
+    }
+    return one_image ? launch_conv_epi<128, 16, 1>(g, st) : launch_conv_epi<128, 16, 2>(g, st);
 }

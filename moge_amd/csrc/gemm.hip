@@ -24,6 +24,18 @@ template <typename T>
 __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float v0, float v1, float v2, float v3) {
     if (m >= g.M || n >= g.N) return;
     float v[4] = {v0, v1, v2, v3};
+    if (g.epi == EPI_RESID) {
+        // x[m][n] += gamma[n] * (acc + bias[n]); same operation order as gemm_pp.hip (resid_term, then one add)
+        float* p = g.xres + (size_t)m * g.ldc + n;
+        f32x4 x = *reinterpret_cast<f32x4*>(p);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = x[i] + resid_term(gm[i], v[i], b[i]);
+        *reinterpret_cast<f32x4*>(p) = x;
+        return;
+    }
     if (g.bias) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
 #pragma unroll
@@ -39,7 +51,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float
             const f32x4 wu = *reinterpret_cast<const f32x4*>(g.uv.wu + n);
             const f32x4 wv = *reinterpret_cast<const f32x4*>(g.uv.wv + n);
 #pragma unroll
-            for (int i = 0; i < 4; i++) v[i] += wu[i] * u + wv[i] * vv;
+            for (int i = 0; i < 4; i++) v[i] = uv_term_add(v[i], wu[i], u, wv[i], vv);
         }
         if (g.add) {
             float a[4];
@@ -52,18 +64,9 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float
             for (int i = 0; i < 4; i++) v[i] = fmaxf(v[i], 0.f);
         } else if (g.act == ACT_GELU) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) v[i] = gelu_erf(v[i]);
+            for (int i = 0; i < 4; i++) v[i] = TT<T>::PREC ? gelu_fast(v[i]) : gelu_erf(v[i]);   // fp16 storage: the fast form (as gemm_pp.hip)
         }
         store4(reinterpret_cast<T*>(g.out) + (size_t)m * g.ldc + n, v[0], v[1], v[2], v[3]);
-        break;
-    }
-    case EPI_RESID: {
-        float* p = g.xres + (size_t)m * g.ldc + n;
-        f32x4 x = *reinterpret_cast<f32x4*>(p);
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
-#pragma unroll
-        for (int i = 0; i < 4; i++) x[i] += gm[i] * v[i];
-        *reinterpret_cast<f32x4*>(p) = x;
         break;
     }
     case EPI_PATCH: {

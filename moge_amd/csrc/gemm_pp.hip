@@ -26,21 +26,6 @@
 #define PP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define PP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-// gelu(x) = x * Phi(x) with Phi(x) = sigmoid(x * P(x^2)); P fitted (weighted minimax, degree 4 in x^2) to
-// logit(Phi(x))/x on |x| <= 5, max abs error of gelu 3.7e-6 over all x (P grows for |x| > 5, so both tails saturate
-// correctly: exp2 -> 0 or +inf).  8 VALU + 2 transcendentals per element instead of erff's ~35.  f16 outputs only.
-__device__ __forceinline__ float gelu_fast(float x) {
-    constexpr float L2E = 1.4426950408889634f;
-    const float x2 = x * x;
-    float p = 2.09755530e-06f * L2E;
-    p = fmaf(p, x2, -5.83663339e-05f * L2E);
-    p = fmaf(p, x2, -2.66659641e-04f * L2E);
-    p = fmaf(p, x2, 7.29729188e-02f * L2E);
-    p = fmaf(p, x2, 1.59563637f * L2E);
-    const float e = __builtin_amdgcn_exp2f(-(p * x));
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
 // ---- shared epilogue: this wave's (TM*32) x 64 accumulator tile -> global memory ---------------------------------
 // Every wave has passed the final barrier: all LDS reads and all DMA writes of the ring are complete, so each wave may
 // reuse its private 16 KiB (TM = 4) / 8 KiB (TM = 2) region of the ring for the output transpose.
@@ -68,13 +53,12 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM]
                 const int n = nw + j * 32 + 8 * q + 4 * hi;
                 const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
                 const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
-                const f32x4 gb = gm * b;
 #pragma unroll
                 for (int i = 0; i < TM; i++) {
                     const int row = i * 32 + l31;
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = fmaf(gm[e], acc[i][j][4 * q + e], gb[e]);
+                    for (int e = 0; e < 4; e++) v[e] = resid_term(gm[e], acc[i][j][4 * q + e], b[e]);
                     *reinterpret_cast<f32x4*>(R + row * 128 + (((2 * q + hi) ^ (row & 7)) << 4)) = v;
                 }
             }
@@ -130,7 +114,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM]
                     for (int e = 0; e < 4; e++) {
                         v[e] = acc[i][j][4 * q + e] + b[e];
                         if constexpr (EPK == EPK_QKV) v[e] *= scale;
-                        if constexpr (EPK == EPK_UV) v[e] += wu[e] * u[i] + wv[e] * vv[i];
+                        if constexpr (EPK == EPK_UV) v[e] = uv_term_add(v[e], wu[e], u[i], wv[e], vv[i]);
                         if constexpr (EPK == EPK_GELU) v[e] = gelu_fast(v[e]);
                         if constexpr (EPK == EPK_RELU) v[e] = fmaxf(v[e], 0.f);
                     }
@@ -188,9 +172,12 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM]
     }
 }
 
-template <int WM, int WN, int TM, int EPK>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs g) {
+// NS = ring slots (prefetch distance NS-1 phases).  <4,2,2,*,3>: 256x128 tile, 72 KiB LDS, <= 128 VGPRs -> TWO workgroups per
+// CU, whose epilogues / prologues overlap each other's main loops (the 256x256 kernel owns the CU and idles the MFMA pipe there)
+template <int WM, int WN, int TM, int EPK, int NS>
+__global__ __launch_bounds__(512, (TM == 2 && NS == 3) ? 4 : 2) void gemm_pp_kernel(const GemmArgs g) {
     constexpr int TN = 2;
+    constexpr int D = NS - 1;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 8 && BM == 256, "8 waves, 256-row tiles");
     constexpr int SLOT = (BM + BN) * 64;          // bytes per ring slot (one phase)
@@ -235,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs g) {
         }
     }
     auto issue = [&](int ph) {
-        char* dst = smem + (ph & 3) * SLOT + wave * 1024;
+        char* dst = smem + (ph % NS) * SLOT + wave * 1024;
 #pragma unroll
         for (int i = 0; i < NPW; i++)
             __builtin_amdgcn_global_load_lds(PP_GPTR(src[i] + (size_t)ph * 32), PP_LPTR(dst + i * 8192), 16, 0, 0);
@@ -257,10 +244,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs g) {
     // ---- prologue: three phases in flight, phase 0 landed for everybody, then stagger the groups ------------------
     issue(0);
     if (nph > 1) issue(1);
-    if (nph > 2) issue(2);
-    if (nph > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
-    else if (nph > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (D > 2 && nph > 2) issue(2);
+    {
+        const int infl = (nph < D ? nph : D) - 1;          // phases allowed to stay in flight behind phase 0
+        if (infl >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+        else if (infl == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if (grp == 1 && !(g.dbg & 8)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -269,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs g) {
     u32x4 af[TM][2], wf[TN][2];
     for (int ph = 0; ph < nph; ph++) {
         // ======== load segment ========
-        const char* sl = smem + (ph & 3) * SLOT;
+        const char* sl = smem + (ph % NS) * SLOT;
         if (!(dbg & 2) || ph == 0) {
 #pragma unroll
         for (int i = 0; i < TM; i++) {
@@ -285,13 +275,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs g) {
         // refill the slot phase ph-1 vacated (every wave finished reading it before the barrier that opened this segment)
         if (dbg & 1) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        } else if (ph + 3 < nph) {
-            issue(ph + 3);
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NPW) : "memory");     // phase ph+1 landed (this wave's pieces)
-        } else if (ph + 2 < nph) {
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPW) : "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (ph + D < nph) issue(ph + D);
+            // phase ph+1 must have landed (this wave's pieces); phases ph+2 .. min(ph+D, nph-1) may stay in flight
+            const int last = ph + D < nph - 1 ? ph + D : nph - 1;
+            const int infl = last - (ph + 1);
+            if (infl >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NPW) : "memory");
+            else if (infl == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
         if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -520,12 +511,12 @@ static int launch_pp128(const GemmArgs& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-template <int WM, int WN, int TM, int EPK>
+template <int WM, int WN, int TM, int EPK, int NS = 4>
 static int launch_pp_cfg(const GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * 64;
-    constexpr int smem = 4 * (BM + BN) * 64;
+    constexpr int smem = NS * (BM + BN) * 64;
     static bool attr_set = false;
-    auto kern = gemm_pp_kernel<WM, WN, TM, EPK>;
+    auto kern = gemm_pp_kernel<WM, WN, TM, EPK, NS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
@@ -565,6 +556,7 @@ static int epilogue_kind(const GemmArgs& g) {
 
 template <int EPK>
 static int launch_pp_any(const GemmArgs& g, bool wide, hipStream_t st) {
+    if (moge_tune_get("PP_NARROW", 0)) return launch_pp_cfg<4, 2, 2, EPK, 3>(g, st);       // 256x128 tiles, two workgroups per CU
     if (wide && (g.K & 63) == 0 && moge_tune_get("PP_ROW128", 1)) return launch_pp128<EPK>(g, st);
     return wide ? launch_pp_cfg<2, 4, 4, EPK>(g, st) : launch_pp_cfg<4, 2, 2, EPK>(g, st);
 }

@@ -166,6 +166,7 @@ static void build_tables(moge_handle* h) {
                 padd(h, name + S(".rs%d.wT", l), (int64_t)4 * co * ci);
                 padd(h, name + S(".rs%d.w3", l), (int64_t)co * 9 * co);
                 aadd(h, name + S(".rs%d.biasT", l), 4 * co);
+                if (!neck) aadd(h, name + S(".rs%d.bias_in", l), co);     // resampler conv bias + next level's input-block bias (fused path)
             } else {
                 tadd(h, name + S(".resamplers.%d.1.weight", l), (int64_t)co * ci * 9);
                 tadd(h, name + S(".resamplers.%d.1.bias", l), co);
@@ -247,6 +248,17 @@ static int build_aux(moge_handle* h, hipStream_t st) {
             const int co = c.dims[l + 1];
             LCHK(launch_repack<float>(M(h, name + S(".resamplers.%d.0.bias", l)), A(h, name + S(".rs%d.biasT", l)), 4, 1, 1, co, 0, 0, 0, 1, co, 0, 0, st));
         }
+        if (name != "neck")
+            for (int l = 0; l < 3; l++) {
+                const int co = c.dims[l + 1];
+                std::vector<float> a(co), b(co);
+                HIPCHK(hipMemcpyAsync(a.data(), M(h, name + S(".resamplers.%d.1.bias", l)), co * sizeof(float), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(b.data(), M(h, name + S(".input_blocks.%d.bias", l + 1)), co * sizeof(float), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                for (int i = 0; i < co; i++) a[i] += b[i];
+                HIPCHK(hipMemcpyAsync(A(h, name + S(".rs%d.bias_in", l)), a.data(), co * sizeof(float), hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+            }
         // level 3->4 (bilinear + 3x3 as a 4-phase conv): bias replicated per phase; the neck adds its level-4 input-block bias
         const float* b4 = name == "neck" ? A(h, "neck.rs3.bias2") : M(h, name + ".resamplers.3.1.bias");
         LCHK(launch_repack<float>(b4, A(h, name + ".rs3.bias4"), 4, 1, 1, c.dims[4], 0, 0, 0, 1, c.dims[4], 0, 0, st));
@@ -449,7 +461,7 @@ static int run_gemm(moge_handle* h, const GemmArgs& g, int amode, int cls, hipSt
 
 template <typename T>
 static int conv3x3(moge_handle* h, const T* in, const T* w, const float* bias, T* out, int B, int Hh, int Ww, int Cin, int Cout, int relu_in,
-                   int act, const T* add, const UVTerm* uv, hipStream_t st) {
+                   int act, const T* add, const UVTerm* uv, hipStream_t st, const T* side = nullptr, const T* side_w = nullptr, bool* fused = nullptr) {
     GemmArgs g = gemm_args();
     g.a = in; g.H = Hh; g.W = Ww; g.C = Cin; g.relu_in = relu_in;
     g.w = w; g.ldw = 9 * Cin;
@@ -457,6 +469,17 @@ static int conv3x3(moge_handle* h, const T* in, const T* w, const float* bias, T
     g.epi = EPI_STORE; g.act = act; g.bias = bias; g.out = out; g.ldc = Cout; g.add = add; g.ldadd = Cout;
     g.pixW = Ww; g.pixH = Hh;
     if (uv) g.uv = *uv;
+    if (fused) *fused = false;
+    if (side && std::is_same<T, f16>::value && Cin == Cout && moge_tune_get("CONV_PP", 1) && moge_tune_get("FUSE_IN", 1)) {
+        // fused 1x1 side input (x + in_l(neck_l), modules.py:245): only the halo kernel implements it; `bias` must already hold
+        // the sum of both biases (the caller passes the combined vector when *fused comes back true, see below)
+        GemmArgs g2 = g;
+        g2.a2 = side; g2.w2 = side_w;
+        if (conv_pp_eligible(g2)) {
+            *fused = true;
+            return run_gemm<T>(h, g2, AMODE_CONV3, MOGE_KC_CONV, st, 9.0 * Cin + Cin);
+        }
+    }
     return run_gemm<T>(h, g, AMODE_CONV3, MOGE_KC_CONV, st);
 }
 
@@ -668,10 +691,25 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
             const int Hh = rows << l, Ww = cols << l, ci = c.dims[l - 1], co = c.dims[l];
             const int a = (cur + 1) % 3, b2 = (cur + 2) % 3;
             int nxt;
+            bool in_fused = false;
             if (l <= 3) {
                 CHK(convT2<T>(h, Sc[cur], P<T>(h, name + S(".rs%d.wT", l - 1)), A(h, name + S(".rs%d.biasT", l - 1)), Sc[a], B, Hh / 2, Ww / 2, ci, co, st));
-                CHK(conv3x3<T>(h, Sc[a], P<T>(h, name + S(".rs%d.w3", l - 1)), M(h, name + S(".resamplers.%d.1.bias", l - 1)), Sc[b2], B, Hh, Ww, co, co, 0,
-                               ACT_NONE, nullptr, nullptr, st));
+                // resampler conv, with the head's `x + in_l(neck_l)` fused as a 1x1 side input when the halo kernel takes the shape
+                // (the first attempt passes the combined bias; if the shape is not eligible nothing ran and the plain form follows)
+                const bool try_fuse = std::is_same<T, f16>::value && moge_tune_get("FUSE_IN", 1) != 0 && moge_tune_get("CONV_PP", 1) != 0;
+                if (try_fuse) {
+                    GemmArgs probe = gemm_args();
+                    probe.a = Sc[a]; probe.H = Hh; probe.W = Ww; probe.C = co; probe.w = P<T>(h, name + S(".rs%d.w3", l - 1)); probe.ldw = 9 * co;
+                    probe.M = B * Hh * Ww; probe.N = co; probe.K = 9 * co; probe.epi = EPI_STORE; probe.bias = A(h, name + S(".rs%d.bias_in", l - 1));
+                    probe.out = Sc[b2]; probe.ldc = co; probe.a2 = N[l]; probe.w2 = P<T>(h, name + S(".in%d.w", l));
+                    if (conv_pp_eligible(probe)) {
+                        CHK(conv3x3<T>(h, Sc[a], P<T>(h, name + S(".rs%d.w3", l - 1)), A(h, name + S(".rs%d.bias_in", l - 1)), Sc[b2], B, Hh, Ww, co, co, 0,
+                                       ACT_NONE, nullptr, nullptr, st, N[l], P<T>(h, name + S(".in%d.w", l)), &in_fused));
+                    }
+                }
+                if (!in_fused)
+                    CHK(conv3x3<T>(h, Sc[a], P<T>(h, name + S(".rs%d.w3", l - 1)), M(h, name + S(".resamplers.%d.1.bias", l - 1)), Sc[b2], B, Hh, Ww, co, co, 0,
+                                   ACT_NONE, nullptr, nullptr, st));
                 nxt = b2;
             } else {
                 CHK(conv_up2_phase<T>(h, Sc[cur], P<T>(h, name + ".rs3.w3p"), A(h, name + ".rs3.bias4"), Sc[a], B, Hh / 2, Ww / 2, ci, co, nullptr, st));
@@ -679,7 +717,7 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
             }
             // x = x + in_l(neck_l)   (in place: each element is read and written by the same lane); at the last level of the fp16
             // path the input block is folded into the output conv of head_final_kernel (no residual blocks in between)
-            if (!(l == MOGE_LEVELS - 1 && fuse_l4))
+            if (!(l == MOGE_LEVELS - 1 && fuse_l4) && !in_fused)
                 CHK(conv1x1<T>(h, N[l], P<T>(h, name + S(".in%d.w", l)), M(h, name + S(".input_blocks.%d.bias", l)), Sc[nxt], (long)B * Hh * Ww, co, co, Sc[nxt],
                                nullptr, Ww, Hh, st));
             cur = nxt;

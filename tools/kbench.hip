@@ -149,6 +149,7 @@ static int bench_gemm(const char* filter, int iters) {
     };
     struct Variant { const char* name; int pp, glds, dbg, row128, stagger; };
     std::vector<Variant> variants = {{"old-glds2", 0, 2, 0, 0}, {"pp64", 1, 2, 0, 0}, {"pp128", 1, 2, 0, 1}};
+    if (getenv("KB_NARROW")) variants = {{"pp128", 1, 2, 0, 1, 0}, {"pp64-2wg", 1, 2, 0, 1, 100}};
     if (getenv("KB_STAGGER")) variants = {{"pp128", 1, 2, 0, 1, 0}, {"pp128-stg2", 1, 2, 0, 1, 2}, {"pp128-stg4", 1, 2, 0, 1, 4}, {"pp128-stg8", 1, 2, 0, 1, 8}};
     if (getenv("KB_ABLATE")) {
         variants = {{"pp128", 1, 2, 0, 1}, {"pp128-noact", 1, 2, 16, 1}, {"pp128-noepi", 1, 2, 32, 1}, {"pp128-nodma", 1, 2, 1, 1}, {"pp128-nolds", 1, 2, 2, 1}, {"pp128-nomfma", 1, 2, 4, 1},
@@ -204,7 +205,8 @@ static int bench_gemm(const char* filter, int iters) {
             moge_tune_set("GLDS_VARIANT", v.glds);
             moge_tune_set("PP_DBG", v.dbg);
             moge_tune_set("PP_ROW128", v.row128);
-            moge_tune_set("PP_STAGGER", v.stagger);
+            moge_tune_set("PP_STAGGER", v.stagger == 100 ? 0 : v.stagger);
+            moge_tune_set("PP_NARROW", v.stagger == 100 ? 1 : 0);
             // correctness: one launch on fresh buffers
             CK(hipMemsetAsync(out, 0, out_elems * 2, st));
             if (x) CK(hipMemcpyAsync(x, x0, M * N * 4, hipMemcpyDeviceToDevice, st));
@@ -378,20 +380,25 @@ __global__ void cmp_f16(const f16* a, const f16* b, size_t n, float* maxratio, i
 static int bench_conv(const char* filter, int iters) {
     hipStream_t st;
     CK(hipStreamCreate(&st));
-    struct Case { const char* name; int B, H, W, C, Cout; int convt, relu_in, act, add, uv; };
+    struct Case { const char* name; int B, H, W, C, Cout; int convt, relu_in, act, add, uv, side; };
     const Case cases[] = {
-        {"L3 res1 64->64 480", 32, 480, 480, 64, 64, 0, 1, ACT_RELU, 0, 0},
-        {"L3 res2 +add", 32, 480, 480, 64, 64, 0, 0, ACT_NONE, 1, 0},
-        {"L3 rs uv", 32, 480, 480, 64, 64, 0, 0, ACT_NONE, 0, 1},
-        {"up2 64->4x32 480", 32, 480, 480, 64, 32, 1, 0, ACT_NONE, 0, 0},
-        {"up2 uv", 32, 480, 480, 64, 32, 1, 0, ACT_NONE, 0, 1},
-        {"L2 128->128 240", 32, 240, 240, 128, 128, 0, 1, ACT_RELU, 0, 0},
-        {"L1 256->256 120", 32, 120, 120, 256, 256, 0, 0, ACT_NONE, 1, 0},
-        {"odd 64->64 50x37", 3, 50, 37, 64, 64, 0, 1, ACT_RELU, 0, 1},
-        {"odd 64->64 add 17x70", 3, 17, 70, 64, 64, 0, 0, ACT_NONE, 1, 1},
-        {"odd 128->128 21x40", 2, 21, 40, 128, 128, 0, 0, ACT_NONE, 0, 1},
-        {"odd up2 64 19x33", 2, 19, 33, 64, 32, 1, 0, ACT_NONE, 0, 1},
-        {"odd up2 128->4x64", 2, 19, 33, 128, 64, 1, 0, ACT_NONE, 0, 0},
+        {"L3 rs +side1x1", 32, 480, 480, 64, 64, 0, 0, ACT_NONE, 0, 0, 1},
+        {"L2 rs +side1x1", 32, 240, 240, 128, 128, 0, 0, ACT_NONE, 0, 0, 1},
+        {"L1 rs +side1x1", 32, 120, 120, 256, 256, 0, 0, ACT_NONE, 0, 0, 1},
+        {"odd side 64 23x45", 2, 23, 45, 64, 64, 0, 0, ACT_NONE, 0, 0, 1},
+        {"odd side 128 17x31", 2, 17, 31, 128, 128, 0, 0, ACT_NONE, 0, 0, 1},
+        {"L3 res1 64->64 480", 32, 480, 480, 64, 64, 0, 1, ACT_RELU, 0, 0, 0},
+        {"L3 res2 +add", 32, 480, 480, 64, 64, 0, 0, ACT_NONE, 1, 0, 0},
+        {"L3 rs uv", 32, 480, 480, 64, 64, 0, 0, ACT_NONE, 0, 1, 0},
+        {"up2 64->4x32 480", 32, 480, 480, 64, 32, 1, 0, ACT_NONE, 0, 0, 0},
+        {"up2 uv", 32, 480, 480, 64, 32, 1, 0, ACT_NONE, 0, 1, 0},
+        {"L2 128->128 240", 32, 240, 240, 128, 128, 0, 1, ACT_RELU, 0, 0, 0},
+        {"L1 256->256 120", 32, 120, 120, 256, 256, 0, 0, ACT_NONE, 1, 0, 0},
+        {"odd 64->64 50x37", 3, 50, 37, 64, 64, 0, 1, ACT_RELU, 0, 1, 0},
+        {"odd 64->64 add 17x70", 3, 17, 70, 64, 64, 0, 0, ACT_NONE, 1, 1, 0},
+        {"odd 128->128 21x40", 2, 21, 40, 128, 128, 0, 0, ACT_NONE, 0, 1, 0},
+        {"odd up2 64 19x33", 2, 19, 33, 64, 32, 1, 0, ACT_NONE, 0, 1, 0},
+        {"odd up2 128->4x64", 2, 19, 33, 128, 64, 1, 0, ACT_NONE, 0, 0, 0},
     };
     int fails = 0;
     for (const Case& c : cases) {
@@ -399,7 +406,12 @@ static int bench_conv(const char* filter, int iters) {
         const size_t px = (size_t)c.B * c.H * c.W;
         const int N = c.convt ? 4 * c.Cout : c.Cout, K = 9 * c.C;
         const size_t n_in = px * c.C, n_out = px * N, n_w = (size_t)N * K;
-        f16 *in, *w, *out0, *out1, *add; float *bias, *wu, *wv, *dmax; int* dbad;
+        f16 *in, *w, *out0, *out1, *add, *side = nullptr, *w2 = nullptr; float *bias, *wu, *wv, *dmax; int* dbad;
+        if (c.side) {
+            CK(hipMalloc(&side, px * c.C * 2)); CK(hipMalloc(&w2, (size_t)N * c.C * 2));
+            fill_f16<<<2048, 256, 0, st>>>(side, px * c.C, 27u, 1.0f);
+            fill_f16<<<256, 256, 0, st>>>(w2, (size_t)N * c.C, 28u, 0.1f);
+        }
         CK(hipMalloc(&in, n_in * 2)); CK(hipMalloc(&w, n_w * 2)); CK(hipMalloc(&out0, n_out * 2)); CK(hipMalloc(&out1, n_out * 2)); CK(hipMalloc(&add, n_out * 2));
         CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&wu, N * 4)); CK(hipMalloc(&wv, N * 4)); CK(hipMalloc(&dmax, 4)); CK(hipMalloc(&dbad, 4));
         fill_f16<<<2048, 256, 0, st>>>(in, n_in, 21u, 1.0f);
@@ -415,19 +427,33 @@ static int bench_conv(const char* filter, int iters) {
         if (c.uv) { g.uv.wu = wu; g.uv.wv = wv; g.uv.u0 = -0.7f; g.uv.u1 = 0.7f; g.uv.v0 = -0.6f; g.uv.v1 = 0.6f;
                     const int uw = c.convt ? 2 * c.W : c.W, uh = c.convt ? 2 * c.H : c.H; g.uv.ustep = 1.4f / (uw - 1); g.uv.vstep = 1.2f / (uh - 1); }
         double ms[2] = {0, 0};
+        GemmArgs gs; memset(&gs, 0, sizeof(gs));          // the separate 1x1 pass of the unfused reference: out0 += w2 . side
+        gs.a = side; gs.lda = c.C; gs.w = w2; gs.ldw = c.C; gs.M = (int)px; gs.N = N; gs.K = c.C; gs.epi = EPI_STORE; gs.out = out0; gs.ldc = N;
+        gs.add = out0; gs.ldadd = N;
         for (int v = 0; v < 2; v++) {
             moge_tune_set("CONV_PP", v);
             g.out = v ? out1 : out0;
+            g.a2 = (v && c.side) ? side : nullptr; g.w2 = (v && c.side) ? w2 : nullptr;
             CK(hipMemsetAsync(g.out, 0, n_out * 2, st));
             int rc = launch_gemm<f16>(g, AMODE_CONV3, st);
+            if (!rc && c.side && v == 0) { moge_tune_set("GEMM_PP", 0); rc = launch_gemm<f16>(gs, AMODE_LINEAR, st); moge_tune_set("GEMM_PP", 1); }
             if (rc) { printf("%s launch rc=%d\n", c.name, rc); fails++; break; }
             CK(hipStreamSynchronize(st));
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             launch_gemm<f16>(g, AMODE_CONV3, st);
             CK(hipEventRecord(e0, st));
-            for (int i = 0; i < iters; i++) launch_gemm<f16>(g, AMODE_CONV3, st);
+            for (int i = 0; i < iters; i++) {
+                launch_gemm<f16>(g, AMODE_CONV3, st);
+                if (c.side && v == 0) launch_gemm<f16>(gs, AMODE_LINEAR, st);        // timing only (accumulates into out0 after the check copy below)
+            }
             CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
             float t; CK(hipEventElapsedTime(&t, e0, e1)); ms[v] = t / iters;
+            if (c.side && v == 0) {        // restore the single-pass reference result
+                CK(hipMemsetAsync(out0, 0, n_out * 2, st));
+                launch_gemm<f16>(g, AMODE_CONV3, st);
+                moge_tune_set("GEMM_PP", 0); launch_gemm<f16>(gs, AMODE_LINEAR, st); moge_tune_set("GEMM_PP", 1);
+                CK(hipStreamSynchronize(st));
+            }
         }
         CK(hipMemsetAsync(dmax, 0, 4, st)); CK(hipMemsetAsync(dbad, 0, 4, st));
         cmp_f16<<<2048, 256, 0, st>>>(out1, out0, n_out, dmax, dbad);
@@ -439,6 +465,7 @@ static int bench_conv(const char* filter, int iters) {
                ms[1], fl / ms[1] / 1e9, hmax, hbad, n_out, hbad ? "FAIL" : "ok");
         fflush(stdout);
         if (hbad) fails++;
+        if (side) { CK(hipFree(side)); CK(hipFree(w2)); }
         CK(hipFree(in)); CK(hipFree(w)); CK(hipFree(out0)); CK(hipFree(out1)); CK(hipFree(add)); CK(hipFree(bias)); CK(hipFree(wu)); CK(hipFree(wv)); CK(hipFree(dmax)); CK(hipFree(dbad));
     }
     moge_tune_set("CONV_PP", 1);
