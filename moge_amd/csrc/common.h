@@ -108,6 +108,22 @@ __device__ __forceinline__ float gelu_fast(float x) {
     const float e = __builtin_amdgcn_exp2f(-(p * x));
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// two elements at a time: the polynomial runs on packed-fp32 VALU ops (v_pk_mul_f32 / v_pk_fma_f32), the two transcendentals
+// stay scalar.  Same operation sequence per element as gelu_fast (bit-identical results).
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    constexpr float L2E = 1.4426950408889634f;
+    const f32x2 x2 = x * x;
+    f32x2 p = {2.09755530e-06f * L2E, 2.09755530e-06f * L2E};
+    p = __builtin_elementwise_fma(p, x2, f32x2{-5.83663339e-05f * L2E, -5.83663339e-05f * L2E});
+    p = __builtin_elementwise_fma(p, x2, f32x2{-2.66659641e-04f * L2E, -2.66659641e-04f * L2E});
+    p = __builtin_elementwise_fma(p, x2, f32x2{7.29729188e-02f * L2E, 7.29729188e-02f * L2E});
+    p = __builtin_elementwise_fma(p, x2, f32x2{1.59563637f * L2E, 1.59563637f * L2E});
+    const f32x2 t = -(p * x);
+    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    const f32x2 d = e + f32x2{1.0f, 1.0f};
+    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return x * r;
+}
 // Epilogue arithmetic shared by gemm.hip and gemm_pp.hip, written with explicit fmaf so that both kernels round identically:
 // the fp16 path picks one or the other by problem size (latency regime), and a batch item must not depend on its batch.
 __device__ __forceinline__ float resid_term(float gamma, float acc, float bias) { return fmaf(gamma, acc, gamma * bias); }   // gamma*(acc+bias)

@@ -34,19 +34,23 @@ template <int TW> struct Halo {
 };
 
 __device__ __forceinline__ u32x4 relu8(u32x4 v) {
-    f16x8 h = __builtin_bit_cast(f16x8, v);
+    // one v_pk_max_f16 per dword (the C++ form compiles to pk_max + compare + select + permute: NaN canonicalisation)
 #pragma unroll
-    for (int i = 0; i < 8; i++) h[i] = h[i] > (f16)0 ? h[i] : (f16)0;
-    return __builtin_bit_cast(u32x4, h);
+    for (int i = 0; i < 4; i++) {
+        unsigned t = v[i];
+        asm("v_pk_max_f16 %0, %0, 0" : "+v"(t));
+        v[i] = t;
+    }
+    return v;
 }
 
 template <int N> __device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
 // BN = 128: waves 4 (pixels) x 2 (channels);  BN = 64: waves 8 x 1.  A wave owns TM = TW*16/32/WM tiles of 32 pixels x 64 channels.
-// NH = halo buffers (1: Cin == 64 and no side input);  EPI: bit 0 = uv term, bit 1 = pixel-shuffle (EPI_CONVT) store
+// NH = halo buffers (1: Cin == 64 and no side input);  EPI: bit 0 = uv term, bit 1 = pixel-shuffle (EPI_CONVT) store, bit 2 = ReLU on the input
 template <int BN, int TW, int NH, int EPI>
 __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) void conv_pp_kernel(const GemmArgs g) {
-    constexpr bool CONVT = (EPI & 2) != 0, HAS_UV = (EPI & 1) != 0;
+    constexpr bool CONVT = (EPI & 2) != 0, HAS_UV = (EPI & 1) != 0, RELU_IN = (EPI & 4) != 0;
     constexpr int WN = BN / 64, WM = 8 / WN, TM = TW * 16 / 32 / WM, TN = 2;
     constexpr int HALO_W = Halo<TW>::W, HALO_PX = Halo<TW>::PX, HALO_PIECES = Halo<TW>::PIECES, HALO_BYTES = Halo<TW>::BYTES, HPW = Halo<TW>::HPW;
     constexpr int LOG_TW = TW == 16 ? 4 : 5;
@@ -161,7 +165,6 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
-    const int relu_in = g.relu_in;
     const int ntot = nchunks + nside;                // halo images consumed: conv chunks, then side chunks
     // one K-step: fragments of (halo image, tap), weights of step kt; DMA for step kt+3 (+ the next halo image at the first step of
     // an image); counted wait; barrier; 16 / 8 MFMAs; barrier.  halo_age: steps since the last halo issue (its 6-10 pieces may
@@ -201,11 +204,13 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
             else wait_vm_lgkm<0>();
         }
         halo_age++;
-        if (relu) {
+        if constexpr (RELU_IN) {
+            if (relu) {             // compile-time for the conv taps (always), false for the side input
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+                for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int ks = 0; ks < 4; ks++) af[i][ks] = relu8(af[i][ks]);
+                    for (int ks = 0; ks < 4; ks++) af[i][ks] = relu8(af[i][ks]);
+            }
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     for (int c = 0; c < nchunks; c++) {
         const char* halo = smem + (c & (NH - 1)) * HALO_BYTES;
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) kstep(halo, tap / 3 - 1, tap % 3 - 1, tap == 0, c, relu_in != 0);
+        for (int tap = 0; tap < 9; tap++) kstep(halo, tap / 3 - 1, tap % 3 - 1, tap == 0, c, true);
     }
     for (int c2 = 0; c2 < nside; c2++) kstep(smem + ((nchunks + c2) & (NH - 1)) * HALO_BYTES, 0, 0, true, nchunks + c2, false);
 
@@ -344,6 +349,7 @@ bool conv_pp_eligible(const GemmArgs& g) {
     if (g.H < 1 || g.W < 1 || (long)g.M % ((long)g.H * g.W) != 0) return false;
     if ((long)g.H * g.W * g.C * 2 >= (1L << 31)) return false;                     // 32-bit halo offsets
     if (g.a2 && (!g.w2 || g.epi != EPI_STORE)) return false;
+    if (g.relu_in && (g.uv.wu || g.epi != EPI_STORE)) return false;
     if (g.epi == EPI_STORE)        // (the residual add is applied after the activation here: never combined by the decoder)
         return (g.ldc & 7) == 0 && (!g.add || ((g.ldadd & 7) == 0 && g.act == ACT_NONE)) && (!g.uv.wu || g.bias) && g.act != ACT_GELU;
     if (g.epi == EPI_CONVT) return !g.add && g.act == ACT_NONE && (g.Cout == 32 || (g.Cout & 63) == 0) && g.N == 4 * g.Cout;
@@ -352,12 +358,14 @@ bool conv_pp_eligible(const GemmArgs& g) {
 
 template <int BN, int TW, int NH>
 static int launch_conv_epi(const GemmArgs& g, hipStream_t st) {
-    const int e = (g.uv.wu ? 1 : 0) | (g.epi == EPI_CONVT ? 2 : 0);
+    const int e = (g.uv.wu ? 1 : 0) | (g.epi == EPI_CONVT ? 2 : 0) | (g.relu_in ? 4 : 0);
     switch (e) {
     case 0: return launch_conv_cfg<BN, TW, NH, 0>(g, st);
     case 1: return launch_conv_cfg<BN, TW, NH, 1>(g, st);
     case 2: return launch_conv_cfg<BN, TW, NH, 2>(g, st);
-    default: return launch_conv_cfg<BN, TW, NH, 3>(g, st);
+    case 3: return launch_conv_cfg<BN, TW, NH, 3>(g, st);
+    case 4: return launch_conv_cfg<BN, TW, NH, 4>(g, st);     // ReLU prologue: plain store only (residual blocks, modules.py:52,58)
+    default: return -1;
     }
 }
 

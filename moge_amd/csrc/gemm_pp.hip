@@ -115,8 +115,11 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM]
                         v[e] = acc[i][j][4 * q + e] + b[e];
                         if constexpr (EPK == EPK_QKV) v[e] *= scale;
                         if constexpr (EPK == EPK_UV) v[e] = uv_term_add(v[e], wu[e], u[i], wv[e], vv[i]);
-                        if constexpr (EPK == EPK_GELU) v[e] = gelu_fast(v[e]);
                         if constexpr (EPK == EPK_RELU) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if constexpr (EPK == EPK_GELU) {
+                        const f32x2 g0 = gelu_fast2(f32x2{v[0], v[1]}), g1 = gelu_fast2(f32x2{v[2], v[3]});
+                        v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
                     }
                     const f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                     *reinterpret_cast<f16x4*>(R + row * 128 + ((((j * 4 + q) ^ (row & 7)) << 4) | (hi << 3))) = hv;
