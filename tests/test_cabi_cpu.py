@@ -49,3 +49,24 @@ def test_create_rejects_bad_config_without_gpu():
     h = ctypes.c_void_p()
     assert L.lib.moge_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == -1
     assert b"unsupported ViT width" in L.lib.moge_last_error()
+
+
+def test_eval_plugin_exposes_the_reference_baseline_interface():
+    """baselines/moge_mi355x.py is loaded BY PATH by the reference's eval harness and must offer
+    Baseline.load (a click command), infer, infer_for_evaluation (moge/test/baseline.py:7-42)."""
+    import importlib.util
+    import os
+    import click
+    import torch
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "baselines", "moge_mi355x.py")
+    spec = importlib.util.spec_from_file_location("moge_mi355x_plugin", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    B = mod.Baseline
+    assert isinstance(B.load, click.Command)
+    names = {p.name for p in B.load.params}
+    assert {"num_tokens", "resolution_level", "pretrained_model_name_or_path", "use_fp16", "device"} <= names
+    assert callable(B.infer) and callable(B.infer_for_evaluation)
+    K = torch.tensor([[[0.8, 0.0, 0.5], [0.0, 1.1, 0.5], [0.0, 0.0, 1.0]]])
+    fov = mod._fov_x_degrees(K)
+    assert abs(float(fov) - float(torch.rad2deg(2 * torch.atan(torch.tensor(0.5 / 0.8))))) < 1e-5

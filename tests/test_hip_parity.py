@@ -193,3 +193,28 @@ def test_batch_split_streams_are_bit_identical(MoGeModel, tmp_path_factory):
     finally:
         L.tune("BATCH_SPLIT", 1)
         model.float()
+
+
+def test_eval_plugin_runs_through_the_click_loader(tmp_path_factory):
+    """the reference's harness does `Baseline.load.main(args, standalone_mode=False)` then
+    `infer_for_evaluation(image, intrinsics)` (moge/scripts/eval_baseline.py:40-42,65-71)."""
+    import importlib.util
+    from oracle import moge_oracle as O
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    cfg = O.named_configs()["tiny-vits-normal"]
+    sd = O.synth_state_dict(cfg, 0, True)
+    path = os.path.join(str(tmp_path_factory.mktemp("ckpt")), "model.pt")
+    O.save_checkpoint(path, cfg, sd)
+    plug = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "baselines", "moge_mi355x.py")
+    spec = importlib.util.spec_from_file_location("moge_mi355x_plugin", plug)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    base = mod.Baseline.load.main(["--pretrained", path, "--num_tokens", "108", "--device", "cuda:0"], standalone_mode=False)
+    x = torch.rand(3, 84, 112, generator=torch.Generator().manual_seed(5)).cuda()
+    K = torch.tensor([[0.9, 0.0, 0.5], [0.0, 1.2, 0.5], [0.0, 0.0, 1.0]], device="cuda")
+    out = base.infer_for_evaluation(x, K)
+    assert set(out) >= {"points_metric", "depth_metric", "intrinsics"}
+    ref = O.infer(cfg, sd, x.cpu(), num_tokens=108, fov_x=float(mod._fov_x_degrees(K.cpu())), apply_mask=False)
+    assert rel_err(out["depth_metric"].cpu().numpy(), ref["depth"].numpy()) < FP32_TOL
+    assert rel_err(out["intrinsics"].cpu().numpy(), ref["intrinsics"].numpy()) < FP32_TOL
