@@ -47,8 +47,10 @@ __device__ __forceinline__ u32x4 pack8(const f32x16& p, int s) {
 constexpr int AP_STAGE = 16384;          // K tile 8 KiB + V tile 8 KiB
 constexpr float AP_PSUM_LIMIT = 16384.f;
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_pp_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
+// QT = 32-query tiles per wave.  QT = 2: the two tiles are independent softmax chains inside one wave (the scheduler can put one
+// tile's MFMAs next to the other's exponentials) and share every K / V fragment read; 2 waves per SIMD instead of 3.
+template <int NW, int QT>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && QT == 1) ? 3 : 2) void attn_pp_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
                                                           f16* __restrict__ out, int Ntok, int nh) {
     constexpr int NPW = 16 / NW;                // DMA pieces (8 rows x 128 B) per wave per tile: K pieces then V pieces
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * AP_STAGE
@@ -58,15 +60,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_pp_kernel(const
     const int hi = lane >> 5, l31 = lane & 31;
     const int bh = blockIdx.y;
     const int b = bh / nh, head = bh - b * nh;
-    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
-    const int qrow = q0 + l31;
-    const int qld = qrow < Ntok ? qrow : Ntok - 1;
+    const int q0 = blockIdx.x * (NW * 32 * QT) + wave * 32 * QT;
 
     // ---- Q fragments (B-operand of S^T = K Q^T): lane = query, 8 d per half and k-step --------------------------------
-    const f16* qp = q + ((size_t)bh * Ntok + qld) * 64;
-    u32x4 qf[4];
+    u32x4 qf[QT][4];
 #pragma unroll
-    for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const u32x4*>(qp + (2 * s + hi) * 8);
+    for (int a = 0; a < QT; a++) {
+        const int qrow = q0 + a * 32 + l31;
+        const f16* qp = q + ((size_t)bh * Ntok + (qrow < Ntok ? qrow : Ntok - 1)) * 64;
+#pragma unroll
+        for (int s = 0; s < 4; s++) qf[a][s] = *reinterpret_cast<const u32x4*>(qp + (2 * s + hi) * 8);
+    }
 
     // ---- DMA sources: piece p of a tile = rows 8p..8p+7 of K (p < 8) or V (p >= 8) ------------------------------------
     const char* kbase = reinterpret_cast<const char*>(k + (size_t)bh * Ntok * 64);
@@ -124,15 +128,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_pp_kernel(const
 #pragma unroll
     for (int dt = 0; dt < 2; dt++) vaddr[dt] = 8192 + vrow * 128 + ((((dt << 2) | vch) ^ vsw) << 4) + (li & 1) * 8;
 
-    f32x16 o[2];
+    f32x16 o[QT][2];
+    float negm[QT];                     // -m, splat into the S^T accumulators before every K Q^T chain
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int a = 0; a < QT; a++) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) o[i][r] = 0.f;
-    f32x16 negm;
+        for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) negm[r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+            for (int r = 0; r < 16; r++) o[a][i][r] = 0.f;
+        negm[a] = 0.f;
+        m_run[a] = -1e30f; l_run[a] = 0.f;
+    }
 
     issue(0);
     if (ntiles > 1) issue(1);
@@ -155,85 +162,89 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_pp_kernel(const
         const bool last = t == ntiles - 1;
         const bool exact = (t == 0) | last;       // tiles that always take the exact path (first: m unknown; last: key mask)
 
-        f32x16 sc[2];
-        float psum = 0.f;
+        f32x16 sc[QT][2];
+        float psum[QT];
+        bool trig = false;
         if (!exact) {
-            // ---- fast path: S^T - m = K Q^T + (-m);  P = exp2(.)  (all eight K fragments are requested before the first
-            // MFMA: read -> wait -> MFMA pairs expose the LDS latency eight times per tile)
-            u32x4 kf[2][4];
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int s = 0; s < 4; s++) kf[h][s] = *reinterpret_cast<const u32x4*>(ka[s] + h * 4096);
-            sc[0] = negm;
-            sc[1] = negm;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                mma_step<f16>(sc[0], kf[0][s], qf[s]);
-                mma_step<f16>(sc[1], kf[1][s], qf[s]);
-            }
-            float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                sc[0][r] = __builtin_amdgcn_exp2f(sc[0][r]);
-                ps0 += sc[0][r];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                sc[1][r] = __builtin_amdgcn_exp2f(sc[1][r]);
-                ps1 += sc[1][r];
-            }
-            psum = ps0 + ps1;
-        }
-        if (exact || __any(!(psum < AP_PSUM_LIMIT))) {
-            // ---- exact path: raise m to the true running max, rescale O and l (first / last tile; rare otherwise) ------
+            // ---- fast path: S^T - m = K Q^T + (-m);  P = exp2(.)  (all eight K fragments are requested before the first MFMA) ----
 #pragma unroll
             for (int h = 0; h < 2; h++) {
+                u32x4 kf[4];
 #pragma unroll
-                for (int r = 0; r < 16; r++) sc[h][r] = 0.f;
+                for (int s = 0; s < 4; s++) kf[s] = *reinterpret_cast<const u32x4*>(ka[s] + h * 4096);
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const u32x4 kf = *reinterpret_cast<const u32x4*>(ka[s] + h * 4096);
-                    mma_step<f16>(sc[h], kf, qf[s]);
-                }
+                for (int a = 0; a < QT; a++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) sc[a][h][r] = negm[a];
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int a = 0; a < QT; a++) mma_step<f16>(sc[a][h], kf[s], qf[a][s]);
             }
-            if (last) {
+#pragma unroll
+            for (int a = 0; a < QT; a++) {
+                float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) { sc[a][0][r] = __builtin_amdgcn_exp2f(sc[a][0][r]); ps0 += sc[a][0][r]; }
+#pragma unroll
+                for (int r = 0; r < 16; r++) { sc[a][1][r] = __builtin_amdgcn_exp2f(sc[a][1][r]); ps1 += sc[a][1][r]; }
+                psum[a] = ps0 + ps1;
+                trig |= !(psum[a] < AP_PSUM_LIMIT);
+            }
+        }
+        if (exact || __any(trig)) {
+            // ---- exact path: raise m to the true running max, rescale O and l (first / last tile; rare otherwise) ------
+#pragma unroll
+            for (int a = 0; a < QT; a++) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) sc[a][h][r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const u32x4 kf = *reinterpret_cast<const u32x4*>(ka[s] + h * 4096);
+                        mma_step<f16>(sc[a][h], kf, qf[a][s]);
+                    }
+                }
+                if (last) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int i = acc_row(r, hi);
+                            const int key = t * 64 + h * 32 + ((i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1));
+                            if (key >= Ntok) sc[a][h][r] = -1e30f;
+                        }
+                }
+                float mx = sc[a][0][0];
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) mx = fmaxf(mx, sc[a][h][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run[a], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[a] - m_new);
+                m_run[a] = m_new;
+                l_run[a] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) o[a][i][r] *= alpha;
+                negm[a] = -m_new;
+                float ps = 0.f;
 #pragma unroll
                 for (int h = 0; h < 2; h++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const int i = acc_row(r, hi);
-                        const int key = t * 64 + h * 32 + ((i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1));
-                        if (key >= Ntok) sc[h][r] = -1e30f;
+                        sc[a][h][r] = __builtin_amdgcn_exp2f(sc[a][h][r] - m_new);
+                        ps += sc[a][h][r];
                     }
+                psum[a] = ps;
             }
-            float mx = sc[0][0];
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) mx = fmaxf(mx, sc[h][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[i][r] *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; r++) negm[r] = -m_new;
-            psum = 0.f;
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    sc[h][r] = __builtin_amdgcn_exp2f(sc[h][r] - m_new);
-                    psum += sc[h][r];
-                }
         }
-        l_run += psum;
-        // ---- O^T += V^T P^T  (the four V^T operands of a 32-key half are requested together) ---------------------------------
+#pragma unroll
+        for (int a = 0; a < QT; a++) l_run[a] += psum[a];
+        // ---- O^T += V^T P^T  (the four V^T operands of a 32-key half are requested together, shared by the query tiles) ----------
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             u32x4 vf[2][2];
@@ -245,36 +256,43 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_pp_kernel(const
                     vf[s][dt] = tr_pair(va[dt] + koff, va[dt] + koff + 4 * 128);
                 }
 #pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const u32x4 pf = pack8(sc[h], s);
+            for (int a = 0; a < QT; a++)
 #pragma unroll
-                for (int dt = 0; dt < 2; dt++) mma_step<f16>(o[dt], vf[s][dt], pf);
-            }
+                for (int s = 0; s < 2; s++) {
+                    const u32x4 pf = pack8(sc[a][h], s);
+#pragma unroll
+                    for (int dt = 0; dt < 2; dt++) mma_step<f16>(o[a][dt], vf[s][dt], pf);
+                }
         }
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.f / l_tot;
-    if (qrow < Ntok) {
-        f16* op = out + ((size_t)b * Ntok + qrow) * ((size_t)nh * 64) + head * 64;
 #pragma unroll
-        for (int dt = 0; dt < 2; dt++)
+    for (int a = 0; a < QT; a++) {
+        const float l_tot = l_run[a] + __shfl_xor(l_run[a], 32);
+        const float inv = 1.f / l_tot;
+        const int qrow = q0 + a * 32 + l31;
+        if (qrow < Ntok) {
+            f16* op = out + ((size_t)b * Ntok + qrow) * ((size_t)nh * 64) + head * 64;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; g4++)
-                store4(op + dt * 32 + 8 * g4 + 4 * hi, o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv, o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+            for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++)
+                    store4(op + dt * 32 + 8 * g4 + 4 * hi, o[a][dt][4 * g4] * inv, o[a][dt][4 * g4 + 1] * inv, o[a][dt][4 * g4 + 2] * inv,
+                           o[a][dt][4 * g4 + 3] * inv);
+        }
     }
 }
 
-template <int NW>
+template <int NW, int QT>
 static int launch_attn_pp_cfg(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
     constexpr int smem = 3 * AP_STAGE;
     static bool attr_set = false;
-    auto kern = attn_pp_kernel<NW>;
+    auto kern = attn_pp_kernel<NW, QT>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((Ntok + NW * 32 - 1) / (NW * 32), B * nh);
+    dim3 grid((Ntok + NW * 32 * QT - 1) / (NW * 32 * QT), B * nh);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
     return (int)hipGetLastError();
 }
@@ -282,6 +300,7 @@ static int launch_attn_pp_cfg(const void* q, const void* k, const void* v, void*
 // q, k, v: (B, nh, Ntok, 64) fp16 (q pre-scaled by log2(e)/8); out: (B, Ntok, nh*64) fp16
 int launch_attention_pp(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
     if (Ntok < 1) return -1;
-    if (moge_tune_get("ATTN_NW", 4) == 8) return launch_attn_pp_cfg<8>(q, k, v, out, B, nh, Ntok, st);
-    return launch_attn_pp_cfg<4>(q, k, v, out, B, nh, Ntok, st);
+    if (moge_tune_get("ATTN_QT", 1) == 2) return launch_attn_pp_cfg<4, 2>(q, k, v, out, B, nh, Ntok, st);
+    if (moge_tune_get("ATTN_NW", 4) == 8) return launch_attn_pp_cfg<8, 1>(q, k, v, out, B, nh, Ntok, st);
+    return launch_attn_pp_cfg<4, 1>(q, k, v, out, B, nh, Ntok, st);
 }
