@@ -95,7 +95,10 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
         int piece = wave + 8 * i;
         piece = piece < HALO_PIECES ? piece : HALO_PIECES - 1;
         int hp = piece * 8 + prow;
-        const int sw = (hp >> 1) & 7;                                   // swizzle follows the LDS pixel index, also for the padding pixels
+        // chunk swizzle by the halo COLUMN: sw = (hx >> 1) & 7.  A 16-lane ds_read_b128 group covers 16 consecutive columns (split over
+        // two image rows for the 16-wide tile); with an even row pitch the LDS half-row bit is hx & 1, so (hx & 1, (hx >> 1) & 7) = hx mod 16
+        // is distinct for every lane of the group at every tap shift: conflict-free (the linear-index swizzle was 2-way on 4 lanes)
+        const int sw = ((hp % HALO_W) >> 1) & 7;                        // padding pixels of the last piece: any consistent value
         hp = hp < HALO_PX ? hp : HALO_PX - 1;
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
         int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
@@ -137,11 +140,12 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
 
     // ---- fragment addressing ---------------------------------------------------------------------------------------
     // pixel of lane l31 in 32-pixel tile i of this wave: tile-linear index mp = wm*WROWS + i*32 + l31 -> (mp >> 4, mp & 15)
-    int hp0[TM];                          // halo pixel index of the CENTRE tap
+    int hp0[TM], hx0[TM];                 // halo pixel index / halo column of the CENTRE tap
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int mp = wm * WROWS + i * 32 + l31;
-        hp0[i] = ((mp >> LOG_TW) + 1) * HALO_W + (mp & (TW - 1)) + 1;
+        hx0[i] = (mp & (TW - 1)) + 1;
+        hp0[i] = ((mp >> LOG_TW) + 1) * HALO_W + hx0[i];
     }
     const int sxw = (l31 >> 1) & 7;
     const int w_off = (wn * 64 + l31) * 128 + ((hi ^ sxw) << 4);          // weight row (wn*64 + j*32 + l31); k-step ks: ^ (ks * 32)
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int hp = hp0[i] + dy * HALO_W + dx;
-            const int a0 = hp * 128 + ((hi ^ ((hp >> 1) & 7)) << 4);
+            const int a0 = hp * 128 + ((hi ^ (((hx0[i] + dx) >> 1) & 7)) << 4);
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) af[i][ks] = *reinterpret_cast<const u32x4*>(halo + (a0 ^ (ks * 32)));
         }
