@@ -325,10 +325,18 @@ __global__ __launch_bounds__(512, (TM == 2 && NS == 3) ? 4 : 2) void gemm_pp_ker
 // counted waits: vmcnt(8) after L_a (X2(t) = A_hi(t) landed), vmcnt(6) after L_b (X1(t+1) and the W half of X2(t+1)).
 // LDS: [parity][A 256 rows x 128 B | W 256 rows x 128 B], chunk swizzle c ^ ((row >> 1) & 7).
 // ------------------------------------------------------------------------------------------------------------------------
-template <int EPK>
+//
+// A3 = 1 (default): the A operand (activations: first touch comes from HBM / the Infinity Cache, ~2 us under load) gets a THREE-deep ring
+// and W (L2-resident) a two-deep one: 3 x 32 KiB + 2 x 32 KiB = all 160 KiB of LDS.  DMA issue order per wave
+//   prologue: W(0) A_lo(0) A_hi(0) A_lo(1) A_hi(1) W(1) A_lo(2)      L_a(t): A_hi(t+2)      L_b(t): W(t+2) A_lo(t+3)
+// so every A piece has two full K-tiles (four phases) to land and every W piece one full K-tile (the two-buffer order above gives
+// W pieces 2,3 a single phase).  The only counted wait is in L_b(t): everything up to W(t+1) has landed (vmcnt(10): A_lo(t+2), A_hi(t+2),
+// W(t+2), A_lo(t+3) may still be in flight); loads return in order, so A_lo(t+1) and A_hi(t+1) - issued earlier - are covered by it.
+// Measured with kbench (K = 4096, N = 1024): cache-resident A panel +12 %, no DMA at all +44 %: the main loop is latency-exposed.
+template <int EPK, int A3>
 __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
     constexpr int TM = 4, TN = 2, WN = 4, BM = 256, BN = 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 * 64 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 * 64 KiB, or 3 * 32 KiB (A ring) + 2 * 32 KiB (W ring)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
     const int nkt = g.K >> 6;
     const int dbg = g.dbg;
     unsigned long long* ts = (g.dbg_ts && blockIdx.x == 777 && lane == 0) ? g.dbg_ts + wave * 8 : nullptr;
-    if (ts) ts[0] = __builtin_amdgcn_s_memtime();
+    if (ts) { ts[0] = __builtin_amdgcn_s_memtime(); ts[5] = __builtin_readcyclecounter(); ts[6] = wall_clock64(); }
     // Phase stagger: every CU's first block starts delayed by a fraction of a tile's main-loop time, so that the epilogue
     // store / read-modify-write bursts of the CUs (all tiles take the same time) do not hit HBM at the same instant.
     if (g.stagger > 1 && blockIdx.x < 256) {
@@ -372,8 +380,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
     const int lchunk = (lane & 7) ^ (((wave & 1) << 2) + (lane >> 4));
     // uniform 64-bit tile bases (SGPRs) + per-lane 32-bit byte offsets: the DMA uses the saddr + voffset form and the
     // load segment carries no 64-bit VALU address arithmetic
-    const char* baseW = reinterpret_cast<const char*>(g.w) + (size_t)n0 * g.ldw * 2;
-    const char* baseA = reinterpret_cast<const char*>(g.a) + (size_t)m0 * g.lda * 2;
+    const char* baseW = reinterpret_cast<const char*>(g.w) + (size_t)((dbg & 128) ? 0 : n0) * g.ldw * 2;     // dbg 64 / 128: every tile reads
+    const char* baseA = reinterpret_cast<const char*>(g.a) + (size_t)((dbg & 64) ? 0 : m0) * g.lda * 2;      // panel 0 (cache-resident operand)
     unsigned offW[4], offA[4];     // A: 0,1 = lo rows (8w, 128+8w)   2,3 = hi rows (64+8w, 192+8w)
     const int mlast = g.M - 1 - m0;
 #pragma unroll
@@ -399,10 +407,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
             __builtin_amdgcn_global_load_lds(PP_GPTR(ga + offA[ka]), PP_LPTR(base + (k * 128 + second * 64 + wave * 8) * 128), 16, 0, 0);
         }
     };
+    // A3 layout: A slot s at s * 32 KiB (s = t mod 3), W buffer at 96 KiB + (t & 1) * 32 KiB
+    auto issue_w = [&](int t) {
+        char* base = smem + 98304 + (t & 1) * 32768;
+        const char* gw = uniform_ptr(baseW + (size_t)t * 128);
+#pragma unroll
+        for (int kw = 0; kw < 4; kw++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[kw]), PP_LPTR(base + (wave + 8 * kw) * 1024), 16, 0, 0);
+    };
+    auto issue_a = [&](int t, int slot, int hi_rows) {
+        char* base = smem + slot * 32768;
+        const char* ga = uniform_ptr(baseA + (size_t)t * 128);
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + offA[hi_rows * 2 + k]), PP_LPTR(base + (k * 128 + hi_rows * 64 + wave * 8) * 128), 16, 0, 0);
+    };
 
     const int sx = (l31 >> 1) & 7;
     const int a_off = (wm * 128 + l31) * 128 + ((hi ^ sx) << 4);             // k-step ks: a_off ^ (ks * 32)
-    const int w_off = 32768 + (wn * 64 + l31) * 128 + ((hi ^ sx) << 4);
+    const int w_off = (A3 ? 0 : 32768) + (wn * 64 + l31) * 128 + ((hi ^ sx) << 4);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -412,23 +434,126 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    issue(0, 0);
-    issue(0, 1);
-    if (nkt > 1) {
-        issue(1, 0);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (A3) {
+        issue_w(0); issue_a(0, 0, 0); issue_a(0, 0, 1);
+        if (nkt > 1) { issue_a(1, 1, 0); issue_a(1, 1, 1); issue_w(1); }
+        if (nkt > 2) {
+            issue_a(2, 2, 0);
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        } else if (nkt > 1) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     } else {
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        issue(0, 0);
+        issue(0, 1);
+        if (nkt > 1) {
+            issue(1, 0);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
     }
     __builtin_amdgcn_s_barrier();
+    u32x4 af[2][4], wf[TN][4];
+    if constexpr (A3 == 2) {                      // fragments of phase a(0): W(0), A_lo(0)
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+            for (int j = 0; j < TN; j++) wf[j][ks] = *reinterpret_cast<const u32x4*>(smem + 98304 + (w_off ^ (ks * 32)) + j * 4096);
+#pragma unroll
+            for (int i = 0; i < 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(smem + (a_off ^ (ks * 32)) + i * 4096);
+        }
+    }
     if (grp == 1 && !(dbg & 8)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
     if (ts) ts[1] = __builtin_amdgcn_s_memtime();
-    u32x4 af[2][4], wf[TN][4];
+    int sa = 0;                                   // t mod 3 (A3)
+    if constexpr (A3 == 2) {
+        // Fragment reads live in the COMPUTE segments: the registers of K-step ks are reloaded right after the four MFMAs that used them
+        // (phase a: A_hi(t) for phase b; phase b: W(t+1), A_lo(t+1) for the next phase a), so the LDS traffic is spread evenly, its latency is
+        // covered by the remaining MFMAs and the "load" segment is only DMA issue + counted wait + barrier.  Segment clock (one barrier
+        // interval each): group 0 runs L_a(t) C_a(t) L_b(t) C_b(t) in intervals 4t .. 4t+3, group 1 one interval later.  W(t+1) / A_lo(t+1) are
+        // read from interval 4t+3 on, so EVERY wave confirms its pieces of them before the barrier that ends interval 4t+2: group 0 in
+        // L_b(t) (vmcnt(10): A_lo(t+2) A_hi(t+2) W(t+2) A_lo(t+3) may be in flight), group 1 at the end of C_a(t) (vmcnt(4): A_lo(t+2) A_hi(t+2)).
+        // Ring slots are rewritten only after the barrier that follows the lgkmcnt(0) of their last reader (see the issue points).
+        for (int t = 0; t < nkt; t++) {
+            const char* sl = smem + sa * 32768;
+            const int sn = sa == 2 ? 0 : sa + 1;
+            const char* sl_n = smem + sn * 32768;                                          // A slot of K-tile t+1
+            const char* slw_n = smem + 98304 + ((t + 1) & 1) * 32768;                      // W buffer of K-tile t+1
+            const int sa2 = sa == 0 ? 2 : sa - 1;                                          // (t + 2) mod 3
+            // ======== L_a ========
+            if (t + 2 < nkt) issue_a(t + 2, sa2, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // ======== C_a ========
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) mma_step<f16>(acc[i][j], wf[j][ks], af[i][ks]);
+#pragma unroll
+                for (int i = 0; i < 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 32)) + (2 + i) * 4096);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (grp == 1) {
+                if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // ======== L_b ========
+            if (t + 3 < nkt) {
+                issue_w(t + 2);
+                issue_a(t + 3, sa, 0);
+                if (grp == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            } else if (t + 2 < nkt) {
+                issue_w(t + 2);
+                if (grp == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // ======== C_b ========
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) mma_step<f16>(acc[2 + i][j], wf[j][ks], af[i][ks]);
+#pragma unroll
+                for (int j = 0; j < TN; j++) wf[j][ks] = *reinterpret_cast<const u32x4*>(slw_n + (w_off ^ (ks * 32)) + j * 4096);
+#pragma unroll
+                for (int i = 0; i < 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl_n + (a_off ^ (ks * 32)) + i * 4096);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("" ::: "memory");
+            if (!(grp == 1 && t == nkt - 1)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            sa = sn;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the (unused) fragment reads of the last phase b
+    } else
     for (int t = 0; t < nkt; t++) {
-        const char* sl = smem + (t & 1) * 65536;
+        const char* sl = A3 ? smem + sa * 32768 : smem + (t & 1) * 65536;                  // A rows of this K-tile
+        const char* slw = A3 ? smem + 98304 + (t & 1) * 32768 : sl;                        // W rows
+        const int sa2 = sa == 0 ? 2 : sa - 1;                                              // (t + 2) mod 3
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             // ======== load segment ========
@@ -437,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < TN; j++)
 #pragma unroll
-                        for (int ks = 0; ks < 4; ks++) wf[j][ks] = *reinterpret_cast<const u32x4*>(sl + (w_off ^ (ks * 32)) + j * 4096);
+                        for (int ks = 0; ks < 4; ks++) wf[j][ks] = *reinterpret_cast<const u32x4*>(slw + (w_off ^ (ks * 32)) + j * 4096);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; i++)
@@ -446,6 +571,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
             }
             if (dbg & 1) {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            } else if (A3) {
+                if (half == 0) {
+                    if (t + 2 < nkt) issue_a(t + 2, sa2, 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
+                    if (t + 3 < nkt) {
+                        issue_w(t + 2);
+                        issue_a(t + 3, sa, 0);
+                        asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+                    } else if (t + 2 < nkt) {
+                        issue_w(t + 2);
+                        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    }
+                }
             } else if (half == 0) {
                 if (t + 1 < nkt) {
                     issue(t + 1, 1);
@@ -482,6 +623,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
+        sa = sa == 2 ? 0 : sa + 1;
     }
     if (ts) ts[2] = __builtin_amdgcn_s_memtime();
     if (dbg & 32) {          // ablation: no epilogue (keep the accumulators alive)
@@ -496,14 +638,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
         ts[3] = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts[4] = __builtin_amdgcn_s_memtime();
+        ts[7] = wall_clock64();                                  // constant 100 MHz: (ts[4] - ts[0]) / (ts[7] - ts[6]) * 100 = shader clock in MHz
     }
 }
 
-template <int EPK>
-static int launch_pp128(const GemmArgs& g, hipStream_t st) {
-    constexpr int smem = 2 * 65536;
+template <int EPK, int A3>
+static int launch_pp128_cfg(const GemmArgs& g, hipStream_t st) {
+    constexpr int smem = A3 ? 163840 : 2 * 65536;
     static bool attr_set = false;
-    auto kern = gemm_pp128_kernel<EPK>;
+    auto kern = gemm_pp128_kernel<EPK, A3>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
@@ -512,6 +655,11 @@ static int launch_pp128(const GemmArgs& g, hipStream_t st) {
     const long nbm = (g.M + 255) / 256, nbn = g.N / 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(512), smem, st, g);
     return (int)hipGetLastError();
+}
+template <int EPK>
+static int launch_pp128(const GemmArgs& g, hipStream_t st) {
+    const int a3 = moge_tune_get("PP_A3", 1);
+    return a3 == 2 ? launch_pp128_cfg<EPK, 2>(g, st) : a3 ? launch_pp128_cfg<EPK, 1>(g, st) : launch_pp128_cfg<EPK, 0>(g, st);
 }
 
 template <int WM, int WN, int TM, int EPK, int NS = 4>

@@ -140,6 +140,8 @@ static int bench_gemm(const char* filter, int iters) {
         {"vits.qkv", 8 * Ntok, 1152, 384, EPI_QKV, ACT_NONE, 384, 6, Ntok, 0, 0, 0, 0},
         {"vits.fc2", 8 * Ntok, 384, 1536, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"tailM", 700, 1024, 1024, EPI_STORE, ACT_GELU, 0, 0, 0, 0, 0, 0, 0},
+        {"sq8192", 8192, 8192, 8192, EPI_STORE, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
+        {"fc1plain", B * Ntok, 4096, 1024, EPI_STORE, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"b1.qkv", Ntok, 3072, 1024, EPI_QKV, ACT_NONE, 1024, 16, Ntok, 0, 0, 0, 0},
         {"b1.proj", Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"b1.fc1", Ntok, 4096, 1024, EPI_STORE, ACT_GELU, 0, 0, 0, 0, 0, 0, 0},
@@ -147,13 +149,16 @@ static int bench_gemm(const char* filter, int iters) {
         {"b4.proj", 4 * Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"b4.fc2", 4 * Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
     };
-    struct Variant { const char* name; int pp, glds, dbg, row128, stagger; };
+    struct Variant { const char* name; int pp, glds, dbg, row128, stagger; int a3 = 1; };
     std::vector<Variant> variants = {{"old-glds2", 0, 2, 0, 0}, {"pp64", 1, 2, 0, 0}, {"pp128", 1, 2, 0, 1}};
+    if (getenv("KB_A3")) variants = {{"pp128-2buf", 1, 2, 0, 1, 0, 0}, {"pp128-a3", 1, 2, 0, 1, 0, 1}, {"pp128-a3c", 1, 2, 0, 1, 0, 2}};
     if (getenv("KB_NARROW")) variants = {{"pp128", 1, 2, 0, 1, 0}, {"pp64-2wg", 1, 2, 0, 1, 100}};
     if (getenv("KB_STAGGER")) variants = {{"pp128", 1, 2, 0, 1, 0}, {"pp128-stg2", 1, 2, 0, 1, 2}, {"pp128-stg4", 1, 2, 0, 1, 4}, {"pp128-stg8", 1, 2, 0, 1, 8}};
     if (getenv("KB_ABLATE")) {
         variants = {{"pp128", 1, 2, 0, 1}, {"pp128-noact", 1, 2, 16, 1}, {"pp128-noepi", 1, 2, 32, 1}, {"pp128-nodma", 1, 2, 1, 1}, {"pp128-nolds", 1, 2, 2, 1}, {"pp128-nomfma", 1, 2, 4, 1},
-                    {"pp128-nobar", 1, 2, 8, 1}, {"pp128-mfmaonly", 1, 2, 11, 1}};
+                    {"pp128-nobar", 1, 2, 8, 1}, {"pp128-mfmaonly", 1, 2, 11, 1}, {"pp128-A0", 1, 2, 64, 1}, {"pp128-W0", 1, 2, 128, 1}, {"pp128-A0W0", 1, 2, 192, 1}};
+        if (getenv("KB_ABLATE")[0] == '2') variants = {{"pp128", 1, 2, 0, 1}, {"pp128-A0", 1, 2, 64, 1}, {"pp128-W0", 1, 2, 128, 1}, {"pp128-A0W0", 1, 2, 192, 1}, {"pp128-nodma", 1, 2, 1, 1}};
+        if (getenv("KB_ABLATE")[0] == '3') variants = {{"pp128-2buf", 1, 2, 0, 1, 0, 0}, {"pp128-2buf-A0W0", 1, 2, 192, 1, 0, 0}, {"pp128-2buf-nodma", 1, 2, 1, 1, 0, 0}, {"pp128-2buf-mfmaonly", 1, 2, 11, 1, 0, 0}, {"pp128-a3", 1, 2, 0, 1, 0, 1}};
     }
     int fails = 0;
     for (const Shape& s : shapes) {
@@ -207,6 +212,7 @@ static int bench_gemm(const char* filter, int iters) {
             moge_tune_set("PP_ROW128", v.row128);
             moge_tune_set("PP_STAGGER", v.stagger == 100 ? 0 : v.stagger);
             moge_tune_set("PP_NARROW", v.stagger == 100 ? 1 : 0);
+            moge_tune_set("PP_A3", v.a3);
             // correctness: one launch on fresh buffers
             CK(hipMemsetAsync(out, 0, out_elems * 2, st));
             if (x) CK(hipMemcpyAsync(x, x0, M * N * 4, hipMemcpyDeviceToDevice, st));
@@ -224,8 +230,9 @@ static int bench_gemm(const char* filter, int iters) {
                 launch_gemm<f16>(g2, AMODE_LINEAR, st);
                 unsigned long long hts[64]; CK(hipMemcpyAsync(hts, dts, 64 * 8, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
                 for (int w = 0; w < 8; w += 4)
-                    printf("   ts wave %d: prologue %llu  mainloop %llu  epilogue-issue %llu  store-drain %llu  (memtime ticks)\n", w, hts[w * 8 + 1] - hts[w * 8],
-                           hts[w * 8 + 2] - hts[w * 8 + 1], hts[w * 8 + 3] - hts[w * 8 + 2], hts[w * 8 + 4] - hts[w * 8 + 3]);
+                    printf("   ts wave %d: prologue %llu  mainloop %llu  epilogue-issue %llu  store-drain %llu  (memtime ticks)  clock %.0f MHz\n", w, hts[w * 8 + 1] - hts[w * 8],
+                           hts[w * 8 + 2] - hts[w * 8 + 1], hts[w * 8 + 3] - hts[w * 8 + 2], hts[w * 8 + 4] - hts[w * 8 + 3],
+                           100.0 * (double)(hts[w * 8 + 4] - hts[w * 8]) / (double)(hts[w * 8 + 7] - hts[w * 8 + 6]));
                 CK(hipFree(dts));
             }
             const double ms = time_launches(g, iters, st);
