@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && QT == 1) ? 3 : 2) void attn_pp
     for (int dt = 0; dt < 2; dt++) vaddr[dt] = 8192 + vrow * 128 + ((((dt << 2) | vch) ^ vsw) << 4) + (li & 1) * 8;
 
     f32x16 o[QT][2];
-    float negm[QT];                     // -m, splat into the S^T accumulators before every K Q^T chain
+    f32x16 negs[QT];                    // -m splat: the C operand of the first MFMA of every K Q^T chain (changes only when m does)
     float m_run[QT], l_run[QT];
 #pragma unroll
     for (int a = 0; a < QT; a++) {
@@ -137,7 +137,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && QT == 1) ? 3 : 2) void attn_pp
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int r = 0; r < 16; r++) o[a][i][r] = 0.f;
-        negm[a] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) negs[a][r] = 0.f;
         m_run[a] = -1e30f; l_run[a] = 0.f;
     }
 
@@ -172,12 +173,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && QT == 1) ? 3 : 2) void attn_pp
                 u32x4 kf[4];
 #pragma unroll
                 for (int s = 0; s < 4; s++) kf[s] = *reinterpret_cast<const u32x4*>(ka[s] + h * 4096);
+                // first MFMA of the chain reads its C operand from the resident -m splat (srcC != vDst): no per-tile accumulator init
 #pragma unroll
                 for (int a = 0; a < QT; a++)
+                    sc[a][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf[0]), __builtin_bit_cast(f16x8, qf[a][0]), negs[a], 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 16; r++) sc[a][h][r] = negm[a];
-#pragma unroll
-                for (int s = 0; s < 4; s++)
+                for (int s = 1; s < 4; s++)
 #pragma unroll
                     for (int a = 0; a < QT; a++) mma_step<f16>(sc[a][h], kf[s], qf[a][s]);
             }
@@ -230,7 +231,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && QT == 1) ? 3 : 2) void attn_pp
                 for (int i = 0; i < 2; i++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) o[a][i][r] *= alpha;
-                negm[a] = -m_new;
+#pragma unroll
+                for (int r = 0; r < 16; r++) negs[a][r] = -m_new;
                 float ps = 0.f;
 #pragma unroll
                 for (int h = 0; h < 2; h++)
