@@ -44,6 +44,16 @@ __device__ __forceinline__ void mma_step<float>(f32x16& acc, const u32x4& a, con
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], acc, 0, 0, 0);
 }
 
+// v_mfma_f32_16x16x32_f16: A rows / B columns = lane & 15, K group (8 halves) = lane >> 4; D: column = lane & 15, rows 4*(lane >> 4) + r.
+// Measured on this chip (tools/mfma_power.cpp, random operands): bare chains of this instruction sustain 1.90 PFLOP/s at 1.94 GHz,
+// the 32x32x16 form 1.43-1.62 at 1.66 GHz - the chip clocks to its power budget and the 16x16 form is the cheaper one per FLOP.
+template <typename T>
+__device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b);
+template <>
+__device__ __forceinline__ void mma16<f16>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+
 // row of the 32x32 accumulator tile held in register r by a lane of half `hi`
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

@@ -33,19 +33,112 @@
 // ~1000 register copies and ~100 branches per wave (measured 13-45k cycles per tile against a 43k-cycle K=1024 main loop).
 enum { EPK_RESID = 0, EPK_STORE = 1, EPK_GELU = 2, EPK_QKV = 3, EPK_CONVT = 4, EPK_UV = 5, EPK_RELU = 6 };
 
+// ---- stage 2: LDS staging region (row-major, 128 B per row, 16-byte chunks XOR-swizzled by row & 7) -> global memory ----
+template <int WROWS>
+__device__ __forceinline__ void pp_resid_rows(const GemmArgs& g, const char* R, int lane, int mw, int ncol) {
+    // read-modify-write of 32 fp32 columns in full 128-byte row segments; all loads of a pass are issued before the first add
+    const int rr = lane >> 3, cc = lane & 7;
+    const int M = g.M;
+    float* const xres = g.xres;
+    const long ldc = g.ldc;
+    f32x4 xv[WROWS / 8];
+#pragma unroll
+    for (int it = 0; it < WROWS / 8; it++) {
+        const int m = mw + it * 8 + rr;
+        const int mc = m < M ? m : M - 1;
+        xv[it] = *reinterpret_cast<const f32x4*>(xres + (size_t)mc * ldc + ncol + cc * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < WROWS / 8; it++) {
+        const int row = it * 8 + rr;
+        const int m = mw + row;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
+        if (m < M) *reinterpret_cast<f32x4*>(xres + (size_t)m * ldc + ncol + cc * 4) = xv[it] + v;
+    }
+}
+
+template <int WROWS, int EPK>
+__device__ __forceinline__ void pp_store_rows(const GemmArgs& g, const char* R, int lane, int mw, int nw) {
+    // 64 f16 columns per row, 16-byte stores; row base pointers of the three store flavours advance by rows of 8 per iteration
+    const int rr = lane >> 3, cc = lane & 7;
+    const int M = g.M;
+    const int mfirst = mw + rr;
+    if constexpr (EPK == EPK_QKV) {
+        const int which = nw / g.D;
+        const int head = (nw - which * g.D) >> 6;
+        const int Ntok = g.Ntok;
+        f16* obase = reinterpret_cast<f16*>(which == 0 ? g.q : (which == 1 ? g.k : g.vT)) + (size_t)head * Ntok * 64 + cc * 8;
+        const size_t bstride = (size_t)g.nh * Ntok * 64;
+        int b0 = mfirst / Ntok;
+        int t0 = mfirst - b0 * Ntok;
+#pragma unroll
+        for (int it = 0; it < WROWS / 8; it++) {
+            const int row = it * 8 + rr;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
+            f16* p = obase + (size_t)b0 * bstride + (size_t)t0 * 64;
+            t0 += 8;
+            if (t0 >= Ntok) { t0 -= Ntok; b0 += 1; }
+            if (mw + row < M) *reinterpret_cast<u32x4*>(p) = v;
+        }
+    } else if constexpr (EPK == EPK_CONVT) {
+        const int Cout = g.Cout, pixW = g.pixW, pixH = g.pixH;
+        const int qd = nw / Cout;
+        const int co0 = nw - qd * Cout, dy = qd >> 1, dx = qd & 1;
+        f16* obase = reinterpret_cast<f16*>(g.out) + co0 + cc * 8;
+        int px = mfirst % pixW;
+        const int t = mfirst / pixW;
+        int py = t % pixH, pb = t / pixH;
+#pragma unroll
+        for (int it = 0; it < WROWS / 8; it++) {
+            const int row = it * 8 + rr;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
+            f16* p = obase + ((((size_t)pb * 2 * pixH + 2 * py + dy) * (2 * pixW)) + 2 * px + dx) * Cout;
+            px += 8;
+            if (px >= pixW) { px -= pixW; py += 1; if (py >= pixH) { py = 0; pb += 1; } }
+            if (mw + row < M) *reinterpret_cast<u32x4*>(p) = v;
+        }
+    } else {
+        f16* obase = reinterpret_cast<f16*>(g.out) + nw + cc * 8;
+        const long ldc = g.ldc;
+#pragma unroll
+        for (int it = 0; it < WROWS / 8; it++) {
+            const int row = it * 8 + rr;
+            const int m = mw + row;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
+            if (m < M) *reinterpret_cast<u32x4*>(obase + (size_t)m * ldc) = v;
+        }
+    }
+}
+
+// the per-quad arithmetic shared by both accumulator layouts: 4 consecutive columns n .. n+3 of one output row
+template <int EPK>
+__device__ __forceinline__ f16x4 pp_quad_f16(const f32x4& a, const f32x4& b, float scale, const f32x4& wu, float u, const f32x4& wv, float vv) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        v[e] = a[e] + b[e];
+        if constexpr (EPK == EPK_QKV) v[e] *= scale;
+        if constexpr (EPK == EPK_UV) v[e] = uv_term_add(v[e], wu[e], u, wv[e], vv);
+        if constexpr (EPK == EPK_RELU) v[e] = fmaxf(v[e], 0.f);
+    }
+    if constexpr (EPK == EPK_GELU) {
+        const f32x2 g0 = gelu_fast2(f32x2{v[0], v[1]}), g1 = gelu_fast2(f32x2{v[2], v[3]});
+        v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+    }
+    return f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+}
+
+// ---- 32x32x16 accumulators: tile (i, j), register quad q: row i*32 + (lane & 31), columns j*32 + 8q + 4*(lane >> 5) .. +3 ----
 template <int TM, int EPK>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][2], char* smem, int wave, int lane, int mw, int nw) {
     constexpr int TN = 2;
     constexpr int WROWS = TM * 32;
     const int hi = lane >> 5, l31 = lane & 31;
     char* R = smem + wave * (WROWS * 128);
-    const int rr = lane >> 3, cc = lane & 7;
     const int M = g.M;
 
     if constexpr (EPK == EPK_RESID) {
         // x[m][n] += gamma[n] * (acc + bias[n])  on the fp32 residual stream (block.py:111-112, layer_scale.py:27)
-        float* const xres = g.xres;
-        const long ldc = g.ldc;
 #pragma unroll
         for (int j = 0; j < TN; j++) {
 #pragma unroll
@@ -62,27 +155,15 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM]
                     *reinterpret_cast<f32x4*>(R + row * 128 + (((2 * q + hi) ^ (row & 7)) << 4)) = v;
                 }
             }
-            // read-modify-write in full 128-byte row segments; all loads of a pass are issued before the first add
-            f32x4 xv[WROWS / 8];
-#pragma unroll
-            for (int it = 0; it < WROWS / 8; it++) {
-                const int m = mw + it * 8 + rr;
-                const int mc = m < M ? m : M - 1;
-                xv[it] = *reinterpret_cast<const f32x4*>(xres + (size_t)mc * ldc + nw + j * 32 + cc * 4);
-            }
-#pragma unroll
-            for (int it = 0; it < WROWS / 8; it++) {
-                const int row = it * 8 + rr;
-                const int m = mw + row;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
-                if (m < M) *reinterpret_cast<f32x4*>(xres + (size_t)m * ldc + nw + j * 32 + cc * 4) = xv[it] + v;
-            }
+            pp_resid_rows<WROWS>(g, R, lane, mw, nw + j * 32);
         }
     } else {
         // bias (+ uv rank-2 term) (+ q scale) (+ activation) in registers, pack to f16, transpose through LDS, 16-byte row stores
         float scale = 1.f;
         if constexpr (EPK == EPK_QKV) scale = nw < g.D ? g.qscale : 1.f;
         float u[TM], vv[TM];
+#pragma unroll
+        for (int i = 0; i < TM; i++) { u[i] = 0.f; vv[i] = 0.f; }
         if constexpr (EPK == EPK_UV) {
 #pragma unroll
             for (int i = 0; i < TM; i++) {
@@ -109,69 +190,77 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM]
 #pragma unroll
                 for (int i = 0; i < TM; i++) {
                     const int row = i * 32 + l31;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        v[e] = acc[i][j][4 * q + e] + b[e];
-                        if constexpr (EPK == EPK_QKV) v[e] *= scale;
-                        if constexpr (EPK == EPK_UV) v[e] = uv_term_add(v[e], wu[e], u[i], wv[e], vv[i]);
-                        if constexpr (EPK == EPK_RELU) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    if constexpr (EPK == EPK_GELU) {
-                        const f32x2 g0 = gelu_fast2(f32x2{v[0], v[1]}), g1 = gelu_fast2(f32x2{v[2], v[3]});
-                        v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
-                    }
-                    const f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                    const f32x4 a = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    const f16x4 hv = pp_quad_f16<EPK>(a, b, scale, wu, u[i], wv, vv[i]);
                     *reinterpret_cast<f16x4*>(R + row * 128 + ((((j * 4 + q) ^ (row & 7)) << 4) | (hi << 3))) = hv;
                 }
             }
-        // ---- row base pointers of the three store flavours (all advance by rows of 8 per iteration) -----------------
-        const int mfirst = mw + rr;
-        if constexpr (EPK == EPK_QKV) {
-            const int which = nw / g.D;
-            const int head = (nw - which * g.D) >> 6;
-            const int Ntok = g.Ntok;
-            f16* obase = reinterpret_cast<f16*>(which == 0 ? g.q : (which == 1 ? g.k : g.vT)) + (size_t)head * Ntok * 64 + cc * 8;
-            const size_t bstride = (size_t)g.nh * Ntok * 64;
-            int b0 = mfirst / Ntok;
-            int t0 = mfirst - b0 * Ntok;
+        pp_store_rows<WROWS, EPK>(g, R, lane, mw, nw);
+    }
+}
+
+// ---- 16x16x32 accumulators acc[i][j0 + jj] (128 rows x 64 columns of the wave's tile): row i*16 + (lane & 15), columns jj*16 + 4*(lane >> 4) .. +3 ----
+template <int EPK>
+__device__ __forceinline__ void pp_epilogue16(const GemmArgs& g, f32x4 (&acc)[8][8], int j0, char* smem, int wave, int lane, int mw, int nw) {
+    constexpr int WROWS = 128;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    char* R = smem + wave * (WROWS * 128);
+    const int M = g.M;
+
+    if constexpr (EPK == EPK_RESID) {
 #pragma unroll
-            for (int it = 0; it < WROWS / 8; it++) {
-                const int row = it * 8 + rr;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
-                f16* p = obase + (size_t)b0 * bstride + (size_t)t0 * 64;
-                t0 += 8;
-                if (t0 >= Ntok) { t0 -= Ntok; b0 += 1; }
-                if (mw + row < M) *reinterpret_cast<u32x4*>(p) = v;
+        for (int J = 0; J < 2; J++) {                       // 32 fp32 columns = 128 B per staging row
+#pragma unroll
+            for (int jh = 0; jh < 2; jh++) {
+                const int n = nw + J * 32 + jh * 16 + 4 * g4;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int row = i * 16 + l15;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = resid_term(gm[e], acc[i][j0 + J * 2 + jh][e], b[e]);
+                    *reinterpret_cast<f32x4*>(R + row * 128 + (((jh * 4 + g4) ^ (row & 7)) << 4)) = v;
+                }
             }
-        } else if constexpr (EPK == EPK_CONVT) {
-            const int Cout = g.Cout, pixW = g.pixW, pixH = g.pixH;
-            const int qd = nw / Cout;
-            const int co0 = nw - qd * Cout, dy = qd >> 1, dx = qd & 1;
-            f16* obase = reinterpret_cast<f16*>(g.out) + co0 + cc * 8;
-            int px = mfirst % pixW;
-            const int t = mfirst / pixW;
-            int py = t % pixH, pb = t / pixH;
+            pp_resid_rows<WROWS>(g, R, lane, mw, nw + J * 32);
+        }
+    } else {
+        float scale = 1.f;
+        if constexpr (EPK == EPK_QKV) scale = nw < g.D ? g.qscale : 1.f;
+        float u[8], vv[8];
 #pragma unroll
-            for (int it = 0; it < WROWS / 8; it++) {
-                const int row = it * 8 + rr;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
-                f16* p = obase + ((((size_t)pb * 2 * pixH + 2 * py + dy) * (2 * pixW)) + 2 * px + dx) * Cout;
-                px += 8;
-                if (px >= pixW) { px -= pixW; py += 1; if (py >= pixH) { py = 0; pb += 1; } }
-                if (mw + row < M) *reinterpret_cast<u32x4*>(p) = v;
-            }
-        } else {
-            f16* obase = reinterpret_cast<f16*>(g.out) + nw + cc * 8;
-            const long ldc = g.ldc;
+        for (int i = 0; i < 8; i++) { u[i] = 0.f; vv[i] = 0.f; }
+        if constexpr (EPK == EPK_UV) {
 #pragma unroll
-            for (int it = 0; it < WROWS / 8; it++) {
-                const int row = it * 8 + rr;
-                const int m = mw + row;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
-                if (m < M) *reinterpret_cast<u32x4*>(obase + (size_t)m * ldc) = v;
+            for (int i = 0; i < 8; i++) {
+                int m = mw + i * 16 + l15;
+                m = m < M ? m : M - 1;
+                const int x = m % g.pixW, y = (m / g.pixW) % g.pixH;
+                u[i] = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, g.pixW, x);
+                vv[i] = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, g.pixH, y);
             }
         }
+        const bool has_bias = g.bias != nullptr;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int n = nw + jj * 16 + 4 * g4;
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (has_bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+            f32x4 wu = {0.f, 0.f, 0.f, 0.f}, wv = wu;
+            if constexpr (EPK == EPK_UV) {
+                wu = *reinterpret_cast<const f32x4*>(g.uv.wu + n);
+                wv = *reinterpret_cast<const f32x4*>(g.uv.wv + n);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int row = i * 16 + l15;
+                const f16x4 hv = pp_quad_f16<EPK>(acc[i][j0 + jj], b, scale, wu, u[i], wv, vv[i]);
+                *reinterpret_cast<f16x4*>(R + row * 128 + ((((jj * 2 + (g4 >> 1)) ^ (row & 7)) << 4) | ((g4 & 1) << 3))) = hv;
+            }
+        }
+        pp_store_rows<WROWS, EPK>(g, R, lane, mw, nw);
     }
 }
 
@@ -642,6 +731,329 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, FOUR waves (one per SIMD), 128 x 128 per wave: 16 accumulator tiles = 256 registers, W fragments of a whole
+// K-tile (4 column blocks x 4 K-steps = 64 registers) + one row half of A (32) resident.  Against the 8-wave kernel above: one
+// third less LDS fragment traffic per MFMA (each A fragment feeds 4 MFMAs, each W fragment 4), half the wave-instruction issue
+// for the DMA, no partner wave - the fragment reloads and the DMA issue sit BETWEEN the MFMAs of the same wave:
+//   C_a(t): rows 0-63 of the wave (blocks i = 0,1): per K-step ks 8 MFMAs, then reload af[.][ks] <- A_hi(t), then 4 DMA pieces
+//   C_b(t): rows 64-127:                            per K-step ks 8 MFMAs, then reload wf[.][ks] <- W(t+1), af[.][ks] <- A_lo(t+1)
+// and ONE synchronisation point per K-tile, where the fragments read during C_b(t-1) are needed anyway:
+//   L(t): lgkmcnt(0); vmcnt(8) = everything up to W(t+1) has landed (A_hi(t+1), A_lo(t+2) may be in flight); s_barrier
+// after which W(t)'s buffer, A_lo(t) and A_hi(t-1) are dead in every wave and receive W(t+2), A_lo(t+3), A_hi(t+2) (issued during
+// C_a(t)): A pieces have two K-tiles to land, W pieces one.  LDS: A ring 3 x 32 KiB (slot = t mod 3), W ring 2 x 32 KiB.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int EPK>
+__global__ __launch_bounds__(256, 1) void gemm_pp4w_kernel(const GemmArgs g) {
+    constexpr int BM = 256, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 160 KiB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nbn = g.N / BN;
+    int wg;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    int bm, bn;
+    {
+        const int nbm = (g.M + BM - 1) / BM;
+        const int grp_cols = 4, per_grp = nbm * grp_cols;
+        const int cg = wg / per_grp, rem = wg - cg * per_grp;
+        const int cols = min(grp_cols, nbn - cg * grp_cols);
+        bm = rem / cols;
+        bn = cg * grp_cols + (rem - bm * cols);
+    }
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int nkt = g.K >> 6;
+
+    // DMA pieces (8 rows x 128 B).  W: rows (wave + 4 kw) * 8, kw = 0..7.  A lo / hi (k = 0..3): rows (k >> 1) * 128 [+ 64] + (k & 1) * 32 + wave * 8.
+    // All piece bases are multiples of 8 with (base >> 1) & 7 = 4 * (wave & 1): one swizzle term per lane.
+    const int prow = lane >> 3;
+    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) + (lane >> 4));
+    const char* baseW = reinterpret_cast<const char*>(g.w) + (size_t)n0 * g.ldw * 2;
+    const char* baseA = reinterpret_cast<const char*>(g.a) + (size_t)m0 * g.lda * 2;
+    unsigned offW[8], offAlo[4], offAhi[4];
+    const int mlast = g.M - 1 - m0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) offW[k] = (unsigned)(((wave + 4 * k) * 8 + prow) * g.ldw * 2 + lchunk * 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int r0 = (k >> 1) * 128 + (k & 1) * 32 + wave * 8 + prow, r1 = r0 + 64;
+        r0 = r0 < mlast ? r0 : mlast;
+        r1 = r1 < mlast ? r1 : mlast;
+        offAlo[k] = (unsigned)(r0 * g.lda * 2 + lchunk * 16);
+        offAhi[k] = (unsigned)(r1 * g.lda * 2 + lchunk * 16);
+    }
+    auto issue_w = [&](int t, int k0) {           // 4 of the 8 W pieces of K-tile t
+        char* base = smem + 98304 + (t & 1) * 32768;
+        const char* gw = uniform_ptr(baseW + (size_t)t * 128);
+#pragma unroll
+        for (int k = k0; k < k0 + 4; k++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[k]), PP_LPTR(base + (wave + 4 * k) * 1024), 16, 0, 0);
+    };
+    auto issue_a = [&](int t, int slot, int hi_rows) {
+        char* base = smem + slot * 32768 + hi_rows * 8192;
+        const char* ga = uniform_ptr(baseA + (size_t)t * 128);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + (hi_rows ? offAhi[k] : offAlo[k])), PP_LPTR(base + ((k >> 1) * 128 + (k & 1) * 32 + wave * 8) * 128), 16, 0, 0);
+    };
+
+    const int sx = (l31 >> 1) & 7;
+    const int a_off = (wm * 128 + l31) * 128 + ((hi ^ sx) << 4);             // K-step ks: a_off ^ (ks * 32); 32-row block i: + i * 4096
+    const int w_off = (wn * 128 + l31) * 128 + ((hi ^ sx) << 4);
+
+    f32x16 accL[4][2], accR[4][2];               // columns 0-63 / 64-127 of the wave's 128 (the epilogue takes 64-column halves)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { accL[i][j][r] = 0.f; accR[i][j][r] = 0.f; }
+
+    // prologue: the issue order continues the steady-state queue  L(s): W(s+2) A_hi(s+2) A_lo(s+3)
+    issue_a(0, 0, 0); issue_w(0, 0); issue_w(0, 4); issue_a(0, 0, 1);
+    if (nkt > 1) { issue_a(1, 1, 0); issue_w(1, 0); issue_w(1, 4); issue_a(1, 1, 1); }
+    if (nkt > 2) issue_a(2, 2, 0);
+    if (nkt > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");          // A_lo(0), W(0) landed
+    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    u32x4 af[2][4], wf[4][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) wf[j][ks] = *reinterpret_cast<const u32x4*>(smem + 98304 + (w_off ^ (ks * 32)) + j * 4096);
+#pragma unroll
+        for (int i = 0; i < 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(smem + (a_off ^ (ks * 32)) + i * 4096);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    int sa = 0;                                   // t mod 3
+    for (int t = 0; t < nkt; t++) {
+        const char* sl = smem + sa * 32768;
+        const int sn = sa == 2 ? 0 : sa + 1;
+        const int sa2 = sa == 0 ? 2 : sa - 1;                                              // (t + 2) mod 3
+        const char* sl_n = smem + sn * 32768;
+        const char* slw_n = smem + 98304 + ((t + 1) & 1) * 32768;
+        // ======== L(t) ========
+        if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ======== C_a(t) ========
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) mma_step<f16>(accL[i][j], wf[j][ks], af[i][ks]);
+#pragma unroll
+                for (int j = 0; j < 2; j++) mma_step<f16>(accR[i][j], wf[2 + j][ks], af[i][ks]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 32)) + (2 + i) * 4096);
+            if (ks < 2) { if (t + 2 < nkt) issue_w(t + 2, ks * 4); }
+            else if (ks == 2) { if (t + 2 < nkt) issue_a(t + 2, sa2, 1); }
+            else { if (t + 3 < nkt) issue_a(t + 3, sa, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ======== C_b(t) ========
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) mma_step<f16>(accL[2 + i][j], wf[j][ks], af[i][ks]);
+#pragma unroll
+                for (int j = 0; j < 2; j++) mma_step<f16>(accR[2 + i][j], wf[2 + j][ks], af[i][ks]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) wf[j][ks] = *reinterpret_cast<const u32x4*>(slw_n + (w_off ^ (ks * 32)) + j * 4096);
+#pragma unroll
+            for (int i = 0; i < 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl_n + (a_off ^ (ks * 32)) + i * 4096);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sa = sn;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the (unused) fragment reads of the last C_b
+    __builtin_amdgcn_s_barrier();                            // every wave is done with the rings: private epilogue regions
+    asm volatile("" ::: "memory");
+    pp_epilogue<4, EPK>(g, accL, smem, wave, lane, m0 + wm * 128, n0 + wn * 128);
+    pp_epilogue<4, EPK>(g, accR, smem, wave, lane, m0 + wm * 128, n0 + wn * 128 + 64);
+}
+
+template <int EPK>
+__global__ __launch_bounds__(256, 1) void gemm_pp4w16_kernel(const GemmArgs g) {
+    constexpr int BM = 256, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 160 KiB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nbn = g.N / BN;
+    int wg;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    int bm, bn;
+    {
+        const int nbm = (g.M + BM - 1) / BM;
+        const int grp_cols = 4, per_grp = nbm * grp_cols;
+        const int cg = wg / per_grp, rem = wg - cg * per_grp;
+        const int cols = min(grp_cols, nbn - cg * grp_cols);
+        bm = rem / cols;
+        bn = cg * grp_cols + (rem - bm * cols);
+    }
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int nkt = g.K >> 6;
+
+    // DMA pieces (8 rows x 128 B).  W: rows (wave + 4 kw) * 8, kw = 0..7.  A lo / hi (k = 0..3): rows (k >> 1) * 128 [+ 64] + (k & 1) * 32 + wave * 8.
+    // All piece bases are multiples of 8 with (base >> 1) & 7 = 4 * (wave & 1): one swizzle term per lane.
+    const int prow = lane >> 3;
+    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) + (lane >> 4));
+    const char* baseW = reinterpret_cast<const char*>(g.w) + (size_t)n0 * g.ldw * 2;
+    const char* baseA = reinterpret_cast<const char*>(g.a) + (size_t)m0 * g.lda * 2;
+    unsigned offW[8], offAlo[4], offAhi[4];
+    const int mlast = g.M - 1 - m0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) offW[k] = (unsigned)(((wave + 4 * k) * 8 + prow) * g.ldw * 2 + lchunk * 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int r0 = (k >> 1) * 128 + (k & 1) * 32 + wave * 8 + prow, r1 = r0 + 64;
+        r0 = r0 < mlast ? r0 : mlast;
+        r1 = r1 < mlast ? r1 : mlast;
+        offAlo[k] = (unsigned)(r0 * g.lda * 2 + lchunk * 16);
+        offAhi[k] = (unsigned)(r1 * g.lda * 2 + lchunk * 16);
+    }
+    auto issue_w = [&](int t, int k0) {           // 4 of the 8 W pieces of K-tile t
+        char* base = smem + 98304 + (t & 1) * 32768;
+        const char* gw = uniform_ptr(baseW + (size_t)t * 128);
+#pragma unroll
+        for (int k = k0; k < k0 + 4; k++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[k]), PP_LPTR(base + (wave + 4 * k) * 1024), 16, 0, 0);
+    };
+    auto issue_a = [&](int t, int slot, int hi_rows) {
+        char* base = smem + slot * 32768 + hi_rows * 8192;
+        const char* ga = uniform_ptr(baseA + (size_t)t * 128);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + (hi_rows ? offAhi[k] : offAlo[k])), PP_LPTR(base + ((k >> 1) * 128 + (k & 1) * 32 + wave * 8) * 128), 16, 0, 0);
+    };
+
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int sx = (l15 >> 1) & 7;
+    const int a_off = (wm * 128 + l15) * 128 + ((g4 ^ sx) << 4);             // K-step k2 (32 halves): a_off ^ (k2 * 64); 16-row block i: + i * 2048
+    const int w_off = (wn * 128 + l15) * 128 + ((g4 ^ sx) << 4);
+
+    f32x4 acc[8][8];                             // [16-row block][16-column block] of the wave's 128 x 128
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: the issue order continues the steady-state queue  L(s): W(s+2) A_hi(s+2) A_lo(s+3)
+    issue_a(0, 0, 0); issue_w(0, 0); issue_w(0, 4); issue_a(0, 0, 1);
+    if (nkt > 1) { issue_a(1, 1, 0); issue_w(1, 0); issue_w(1, 4); issue_a(1, 1, 1); }
+    if (nkt > 2) issue_a(2, 2, 0);
+    if (nkt > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");          // A_lo(0), W(0) landed
+    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    u32x4 af[4][2], wf[8][2];                    // [16-row block][K-step of 32]
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) wf[j][ks] = *reinterpret_cast<const u32x4*>(smem + 98304 + (w_off ^ (ks * 64)) + j * 2048);
+#pragma unroll
+        for (int i = 0; i < 4; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(smem + (a_off ^ (ks * 64)) + i * 2048);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    int sa = 0;                                   // t mod 3
+    for (int t = 0; t < nkt; t++) {
+        const char* sl = smem + sa * 32768;
+        const int sn = sa == 2 ? 0 : sa + 1;
+        const int sa2 = sa == 0 ? 2 : sa - 1;                                              // (t + 2) mod 3
+        const char* sl_n = smem + sn * 32768;
+        const char* slw_n = smem + 98304 + ((t + 1) & 1) * 32768;
+        // ======== L(t) ========
+        if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ======== C_a(t) ========
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+            for (int ih = 0; ih < 2; ih++) {                 // two 16-row blocks at a time: 16 MFMAs, then their A registers are reloaded
+#pragma unroll
+                for (int i = 2 * ih; i < 2 * ih + 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) mma16<f16>(acc[i][j], wf[j][ks], af[i][ks]);
+#pragma unroll
+                for (int i = 2 * ih; i < 2 * ih + 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 64)) + (4 + i) * 2048);
+                const int c = ks * 2 + ih;
+                if (c < 2) { if (t + 2 < nkt) issue_w(t + 2, c * 4); }
+                else if (c == 2) { if (t + 2 < nkt) issue_a(t + 2, sa2, 1); }
+                else { if (t + 3 < nkt) issue_a(t + 3, sa, 0); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ======== C_b(t) ========
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+            for (int ih = 0; ih < 2; ih++) {
+#pragma unroll
+                for (int i = 2 * ih; i < 2 * ih + 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) mma16<f16>(acc[4 + i][j], wf[j][ks], af[i][ks]);
+#pragma unroll
+                for (int i = 2 * ih; i < 2 * ih + 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl_n + (a_off ^ (ks * 64)) + i * 2048);
+                if (ih == 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) wf[j][ks] = *reinterpret_cast<const u32x4*>(slw_n + (w_off ^ (ks * 64)) + j * 2048);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        sa = sn;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the (unused) fragment reads of the last C_b
+    __builtin_amdgcn_s_barrier();                            // every wave is done with the rings: private epilogue regions
+    asm volatile("" ::: "memory");
+    pp_epilogue16<EPK>(g, acc, 0, smem, wave, lane, m0 + wm * 128, n0 + wn * 128);
+    pp_epilogue16<EPK>(g, acc, 4, smem, wave, lane, m0 + wm * 128, n0 + wn * 128 + 64);
+}
+
+template <int EPK, int MF16>
+static int launch_pp4w(const GemmArgs& g, hipStream_t st) {
+    constexpr int smem = 163840;
+    static bool attr_set = false;
+    auto kern = MF16 ? gemm_pp4w16_kernel<EPK> : gemm_pp4w_kernel<EPK>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long nbm = (g.M + 255) / 256, nbn = g.N / 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(256), smem, st, g);
+    return (int)hipGetLastError();
+}
+
 template <int EPK, int A3>
 static int launch_pp128_cfg(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = A3 ? 163840 : 2 * 65536;
@@ -658,6 +1070,9 @@ static int launch_pp128_cfg(const GemmArgs& g, hipStream_t st) {
 }
 template <int EPK>
 static int launch_pp128(const GemmArgs& g, hipStream_t st) {
+    const int w4 = moge_tune_get("PP_4W", 0);
+    if (w4 == 2) return launch_pp4w<EPK, 1>(g, st);
+    if (w4) return launch_pp4w<EPK, 0>(g, st);
     const int a3 = moge_tune_get("PP_A3", 1);
     return a3 == 2 ? launch_pp128_cfg<EPK, 2>(g, st) : a3 ? launch_pp128_cfg<EPK, 1>(g, st) : launch_pp128_cfg<EPK, 0>(g, st);
 }
