@@ -83,6 +83,7 @@ def main():
     model.half()
 
     B = args.batch
+    default_workload = (args.batch == BATCH_PER_GPU and args.config == WORKLOAD_CONFIG and args.num_tokens is None and args.shape == f"{IMG}x{IMG}")
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     if args.shape == "mixed":
         xs = [torch.rand(B // 2, 3, 518, 1036, generator=g).to(dev), torch.rand(B - B // 2, 3, 1036, 518, generator=g).to(dev)]
@@ -163,7 +164,17 @@ def main():
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp128_kernel (ViT qkv/proj/fc1/fc2 + out-proj ping-pong MFMA GEMMs)",
                                "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4),
-                               "traffic": None, "avg_launch_ms": round(gm["ms"] / max(gm["launches"], 1), 4), "launches": gm["launches"]}
+                               "traffic": None, "avg_launch_ms": round(gm["ms"] / max(gm["launches"], 1), 4), "launches": gm["launches"],
+                               "algorithmic_bytes_per_launch": round(gm["bytes"] / max(gm["launches"], 1))}
+            # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (they cannot be collected inside this process);
+            # the committed summary applies to the default workload only and names its source
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "moge_amd", "pmc_traffic.json")
+            if default_workload and os.path.exists(tpath):
+                with open(tpath) as f:
+                    tj = json.load(f)
+                res["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
+                res["roofline"]["traffic_unit"] = "bytes per launch (fabric reads x2-corrected + writes)"
+                res["roofline"]["traffic_source"] = tj["source"]
             tot_ms = sum(v["ms"] for v in prof.values())
             tot_fl = sum(v["flops"] for v in prof.values())
             res["kernel_classes"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),

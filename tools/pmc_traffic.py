@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_pmc_FETCH_SIZE.csv + profiles/<tag>_pmc_WRITE_SIZE.csv -> moge_amd/pmc_traffic.json (bench.py's roofline.traffic).
+
+Usage: python tools/pmc_traffic.py r01c          (after tools/profile_round.sh <tag> on the GPU box and copying the summaries)
+Per launch of the roofline kernel class (gemm_pp128_kernel, full-size launches only): KiB -> bytes, FETCH_SIZE doubled
+(gfx950 tallies 128-byte requests at 64 B: MI355X_MICROARCH.md, HBM section), WRITE_SIZE as reported.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(path):
+    d = {}
+    for ln in open(path).read().strip().splitlines()[1:]:
+        p = ln.rsplit(",", 4)                       # kernel names may contain commas
+        d[(p[0], int(p[1]))] = (int(p[2]), float(p[4]))
+    return d
+
+
+def main(tag):
+    F = load(os.path.join(ROOT, "profiles", f"{tag}_pmc_FETCH_SIZE.csv"))
+    W = load(os.path.join(ROOT, "profiles", f"{tag}_pmc_WRITE_SIZE.csv"))
+    calls = fb = wb = 0
+    for k, (c, f) in F.items():
+        if "gemm_pp128" in k[0] and k[1] >= 1000 and k in W:
+            calls += c
+            fb += c * f * 1024 * 2
+            wb += c * W[k][1] * 1024
+    out = {
+        "kernel": "gemm_pp128_kernel", "launches": calls,
+        "fetch_bytes_per_launch": round(fb / calls), "write_bytes_per_launch": round(wb / calls),
+        "traffic_bytes_per_launch": round((fb + wb) / calls),
+        "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs, --kernel-trace only) of `python bench.py --steps 3 "
+                  f"--warmup 1` with MOGE_BATCH_SPLIT=0; profiles/{tag}_pmc_FETCH_SIZE.csv + profiles/{tag}_pmc_WRITE_SIZE.csv; KiB -> bytes; "
+                  "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); Infinity-Cache hits are "
+                  "counted, so this is fabric traffic = an upper bound on HBM bytes",
+    }
+    with open(os.path.join(ROOT, "moge_amd", "pmc_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01c")
