@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--shape", default=f"{IMG}x{IMG}", help="HxW of the synthetic images; 'mixed' = half 518x1036, half 1036x518 "
                                                            "(BASELINE configs[4]: two same-shape sub-batches per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pipeline leg and the blob load-time comparison")
     ap.add_argument("--no-profile", action="store_true", help="disable the per-kernel HIP-event profiler")
     args = ap.parse_args()
 
@@ -188,6 +189,37 @@ def main():
                                  "note": "kernel classes / roofline: HIP events on the launch stream over K single-stream steps run "
                                          "right after the timed region (same inputs); the timed region runs the production path "
                                          "(two half-batch streams, no events)"}
+        if world == 1 and not args.no_pcie and args.shape != "mixed":
+            # PCIe-inclusive rate of the caller-side pipeline (never `value`): uint8 host batches in, all maps back to pinned host memory,
+            # transfers of neighbouring batches overlapped with the kernels (moge_amd/pipeline.py); also the load-time comparison of the
+            # packed master blob against the .pt checkpoint
+            import numpy as np
+            from moge_amd.pipeline import InferPipeline
+            hh, ww = x.shape[-2:]
+            u8 = (x.float().cpu().permute(0, 2, 3, 1) * 255).round().clamp(0, 255).to(torch.uint8).numpy()
+            pipe = InferPipeline(model, B, hh, ww, use_fp16=True, **({"num_tokens": num_tokens} if args.num_tokens else {}))
+            nb = 6
+            for _ in pipe.run(iter([u8] * 2), copy=False):
+                pass
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in pipe.run(iter([u8] * nb), copy=False):
+                pass
+            dtp = time.perf_counter() - t1
+            res["pcie_inclusive"] = {"value": round(nb * B / dtp, 3), "unit": "images/s", "batches": nb,
+                                     "note": "host uint8 (B,H,W,3) -> pinned -> H2D -> infer_uint8 -> D2H of points/depth/mask/intrinsics(/normal) into "
+                                             "pinned memory, 2 batches in flight (moge_amd/pipeline.py); not `value`"}
+            del pipe
+            with tempfile.TemporaryDirectory() as td:
+                ckpt, blob = os.path.join(td, "model.pt"), os.path.join(td, "model.blob")
+                O.save_checkpoint(ckpt, cfg, sd)
+                model.save_blob(blob)
+                t1 = time.perf_counter(); m_pt = MoGeModel.from_pretrained(ckpt).to(dev); torch.cuda.synchronize(); t_pt = time.perf_counter() - t1
+                del m_pt
+                t1 = time.perf_counter(); m_bl = MoGeModel.from_blob(blob).to(dev); torch.cuda.synchronize(); t_bl = time.perf_counter() - t1
+                del m_bl
+            res["load_seconds"] = {"checkpoint_pt": round(t_pt, 3), "master_blob": round(t_bl, 3),
+                                   "note": "from_pretrained(.pt) vs from_blob(packed fp32 master blob) to a ready fp32 model on the device, page cache warm"}
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample: ONE image of the same workload through the CPU oracle (fp32), all host threads
             xc = x[:1].float().cpu()

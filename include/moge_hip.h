@@ -129,7 +129,9 @@ int moge_set_precision(moge_handle* h, int precision, void* stream);
 int moge_workspace_bytes(moge_handle* h, int B, int H, int W, int token_rows, int token_cols, size_t* bytes);
 
 /* replaces MoGeModel.forward (v2.py:138-192).  image: device, (B,3,H,W), fp32 (img_dtype 0) or fp16 (1),
- * values in [0,1].  token_rows/cols = base_h/base_w computed by the host exactly as v2.py:142-147.
+ * values in [0,1]; or img_dtype 2: uint8 (B,H,W,3) as decoded from a file - the library then does the caller's
+ * `image / 255` + HWC->CHW + cast to the model dtype (scripts/infer.py:98, v2.py:229) on the device (4x / 2x less
+ * PCIe traffic than uploading floats).  token_rows/cols = base_h/base_w computed by the host exactly as v2.py:142-147.
  * Writes points (remapped), normal (unit), mask_prob, metric_scale. */
 int moge_forward(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int token_rows, int token_cols,
                  const moge_outputs* out, void* stream);
@@ -145,6 +147,12 @@ int moge_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, i
 int moge_postprocess(moge_handle* h, const float* points_in, const float* normal_in, const float* mask_prob_in,
                      const float* metric_scale_in, int B, int H, int W, const float* fov_x_deg, int flags,
                      const moge_outputs* out, void* stream);
+
+/* replaces the caller-side mesh clean-up `mask & ~utils3d.np.depth_map_edge(depth, rtol=threshold)` (scripts/infer.py:127;
+ * utils3d is an un-vendored dependency - algorithm restated in csrc/post.hip and oracle/caller_side.py, parity unpinned):
+ * depth (B,H,W) fp32 with +inf outside the mask, mask (B,H,W) bytes or NULL, out (B,H,W) bytes = mask && !edge. */
+int moge_depth_edge_mask(moge_handle* h, const float* depth, const unsigned char* mask, int B, int H, int W, float rtol,
+                         unsigned char* out, void* stream);
 
 /* Synchronise `stream` and report the sticky device-side status of the calls since the last sync
  * (MOGE_ERR_NONFINITE if a recovery solve saw non-finite residuals). */

@@ -74,6 +74,29 @@ template int launch_preprocess<float, float>(const void*, void*, int, int, int, 
 template int launch_preprocess<f16, f16>(const void*, void*, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
 template int launch_preprocess<f16, float>(const void*, void*, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
 
+// Caller-side ingest (scripts/infer.py:98: `torch.tensor(image / 255, dtype=torch.float32).permute(2, 0, 1)`, then v2.py:229 casts to the model
+// dtype): uint8 (B,H,W,3) -> T (B,3,H,W).  numpy divides in float64 and the tensor constructor rounds to float32 once: same here.
+template <typename T>
+__global__ void u8hwc_to_chw_kernel(const unsigned char* __restrict__ in, T* __restrict__ out, long B, int H, int W) {
+    const long px = (long)H * W, total = B * px;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long b = idx / px, p = idx - b * px;
+        const unsigned char* s = in + idx * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) out[(b * 3 + c) * px + p] = (T)(float)((double)s[c] / 255.0);
+    }
+}
+template <typename T>
+int launch_u8hwc_to_chw(const void* in, void* out, int B, int H, int W, hipStream_t st) {
+    const long total = (long)B * H * W;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(u8hwc_to_chw_kernel<T>, dim3(blocks), dim3(256), 0, st, (const unsigned char*)in, (T*)out, (long)B, H, W);
+    return (int)hipGetLastError();
+}
+template int launch_u8hwc_to_chw<f16>(const void*, void*, int, int, int, hipStream_t);
+template int launch_u8hwc_to_chw<float>(const void*, void*, int, int, int, hipStream_t);
+
 // zero the K padding columns [kfrom, ldk) of the im2col matrix (written once per forward)
 template <typename T>
 __global__ void zero_cols_kernel(T* a, long rowsN, int ldk, int kfrom) {

@@ -11,6 +11,8 @@ template <typename TIn, typename TOut>
 int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out, const float* mean,
                       const float* std_, hipStream_t st);
 template <typename T> int launch_zero_cols(void* a, long rowsN, int ldk, int kfrom, hipStream_t st);
+template <typename T> int launch_u8hwc_to_chw(const void* in, void* out, int B, int H, int W, hipStream_t st);      // uint8 (B,H,W,3) -> T (B,3,H,W), /255
+int launch_depth_edge_mask(const float* depth, const unsigned char* mask, unsigned char* out, int B, int H, int W, float rtol, hipStream_t st);
 int launch_posembed(const float* pos, float* out, int D, int rows, int cols, hipStream_t st);
 int launch_cls_row(float* x, const float* cls, const float* pos, int B, int Ntok, int D, hipStream_t st);
 template <typename T>

@@ -68,6 +68,9 @@ struct moge_handle {
     struct PosEntry { int rows, cols; float* ptr; };
     std::vector<PosEntry> pos_cache;
     int* d_status = nullptr;
+    // staging for uint8 HWC input (img_dtype 2): converted to the model dtype, CHW, before the forward
+    void* u8_stage = nullptr;
+    size_t u8_stage_bytes = 0;
     // batch-split execution: two internal streams run the two halves of a batch concurrently (tails of one half's kernels
     // and its HBM-bound kernels overlap the other half's MFMA kernels); joined on the caller's stream before post-processing
     hipStream_t split_st[2] = {nullptr, nullptr};
@@ -783,6 +786,7 @@ void moge_destroy(moge_handle* h) {
     if (h->aux) hipFree(h->aux);
     for (int i = 0; i < 2; i++) if (h->packed[i]) hipFree(h->packed[i]);
     if (h->ws) hipFree(h->ws);
+    if (h->u8_stage) hipFree(h->u8_stage);
     for (auto& e : h->pos_cache) hipFree(e.ptr);
     if (h->d_status) hipFree(h->d_status);
     for (int i = 0; i < 2; i++) { if (h->split_st[i]) hipStreamDestroy(h->split_st[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
@@ -926,10 +930,34 @@ static int forward_dispatch(moge_handle* h, const void* image, int img_dtype, co
     return 0;
 }
 
+// img_dtype 2: uint8 (B,H,W,3) as decoded from a file -> /255 in the model dtype, CHW (the reference's caller does this on the host:
+// scripts/infer.py:98); the rest of the path then sees an ordinary fp32 / fp16 image.
+static int ingest_image(moge_handle* h, const void*& image, int& img_dtype, int B, int H, int W, hipStream_t st) {
+    if (img_dtype != 2) {
+        if (img_dtype != 0 && img_dtype != 1) return fail(MOGE_ERR_INVALID, "img_dtype must be 0 (fp32 CHW), 1 (fp16 CHW) or 2 (uint8 HWC)");
+        return 0;
+    }
+    const bool half = h->prec == MOGE_FP16;
+    const size_t need = (size_t)B * 3 * H * W * (half ? 2 : 4);
+    if (need > h->u8_stage_bytes) {
+        HIPCHK(hipStreamSynchronize(st));
+        if (h->u8_stage) HIPCHK(hipFree(h->u8_stage));
+        h->u8_stage = nullptr; h->u8_stage_bytes = 0;
+        HIPCHK(hipMalloc(&h->u8_stage, need));
+        h->u8_stage_bytes = need;
+    }
+    if (half) LCHK(launch_u8hwc_to_chw<f16>(image, h->u8_stage, B, H, W, st));
+    else LCHK(launch_u8hwc_to_chw<float>(image, h->u8_stage, B, H, W, st));
+    image = h->u8_stage;
+    img_dtype = half ? 1 : 0;
+    return 0;
+}
+
 int moge_forward(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int rows, int cols, const moge_outputs* out, void* stream) {
     CHK(check_call(h, image, B, H, W, rows, cols));
     if (!out) return fail(MOGE_ERR_INVALID, "null outputs");
     hipStream_t st = (hipStream_t)stream;
+    CHK(ingest_image(h, image, img_dtype, B, H, W, st));
     Plan pl = make_plan(h->cfg, h->prec, B, H, W, rows, cols);
     return forward_dispatch(h, image, img_dtype, pl, out->points, out->normal, out->mask_prob, out->metric_scale, st);
 }
@@ -960,6 +988,7 @@ int moge_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, i
     if (!(c.heads & MOGE_HEAD_POINTS)) return fail(MOGE_ERR_INVALID, "infer needs a points head");
     if (!out->points || !out->depth) return fail(MOGE_ERR_INVALID, "points and depth output buffers are required");
     hipStream_t st = (hipStream_t)stream;
+    CHK(ingest_image(h, image, img_dtype, B, H, W, st));
     Plan pl = make_plan(c, h->prec, B, H, W, rows, cols);
     CHK(ensure_ws(h, forward_ws_bytes(h, pl)));
     float* mp = (c.heads & MOGE_HEAD_MASK) ? (out->mask_prob ? out->mask_prob : (float*)(h->ws + pl.maskprob)) : nullptr;
@@ -979,6 +1008,13 @@ int moge_postprocess(moge_handle* h, const float* points_in, const float* normal
     pl.focal = take(pl, (size_t)B * 4); pl.shift = take(pl, (size_t)B * 4); pl.intr = take(pl, (size_t)B * 36);
     CHK(ensure_ws(h, pl.total));
     return post_impl(h, pl, points_in, normal_in, mask_prob_in, metric_scale_in, fov_x_deg, flags, out, st);
+}
+
+int moge_depth_edge_mask(moge_handle* h, const float* depth, const unsigned char* mask, int B, int H, int W, float rtol, unsigned char* out, void* stream) {
+    if (!h || !depth || !out || B < 1 || H < 1 || W < 1) return fail(MOGE_ERR_INVALID, "null / empty argument");
+    HIPCHK(hipSetDevice(h->device));
+    LCHK(launch_depth_edge_mask(depth, mask, out, B, H, W, rtol, (hipStream_t)stream));
+    return 0;
 }
 
 int moge_sync(moge_handle* h, void* stream) {

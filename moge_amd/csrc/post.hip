@@ -597,3 +597,41 @@ int launch_finalize(const float* points_in, const float* normal_in, const float*
                        points_out, depth_out, normal_out, mask_out);
     return (int)hipGetLastError();
 }
+
+// --------------------------------------------------------------------------------------------
+// Caller-side mesh clean-up (scripts/infer.py:127: `mask & ~utils3d.np.depth_map_edge(depth, rtol=threshold)`).  utils3d is an un-vendored
+// dependency (pyproject.toml:23); its published algorithm, restated: diff = maxpool3x3(depth) + maxpool3x3(-depth) with -inf padding
+// (= max - min over the in-image 3x3 neighbourhood), edge = diff / depth > rtol evaluated in IEEE arithmetic (inf / inf = nan -> false,
+// inf / finite = inf -> true, so a valid pixel next to a masked-out (+inf) one is an edge).  out = mask & ~edge, one byte per pixel.
+// --------------------------------------------------------------------------------------------
+__global__ void depth_edge_mask_kernel(const float* __restrict__ depth, const unsigned char* __restrict__ mask, unsigned char* __restrict__ out,
+                                       long B, int H, int W, float rtol) {
+    const long px = (long)H * W, total = B * px;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long b = idx / px, p = idx - b * px;
+        const int y = (int)(p / W), x = (int)(p - (long)y * W);
+        const float* d = depth + b * px;
+        float mx = -INFINITY, mn = INFINITY;
+        for (int dy = -1; dy <= 1; dy++) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -1; dx <= 1; dx++) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                const float v = d[(long)yy * W + xx];
+                mx = fmaxf(mx, v);            // fmaxf drops a NaN operand like np.fmax; depth maps on this path carry no NaN (finite or +inf)
+                mn = fminf(mn, v);
+            }
+        }
+        const float diff = mx + (-mn);
+        const bool edge = (diff / d[p]) > rtol;
+        out[idx] = (mask ? mask[idx] != 0 : true) && !edge;
+    }
+}
+int launch_depth_edge_mask(const float* depth, const unsigned char* mask, unsigned char* out, int B, int H, int W, float rtol, hipStream_t st) {
+    const long total = (long)B * H * W;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(depth_edge_mask_kernel, dim3(blocks), dim3(256), 0, st, depth, mask, out, (long)B, H, W, rtol);
+    return (int)hipGetLastError();
+}

@@ -7,6 +7,8 @@ num_tokens: v2.py:236-238), owns the output tensors and translates status codes 
 from __future__ import annotations
 
 import ctypes as C
+import json
+import os
 import warnings
 from numbers import Number
 from pathlib import Path
@@ -104,6 +106,8 @@ class MoGeModel:
         self._cfg = cfg
         self._bits = bits
         self._state: Optional[Dict[str, torch.Tensor]] = None       # host fp32 state dict until the model is placed on a GPU
+        self._blob_path: Optional[str] = None                       # or: a packed master blob on disk (from_blob), uploaded as one copy
+        self._blob_offset = 0
         self._handle = None
         self._device = torch.device("cpu")
         self._dtype = torch.float32
@@ -210,6 +214,8 @@ class MoGeModel:
         self._state_ready = False
         if self._state is not None:
             self._upload()
+        elif self._blob_path is not None:
+            self._upload_blob()
 
     def _upload(self):
         names = [k.encode() for k in self._state]
@@ -221,6 +227,58 @@ class MoGeModel:
         with torch.cuda.device(self._device):
             L.check(L.lib.moge_load_weights(self._handle, descs, len(names), L.stream_ptr(self._device)))
         self._state_ready = True
+
+    # ------------------------------------------------------------------ packed master blob on disk
+    # File = MAGIC | u64 header length | JSON header {model_config, nbytes, layout} | zero padding to 4096 | the fp32 master blob exactly
+    # as the library lays it out in HBM (order = f(config) only, `build_tables` in csrc/model.hip), i.e. what the RCCL broadcast ships.
+    # Loading it is one H2D copy + the on-device packing kernels: no torch.load / unpickling, no per-tensor name lookup.
+    BLOB_MAGIC = b"MOGE-MI355X-MASTER-BLOB-v1\n"
+
+    def save_blob(self, path: Union[str, Path]) -> None:
+        """Write the device-resident fp32 master blob (+ model_config) to `path` (the model must be on a GPU with weights loaded)."""
+        self._require_ready()
+        blob = self.master_blob()
+        header = json.dumps({"model_config": self.model_config, "nbytes": int(blob.numel()), "layout": "moge_master_blob fp32, build_tables order"}).encode()
+        host = blob.cpu().numpy()
+        with open(path, "wb") as f:
+            f.write(self.BLOB_MAGIC)
+            f.write(len(header).to_bytes(8, "little"))
+            f.write(header)
+            f.write(b"\0" * ((-f.tell()) % 4096))
+            host.tofile(f)
+
+    @classmethod
+    def read_blob_header(cls, path: Union[str, Path]):
+        with open(path, "rb") as f:
+            if f.read(len(cls.BLOB_MAGIC)) != cls.BLOB_MAGIC:
+                raise ValueError(f"{path}: not a moge_amd master blob")
+            n = int.from_bytes(f.read(8), "little")
+            header = json.loads(f.read(n).decode())
+            off = f.tell()
+        off += (-off) % 4096
+        if os.path.getsize(path) != off + header["nbytes"]:
+            raise ValueError(f"{path}: truncated master blob (expected {off + header['nbytes']} bytes)")
+        return header, off
+
+    @classmethod
+    def from_blob(cls, path: Union[str, Path], model_kwargs: Optional[Dict[str, Any]] = None) -> "MoGeModel":
+        """Build a model from a file written by `save_blob`; the weights go to the GPU as one copy when the model is placed there."""
+        header, off = cls.read_blob_header(path)
+        cfg = header["model_config"]
+        if model_kwargs is not None:
+            cfg.update(model_kwargs)
+        model = cls(**cfg)
+        model._blob_path, model._blob_offset = str(path), off
+        return model
+
+    def _upload_blob(self):
+        import numpy as np
+        blob = self.master_blob()
+        host = torch.from_numpy(np.memmap(self._blob_path, dtype=np.uint8, mode="c", offset=self._blob_offset))      # copy-on-write: file untouched
+        if host.numel() != blob.numel():
+            raise ValueError(f"{self._blob_path}: blob is {host.numel()} bytes, this config needs {blob.numel()} (config / library version mismatch)")
+        blob.copy_(host)
+        self.master_received()
 
     # ------------------------------------------------------------------ multi-GPU weight distribution (SURVEY 8(e))
     def master_blob(self) -> torch.Tensor:
@@ -246,13 +304,33 @@ class MoGeModel:
         else:
             from huggingface_hub import hf_hub_download
             checkpoint_path = hf_hub_download(repo_id=pretrained_model_name_or_path, repo_type="model", filename="model.pt", **hf_kwargs)
+        # sidecar cache: "<checkpoint>.mi355x-blob" written by `cache_blob=True` on a previous load, valid while the checkpoint is unchanged
+        sidecar = None
+        if isinstance(checkpoint_path, (str, Path)):
+            sidecar = str(checkpoint_path) + ".mi355x-blob"
+            try:
+                if os.path.exists(sidecar) and os.path.getmtime(sidecar) >= os.path.getmtime(checkpoint_path):
+                    model = cls.from_blob(sidecar, model_kwargs)
+                    return model
+            except (ValueError, OSError, KeyError):
+                pass                                     # stale / foreign file: fall through to the checkpoint
         checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
         model_config = checkpoint["model_config"]
         if model_kwargs is not None:
             model_config.update(model_kwargs)
         model = cls(**model_config)
         model.load_state_dict(checkpoint["model"], strict=False)
+        model._sidecar = sidecar
         return model
+
+    def cache_blob(self) -> Optional[str]:
+        """Write the sidecar master blob next to the checkpoint this model was loaded from (next `from_pretrained` of the same file skips
+        torch.load).  Returns the path, or None when the model did not come from a local checkpoint file."""
+        sidecar = getattr(self, "_sidecar", None)
+        if sidecar is None:
+            return None
+        self.save_blob(sidecar)
+        return sidecar
 
     # ------------------------------------------------------------------ compute
     def _grid(self, H: int, W: int, num_tokens: int):
@@ -313,6 +391,42 @@ class MoGeModel:
             image = image.unsqueeze(0)
         image = self._prep_image(image)
         B, _, H, W = image.shape
+        return self._infer_device(image, 1 if image.dtype == torch.float16 else 0, B, H, W, omit_batch_dim, num_tokens, resolution_level,
+                                  force_projection, apply_mask, fov_x, use_fp16)
+
+    @torch.inference_mode()
+    def infer_uint8(self, image: torch.Tensor, num_tokens: int = None, resolution_level: int = 9, force_projection: bool = True,
+                    apply_mask: bool = True, fov_x: Optional[Union[Number, torch.Tensor]] = None, use_fp16: bool = True) -> Dict[str, torch.Tensor]:
+        """`infer` for images as they come out of a decoder: uint8 (H, W, 3) or (B, H, W, 3), RGB.  Equivalent to the reference caller's
+        `infer(torch.tensor(image / 255, dtype=torch.float32).permute(2, 0, 1), ...)` (scripts/infer.py:98-101), with the division, the
+        layout change and the cast to the model dtype done on the device: a quarter of the PCIe bytes of a float upload."""
+        self._require_ready()
+        if image.dtype != torch.uint8 or image.shape[-1] != 3 or image.dim() not in (3, 4):
+            raise ValueError("infer_uint8 expects a uint8 tensor of shape (H, W, 3) or (B, H, W, 3)")
+        omit_batch_dim = image.dim() == 3
+        if omit_batch_dim:
+            image = image.unsqueeze(0)
+        image = image.to(device=self._device, non_blocking=True).contiguous()
+        B, H, W, _ = image.shape
+        return self._infer_device(image, 2, B, H, W, omit_batch_dim, num_tokens, resolution_level, force_projection, apply_mask, fov_x, use_fp16)
+
+    @torch.inference_mode()
+    def depth_edge_mask(self, depth: torch.Tensor, mask: Optional[torch.Tensor] = None, rtol: float = 0.04) -> torch.Tensor:
+        """`mask & ~utils3d.np.depth_map_edge(depth, rtol=rtol)` on the device (scripts/infer.py:127; default threshold = the CLI's 0.04)."""
+        self._require_ready()
+        squeeze = depth.dim() == 2
+        d = (depth[None] if squeeze else depth).to(device=self._device, dtype=torch.float32).contiguous()
+        B, H, W = d.shape
+        m = None
+        if mask is not None:
+            m = (mask[None] if squeeze else mask).to(device=self._device, dtype=torch.bool).contiguous()
+        out = torch.empty((B, H, W), dtype=torch.bool, device=self._device)
+        with torch.cuda.device(self._device):
+            L.check(L.lib.moge_depth_edge_mask(self._handle, d.data_ptr(), m.data_ptr() if m is not None else None, B, H, W, float(rtol),
+                                               out.data_ptr(), L.stream_ptr(self._device)))
+        return out[0] if squeeze else out
+
+    def _infer_device(self, image, img_dtype, B, H, W, omit_batch_dim, num_tokens, resolution_level, force_projection, apply_mask, fov_x, use_fp16):
         if num_tokens is None:
             min_tokens, max_tokens = self.num_tokens_range
             num_tokens = int(min_tokens + (resolution_level / 9) * (max_tokens - min_tokens))
@@ -340,7 +454,7 @@ class MoGeModel:
                 fov = fov.contiguous()
                 fov_ptr = fov.data_ptr()
             flags = (L.FORCE_PROJECTION if force_projection else 0) | (L.APPLY_MASK if apply_mask else 0)
-            L.check(L.lib.moge_infer(self._handle, image.data_ptr(), 1 if image.dtype == torch.float16 else 0, B, H, W, rows, cols,
+            L.check(L.lib.moge_infer(self._handle, image.data_ptr(), img_dtype, B, H, W, rows, cols,
                                      fov_ptr, flags, C.byref(o), L.stream_ptr(dev)))
             if self.sync_on_infer:
                 L.check(L.lib.moge_sync(self._handle, L.stream_ptr(dev)))

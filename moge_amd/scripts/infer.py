@@ -1,0 +1,113 @@
+"""`python -m moge_amd.scripts.infer` - the reference's `moge infer` caller loop (moge/scripts/infer.py:18-156) on the MI355X path.
+
+Same flags where the step exists here (`--input/-i`, `--output/-o`, `--pretrained`, `--fov_x`, `--resize`, `--resolution_level`,
+`--num_tokens`, `--threshold`, `--maps`, `--ply`, `--fp16`, `--device`); images of equal size are batched (`--batch`) and run through
+`moge_amd.pipeline.InferPipeline` (uint8 upload, transfers overlapped with compute).  Differences, all forced by what this image ships:
+decode / resize use PIL instead of cv2 (BOX filter for `--resize`, the closest PIL has to INTER_AREA); float maps are written as
+`.npy` instead of `.exr`; `--glb` / `--show` (trimesh) are not provided; the point cloud's vertices are the pixels of
+`mask & ~depth_map_edge(depth, rtol=threshold)` (the vertex set `utils3d.np.build_mesh_from_map` produces at scripts/infer.py:128-145).
+"""
+from __future__ import annotations
+
+import itertools
+import json
+import math
+from pathlib import Path
+
+import click
+import numpy as np
+
+
+@click.command(help="Inference script (MI355X)")
+@click.option("--input", "-i", "input_path", type=click.Path(exists=True), required=True, help="Input image or folder.")
+@click.option("--fov_x", "fov_x_", type=float, default=None, help="Horizontal FoV in degrees; recovered from the point map if unset.")
+@click.option("--output", "-o", "output_path", default="./output", type=click.Path(), help='Output folder, default "./output".')
+@click.option("--pretrained", "pretrained_model_name_or_path", type=str, required=True, help="Checkpoint path or Hugging Face repo id.")
+@click.option("--device", "device_name", type=str, default="cuda", help='Device, default "cuda".')
+@click.option("--fp16", "use_fp16", is_flag=True, help="fp16 inference.")
+@click.option("--resize", "resize_to", type=int, default=None, help="Resize the long side to this size before inference.")
+@click.option("--resolution_level", type=int, default=9, help="0-9; ignored when --num_tokens is given.")
+@click.option("--num_tokens", type=int, default=None, help="Number of ViT tokens, [1200, 2500] suggested.")
+@click.option("--threshold", type=float, default=0.04, help="Relative depth-edge threshold for the point cloud, default 0.04.")
+@click.option("--maps", "save_maps_", is_flag=True, help="Save depth / points / mask / normal maps and fov.json.")
+@click.option("--ply", "save_ply_", is_flag=True, help="Save a coloured point cloud (.ply).")
+@click.option("--batch", "batch", type=int, default=8, help="Images of equal size per infer() call.")
+def main(input_path, fov_x_, output_path, pretrained_model_name_or_path, device_name, use_fp16, resize_to, resolution_level, num_tokens,
+         threshold, save_maps_, save_ply_, batch):
+    import torch
+    from PIL import Image
+
+    from moge_amd.io import masked_point_cloud, save_ply
+    from moge_amd.model import import_model_class_by_version
+    from moge_amd.pipeline import InferPipeline
+
+    suffices = ["jpg", "png", "jpeg", "JPG", "PNG", "JPEG"]
+    if Path(input_path).is_dir():
+        image_paths = sorted(itertools.chain(*(Path(input_path).rglob(f"*.{s}") for s in suffices)))
+        root = Path(input_path)
+    else:
+        image_paths, root = [Path(input_path)], Path(input_path).parent
+    if len(image_paths) == 0:
+        raise FileNotFoundError(f"No image files found in {input_path}")
+    model = import_model_class_by_version("v2").from_pretrained(pretrained_model_name_or_path).to(torch.device(device_name)).eval()
+    if use_fp16:
+        model.half()
+    if not (save_maps_ or save_ply_):
+        save_maps_ = save_ply_ = True
+
+    def load(path):
+        im = Image.open(path).convert("RGB")
+        if resize_to is not None:
+            w, h = im.size
+            h2, w2 = min(resize_to, int(resize_to * h / w)), min(resize_to, int(resize_to * w / h))
+            im = im.resize((w2, h2), Image.BOX)
+        return np.asarray(im, dtype=np.uint8)
+
+    by_shape = {}
+    for p in image_paths:
+        with Image.open(p) as im:
+            w, h = im.size
+        if resize_to is not None:
+            h, w = min(resize_to, int(resize_to * h / w)), min(resize_to, int(resize_to * w / h))
+        by_shape.setdefault((h, w), []).append(p)
+
+    for (h, w), paths in by_shape.items():
+        B = min(batch, len(paths))
+        pipe = InferPipeline(model, B, h, w, fov_x=fov_x_, resolution_level=resolution_level, num_tokens=num_tokens, use_fp16=use_fp16)
+        chunks = [paths[i:i + B] for i in range(0, len(paths), B)]
+        loaded = []
+
+        def gen():
+            for ch in chunks:
+                imgs = np.stack([load(p) for p in ch])
+                loaded.append(imgs)
+                yield imgs
+
+        for ch, out in zip(chunks, pipe.run(gen())):
+            imgs = loaded.pop(0)
+            cleaned = None
+            if save_ply_:
+                cleaned = model.depth_edge_mask(torch.from_numpy(out["depth"]), torch.from_numpy(out["mask"]) if "mask" in out else None,
+                                                rtol=threshold).cpu().numpy()
+            for j, p in enumerate(ch):
+                save_path = Path(output_path, p.relative_to(root).parent, p.stem)
+                save_path.mkdir(exist_ok=True, parents=True)
+                if save_maps_:
+                    Image.fromarray(imgs[j]).save(save_path / "image.jpg")
+                    np.save(save_path / "depth.npy", out["depth"][j])
+                    np.save(save_path / "points.npy", out["points"][j])
+                    if "mask" in out:
+                        Image.fromarray((out["mask"][j] * 255).astype(np.uint8)).save(save_path / "mask.png")
+                    if "normal" in out:
+                        Image.fromarray(((out["normal"][j] * [0.5, -0.5, -0.5] + 0.5).clip(0, 1) * 255).astype(np.uint8)).save(save_path / "normal.png")
+                    K = out["intrinsics"][j]
+                    with open(save_path / "fov.json", "w") as f:           # normalised intrinsics: fov = 2 atan(0.5 / f)
+                        json.dump({"fov_x": round(math.degrees(2 * math.atan(0.5 / float(K[0, 0]))), 2),
+                                   "fov_y": round(math.degrees(2 * math.atan(0.5 / float(K[1, 1]))), 2)}, f)
+                if save_ply_:
+                    v, c, n = masked_point_cloud(out["points"][j], cleaned[j], imgs[j], out["normal"][j] if "normal" in out else None)
+                    save_ply(save_path / "pointcloud.ply", v, None, c, n)
+
+
+if __name__ == "__main__":
+    main()

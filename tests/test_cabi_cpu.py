@@ -70,3 +70,32 @@ def test_eval_plugin_exposes_the_reference_baseline_interface():
     K = torch.tensor([[[0.8, 0.0, 0.5], [0.0, 1.1, 0.5], [0.0, 0.0, 1.0]]])
     fov = mod._fov_x_degrees(K)
     assert abs(float(fov) - float(torch.rad2deg(2 * torch.atan(torch.tensor(0.5 / 0.8))))) < 1e-5
+
+
+def test_master_blob_file_header_roundtrip_and_rejects_foreign_files(tmp_path):
+    """file format of the packed master blob (host logic only; the GPU round trip is in test_hip_parity.py)."""
+    import json
+    import numpy as np
+    from moge_amd.model.v2 import MoGeModel
+    from oracle import moge_oracle as O
+    cfg = O.named_configs()["tiny-vits-normal"]
+    header = json.dumps({"model_config": cfg, "nbytes": 8192, "layout": "test"}).encode()
+    p = tmp_path / "m.blob"
+    with open(p, "wb") as f:
+        f.write(MoGeModel.BLOB_MAGIC)
+        f.write(len(header).to_bytes(8, "little"))
+        f.write(header)
+        f.write(b"\0" * ((-f.tell()) % 4096))
+        np.arange(2048, dtype=np.float32).tofile(f)
+    h, off = MoGeModel.read_blob_header(p)
+    assert h["nbytes"] == 8192 and off % 4096 == 0 and h["model_config"]["encoder"]["backbone"] == cfg["encoder"]["backbone"]
+    m = MoGeModel.from_blob(p)
+    assert m._state is None and m._blob_path == str(p) and m.model_config["remap_output"] == cfg["remap_output"]
+    with open(p, "ab") as f:
+        f.write(b"x")
+    with pytest.raises(ValueError):
+        MoGeModel.read_blob_header(p)                      # size mismatch = truncated / foreign
+    q = tmp_path / "n.blob"
+    q.write_bytes(b"not a blob at all")
+    with pytest.raises(ValueError):
+        MoGeModel.from_blob(q)

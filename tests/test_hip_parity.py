@@ -218,3 +218,35 @@ def test_eval_plugin_runs_through_the_click_loader(tmp_path_factory):
     ref = O.infer(cfg, sd, x.cpu(), num_tokens=108, fov_x=float(mod._fov_x_degrees(K.cpu())), apply_mask=False)
     assert rel_err(out["depth_metric"].cpu().numpy(), ref["depth"].numpy()) < FP32_TOL
     assert rel_err(out["intrinsics"].cpu().numpy(), ref["intrinsics"].numpy()) < FP32_TOL
+
+
+def test_master_blob_cache_is_bit_identical_to_the_checkpoint_load(MoGeModel, tmp_path_factory):
+    """save_blob -> from_blob and the from_pretrained sidecar reproduce the .pt-loaded model bit for bit (fp32 and fp16 mode)."""
+    from oracle import moge_oracle as O
+    cfg = O.named_configs()["tiny-vits-normal"]
+    sd = O.synth_state_dict(cfg, 3, True)
+    d = str(tmp_path_factory.mktemp("blob"))
+    path = os.path.join(d, "model.pt")
+    O.save_checkpoint(path, cfg, sd)
+    m0 = MoGeModel.from_pretrained(path).to("cuda").eval()
+    x = torch.rand(2, 3, 84, 112, generator=torch.Generator().manual_seed(11)).cuda()
+    ref32 = m0.infer(x, num_tokens=108, use_fp16=False)
+    ref16 = m0.infer(x, num_tokens=108, use_fp16=True)
+    blob = os.path.join(d, "model.blob")
+    m0.save_blob(blob)
+    header, off = MoGeModel.read_blob_header(blob)
+    assert header["model_config"]["encoder"]["backbone"] == cfg["encoder"]["backbone"] and off % 4096 == 0
+    m1 = MoGeModel.from_blob(blob).to("cuda").eval()
+    assert m0.cache_blob() == path + ".mi355x-blob"
+    m2 = MoGeModel.from_pretrained(path)                       # now served by the sidecar: no state dict on the host
+    assert m2._state is None and m2._blob_path == path + ".mi355x-blob"
+    m2 = m2.to("cuda").eval()
+    for m in (m1, m2):
+        o32 = m.infer(x, num_tokens=108, use_fp16=False)
+        o16 = m.infer(x, num_tokens=108, use_fp16=True)
+        for k in ref32:
+            assert torch.equal(o32[k], ref32[k]), k
+            assert torch.equal(o16[k], ref16[k]), k
+    # a stale sidecar (checkpoint rewritten later) is ignored
+    os.utime(path + ".mi355x-blob", (1, 1))
+    assert MoGeModel.from_pretrained(path)._state is not None
