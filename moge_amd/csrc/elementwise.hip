@@ -254,17 +254,107 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if (i < nit && col < D) {
                 float y[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) y[e] = (v[i][e] - mean) * rstd * ww[i][e] + bb[i][e];
+                for (int e = 0; e < 4; e++) y[e] = fmaf((v[i][e] - mean) * rstd, ww[i][e], bb[i][e]);
                 if (cp) *reinterpret_cast<f32x4*>(cp + col) = f32x4{y[0], y[1], y[2], y[3]};
                 else store4(op + col, y[0], y[1], y[2], y[3]);
             }
         }
     }
 }
+#define LR_LD2(base, off) (*reinterpret_cast<const __attribute__((address_space(1))) f32x2*>((const __attribute__((address_space(1))) char*)(base) + (off)))
+#define LR_LD(base, off) (*reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((const __attribute__((address_space(1))) char*)(base) + (off)))
+// Low-register variant (<= 32 VGPRs, no LDS): the same arithmetic in the same order, but the row is re-read from L1/L2 in each of the
+// three passes instead of being held in registers, and weight / bias are fetched where they are used.  Purpose: CO-RESIDENCY.  The MFMA
+// kernels leave 32 (gemm_pp128: 2 x 240 of 512 registers per SIMD), 56 (attn_pp) or 96 (conv_pp) registers per SIMD unused, so one wave
+// of this kernel per SIMD runs NEXT TO them when the other half-batch stream is inside a GEMM / attention / conv (model.hip,
+// forward_dispatch): the HBM-bound LayerNorm would then cost no wall time of its own.  MEASURED (bench.py, vitl B=32): it does not pay - the
+// norm class goes 7.1 -> 10.6 ms (three passes, one row in flight per wave) and the step 161.1 -> 164.1 ms, i.e. the two half-batch streams did
+// not overlap it any better than the fast kernel's tails already do.  Kept behind MOGE_LN_LOWREG=1 (default off) as the record of the experiment.
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void layernorm_lr_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                                                const float* __restrict__ bias, T* __restrict__ out,
+                                                                                                float* __restrict__ cls_out, long rowsN, int D, int ldo,
+                                                                                                int coloff, int tap_mode, int Ntok) {
+    // wave-uniform row / weight / output bases live in SGPRs (uniform_ptr), the lane contributes one 32-bit byte offset: the loads and
+    // stores use the saddr + voffset form and no 64-bit per-lane address survives a pass
+    constexpr int LN_RPW = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long row0 = (blockIdx.x * 4L + wave) * LN_RPW;
+    if (row0 >= rowsN) return;
+    const int nit = (D + 255) >> 8;
+    const float invD = 1.f / (float)D;
+    const int loff = lane * 16;                       // byte offset of this lane's 4 fp32 columns inside a 1-KiB segment
+    const int ncols = D - lane * 4;                   // column i*256 + 4*lane is in range iff i*256 < ncols
+    for (int r = 0; r < LN_RPW; r++) {
+        const long row = row0 + r;
+        if (row >= rowsN) break;
+        const char* xr = uniform_ptr(reinterpret_cast<const char*>(x + row * (long)D));
+        float s = 0.f;
+#pragma unroll 1
+        for (int i = 0; i < nit; i++) {
+            if (i * 256 < ncols) { const f32x4 v = LR_LD(xr, i * 1024 + loff); s += (v[0] + v[1]) + (v[2] + v[3]); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * invD;
+        float q = 0.f;
+#pragma unroll 1
+        for (int i = 0; i < nit; i++) {
+            if (i * 256 < ncols) {
+                const f32x4 v = LR_LD(xr, i * 1024 + loff);
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const float a = v[e] - mean; q += a * a; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q * invD + 1e-6f);
+        const char* op = nullptr; const char* cp = nullptr;
+        if (tap_mode) {
+            const long b = row / Ntok; const int t = (int)(row - b * Ntok);
+            if (t == 0) { if (!cls_out) continue; cp = uniform_ptr(reinterpret_cast<const char*>(cls_out + b * D)); }
+            else op = uniform_ptr(reinterpret_cast<const char*>(out + (b * (Ntok - 1) + t - 1) * (long)ldo + coloff));
+        } else {
+            op = uniform_ptr(reinterpret_cast<const char*>(out + row * (long)ldo + coloff));
+        }
+        const char* wp = reinterpret_cast<const char*>(w);
+        const char* bp = reinterpret_cast<const char*>(bias);
+#pragma unroll 1
+        for (int i = 0; i < nit; i++) {
+            if (i * 256 < ncols) {
+                const f32x4 v = LR_LD(xr, i * 1024 + loff);
+                float y[4];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++) {          // weight / bias in 8-byte halves: 4 fewer live registers, same fma as layernorm_kernel
+                    const f32x2 ww = LR_LD2(wp, i * 1024 + loff + 8 * h2), bb = LR_LD2(bp, i * 1024 + loff + 8 * h2);
+#pragma unroll
+                    for (int e = 0; e < 2; e++) y[2 * h2 + e] = fmaf((v[2 * h2 + e] - mean) * rstd, ww[e], bb[e]);
+                    asm volatile("" : "+v"(y[2 * h2]), "+v"(y[2 * h2 + 1]));
+                }
+                if (cp) {
+                    *reinterpret_cast<__attribute__((address_space(1))) f32x4*>((__attribute__((address_space(1))) char*)cp + (i * 1024 + loff)) = f32x4{y[0], y[1], y[2], y[3]};
+                } else if constexpr (sizeof(T) == 2) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<__attribute__((address_space(1))) h4*>((__attribute__((address_space(1))) char*)op + (i * 512 + lane * 8)) =
+                        h4{(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+                } else {
+                    *reinterpret_cast<__attribute__((address_space(1))) f32x4*>((__attribute__((address_space(1))) char*)op + (i * 1024 + loff)) = f32x4{y[0], y[1], y[2], y[3]};
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 int launch_layernorm(const float* x, const float* w, const float* b, void* out, float* cls_out, long rowsN, int D, int ldo, int coloff,
                      int tap_mode, int Ntok, hipStream_t st) {
     if (D % 4 != 0 || D > 1024 || (ldo & 3) || (coloff & 3)) return -1;
+    if (sizeof(T) == 2 && moge_tune_get("LN_LOWREG", 0)) {
+        hipLaunchKernelGGL(layernorm_lr_kernel<T>, dim3((unsigned)((rowsN + 15) / 16)), dim3(256), 0, st, x, w, b, (T*)out, cls_out, rowsN, D, ldo, coloff,
+                           tap_mode, Ntok);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(layernorm_kernel<T>, dim3((unsigned)((rowsN + 15) / 16)), dim3(256), 0, st, x, w, b, (T*)out, cls_out, rowsN, D, ldo, coloff,
                        tap_mode, Ntok);
     return (int)hipGetLastError();
