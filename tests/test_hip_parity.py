@@ -250,3 +250,17 @@ def test_master_blob_cache_is_bit_identical_to_the_checkpoint_load(MoGeModel, tm
     # a stale sidecar (checkpoint rewritten later) is ignored
     os.utime(path + ".mi355x-blob", (1, 1))
     assert MoGeModel.from_pretrained(path)._state is not None
+
+
+@pytest.mark.parametrize("shape,tokens", [((37, 211), 96), ((300, 100), 147), ((64, 64), 16), ((97, 131), 300), ((518, 130), 120)])
+def test_odd_shapes_and_token_grids_match_the_oracle_fp32(MoGeModel, tmp_path_factory, shape, tokens):
+    """Ragged sizes either side of the resampler: down- AND up-sampling in the same image (37x211 -> 5x30 grid), a 1:3 portrait strip,
+    the smallest grids, a prime-sized image, a 4:1 strip of the BASELINE height; token grid = Python half-to-even rounding (v2.py:147)."""
+    from oracle import moge_oracle as O
+    model, cfg, sd = get_model(MoGeModel, "tiny-vits-normal", 0, True, tmp_path_factory)
+    H, W = shape
+    x = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(H * 1000 + W))
+    out = model.infer(x, num_tokens=tokens, use_fp16=False)
+    ref = O.infer(cfg, sd, x, num_tokens=tokens)
+    assert out["mask"].shape == (2, H, W) and out["points"].shape == (2, H, W, 3)
+    compare(out, ref, FP32_TOL)
