@@ -139,6 +139,13 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
 __device__ __forceinline__ float resid_term(float gamma, float acc, float bias) { return fmaf(gamma, acc, gamma * bias); }   // gamma*(acc+bias)
 __device__ __forceinline__ float uv_term_add(float v, float wu, float u, float wv, float vv) { return fmaf(wu, u, fmaf(wv, vv, v)); }
 
+// LN fold (GemmArgs::ln_mr): one output element of the consumer GEMM, and the (sum, sum of squares) of 4 consecutive residual columns
+__device__ __forceinline__ float ln_fold_term(float acc, float mean, float rstd, float c, float b) { return fmaf(rstd, fmaf(-mean, c, acc), b); }
+__device__ __forceinline__ void ln_quad_sums(const f32x4& x, float& s1, float& s2) {
+    s1 = (x[0] + x[1]) + (x[2] + x[3]);
+    s2 = fmaf(x[1], x[1], x[0] * x[0]) + fmaf(x[3], x[3], x[2] * x[2]);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // torch.linspace(start, end, steps) element i in fp32 (ATen: symmetric evaluation around the middle)
@@ -194,6 +201,15 @@ struct GemmArgs {
     float qscale;
     // EPI_CONVT: n = (dy*2+dx)*Cout + co -> out[((b*2H+2y+dy)*2W+2x+dx)*Cout+co]
     int Cout;
+    // LayerNorm folded into the GEMMs around it (fp16 path; model.hip "LN fold"):  LN(x) W^T + b = rstd (x W'^T - mean c) + b'
+    //   with W' = g (.) W (fp16),  c[n] = sum_k W'[n][k],  b' = b + W beta.
+    //   producer (EPI_RESID): x16[m*ldc+n] = fp16 copy of the UPDATED residual, ln_part[(m*(N/32) + n/32)*2 + {0,1}] = (sum, sum of
+    //     squares) of its 32-column group (fixed summation tree, identical in gemm.hip and gemm_pp.hip)
+    //   consumer (EPI_QKV / EPI_STORE): A = x16, W = W', bias = b', ln_mr[2m + {0,1}] = (mean, rstd) of row m, ln_c = c
+    void* x16;
+    float* ln_part;
+    const float* ln_mr;
+    const float* ln_c;
     unsigned long long* dbg_ts;   // gemm_pp128: optional s_memtime stamps of one block (tools/kbench)
     int stagger;           // gemm_pp128: number of start-phase classes (0/1 = off)
     int dbg;               // gemm_pp ablation bits (tools/kbench only): 1 no DMA, 2 no LDS reads, 4 no MFMA, 8 no barriers

@@ -261,6 +261,105 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
     }
 }
+// --------------------------------------------------------------------------------------------
+// LayerNorm folded into the neighbouring GEMMs (fp16 path, model.hip "LN fold").
+//   ln_raw_kernel      : first block only - fp16 copy of the residual row + its (mean, rstd) (two-pass, as layernorm_kernel)
+//   ln_finalize_kernel : (sum, sum of squares) partials of the RESID epilogues -> (mean, rstd); var = E[x^2] - mean^2 in fp32, clamped at 0
+//   fold_ln_kernel     : W'[n][k] = T(g[k] * W[n][k]),  c[n] = sum_k float(W'[n][k]),  b'[n] = b[n] + sum_k beta[k] * W[n][k]
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ln_raw_kernel(const float* __restrict__ x, T* __restrict__ out, float* __restrict__ mr, long rowsN, int D) {
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rowsN) return;
+    const int nit = (D + 255) >> 8;
+    const float invD = 1.f / (float)D;
+    const float* xr = x + row * (long)D;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int col = i * 256 + lane * 4;
+        if (i < nit && col < D) { v[i] = *reinterpret_cast<const f32x4*>(xr + col); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int col = i * 256 + lane * 4;
+        if (i < nit && col < D) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const float a = v[i][e] - mean; q += a * a; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * invD + 1e-6f);
+    if (lane == 0) *reinterpret_cast<f32x2*>(mr + 2 * row) = f32x2{mean, rstd};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int col = i * 256 + lane * 4;
+        if (i < nit && col < D) store4(out + row * (long)D + col, v[i][0], v[i][1], v[i][2], v[i][3]);
+    }
+}
+template <typename T>
+int launch_ln_raw(const float* x, void* out, float* mr, long rowsN, int D, hipStream_t st) {
+    if (D % 4 != 0 || D > 1024) return -1;
+    hipLaunchKernelGGL(ln_raw_kernel<T>, dim3((unsigned)((rowsN + 3) / 4)), dim3(256), 0, st, x, (T*)out, mr, rowsN, D);
+    return (int)hipGetLastError();
+}
+template int launch_ln_raw<f16>(const float*, void*, float*, long, int, hipStream_t);
+
+__global__ void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ mr, long rowsN, int NP, float invD) {
+    const long row = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (row >= rowsN) return;
+    const f32x4* p = reinterpret_cast<const f32x4*>(part + row * (long)NP * 2);
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < NP / 2; i++) {              // partials in column order: (s1, s2) pairs, two per 16-byte load
+        const f32x4 t = p[i];
+        s1 += t[0]; s2 += t[1];
+        s1 += t[2]; s2 += t[3];
+    }
+    const float mean = s1 * invD;
+    const float var = fmaxf(fmaf(-mean, mean, s2 * invD), 0.f);
+    *reinterpret_cast<f32x2*>(mr + 2 * row) = f32x2{mean, rsqrtf(var + 1e-6f)};
+}
+int launch_ln_finalize(const float* part, float* mr, long rowsN, int NP, int D, hipStream_t st) {
+    if (NP & 1) return -1;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rowsN + 255) / 256)), dim3(256), 0, st, part, mr, rowsN, NP, 1.f / (float)D);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ g, const float* __restrict__ beta,
+                                                      const float* __restrict__ b, T* __restrict__ Wf, float* __restrict__ c, float* __restrict__ bf, int K) {
+    __shared__ float red[2][256];
+    const int n = blockIdx.x, t = threadIdx.x;
+    float sc = 0.f, sb = 0.f;
+    for (int k = t; k < K; k += 256) {
+        const float w = W[(size_t)n * K + k];
+        const T wf = (T)(g[k] * w);
+        Wf[(size_t)n * K + k] = wf;
+        sc += (float)wf;
+        sb = fmaf(beta[k], w, sb);
+    }
+    red[0][t] = sc; red[1][t] = sb;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) { c[n] = red[0][0]; bf[n] = b[n] + red[1][0]; }
+}
+template <typename T>
+int launch_fold_ln(const float* W, const float* g, const float* beta, const float* b, void* Wf, float* c, float* bf, int N, int K, hipStream_t st) {
+    hipLaunchKernelGGL(fold_ln_kernel<T>, dim3((unsigned)N), dim3(256), 0, st, W, g, beta, b, (T*)Wf, c, bf, K);
+    return (int)hipGetLastError();
+}
+template int launch_fold_ln<f16>(const float*, const float*, const float*, const float*, void*, float*, float*, int, int, hipStream_t);
+
 #define LR_LD2(base, off) (*reinterpret_cast<const __attribute__((address_space(1))) f32x2*>((const __attribute__((address_space(1))) char*)(base) + (off)))
 #define LR_LD(base, off) (*reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((const __attribute__((address_space(1))) char*)(base) + (off)))
 // Low-register variant (<= 32 VGPRs, no LDS): the same arithmetic in the same order, but the row is re-read from L1/L2 in each of the

@@ -36,7 +36,13 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float
         *reinterpret_cast<f32x4*>(p) = x;
         return;
     }
-    if (g.bias) {
+    if (g.ln_mr) {           // LN-fold consumer (same arithmetic as gemm_pp.hip: ln_fold_term)
+        const f32x2 mr = *reinterpret_cast<const f32x2*>(g.ln_mr + 2 * (size_t)m);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
+        const f32x4 lc = *reinterpret_cast<const f32x4*>(g.ln_c + n);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = ln_fold_term(v[i], mr[0], mr[1], lc[i], b[i]);
+    } else if (g.bias) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
 #pragma unroll
         for (int i = 0; i < 4; i++) v[i] += b[i];
@@ -114,6 +120,43 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float
         break;
     }
     }
+}
+
+// One 32 x 32 accumulator tile of a lane: row m, quads at columns nb + 8q (nb already includes 4*hi).  EPI_RESID with the LN-fold
+// producer outputs (GemmArgs::x16 / ln_part): residual update + fp16 copy + the (sum, sum of squares) of the row's 32-column group with the
+// SAME summation tree as gemm_pp.hip's pp_resid_rows (quad sums, then pairs 2q/2q+1 across the two half-waves, then (0+1)+(2+3)), so the
+// folded LayerNorm statistics - and with them every output - do not depend on which kernel a batch size selects.
+template <typename T>
+__device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, int m, int nb, int hi, const f32x16& a) {
+    if (g.epi == EPI_RESID && g.x16) {
+        const bool ok = m < g.M;
+        float t1[4], t2[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int n = nb + 8 * q;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                float* p = g.xres + (size_t)m * g.ldc + n;
+                x = *reinterpret_cast<f32x4*>(p);
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (g.bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[i] = x[i] + resid_term(gm[i], a[4 * q + i], b[i]);
+                *reinterpret_cast<f32x4*>(p) = x;
+                *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(g.x16) + (size_t)m * g.ldc + n) = f16x4{(f16)x[0], (f16)x[1], (f16)x[2], (f16)x[3]};
+            }
+            float s1, s2;
+            ln_quad_sums(x, s1, s2);
+            t1[q] = s1 + __shfl_xor(s1, 32);
+            t2[q] = s2 + __shfl_xor(s2, 32);
+        }
+        const float u1 = (t1[0] + t1[1]) + (t1[2] + t1[3]), u2 = (t2[0] + t2[1]) + (t2[2] + t2[3]);
+        if (hi == 0 && ok) *reinterpret_cast<f32x2*>(g.ln_part + ((size_t)m * (g.N >> 5) + (nb >> 5)) * 2) = f32x2{u1, u2};
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) epilogue4<T>(g, m, nb + 8 * q, a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
 }
 
 template <typename T, int WM, int WN, int TM, int TN, int AMODE>
@@ -258,9 +301,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; j++) {
             const int nb = n0 + (wn * TN + j) * 32 + 4 * hi;
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                epilogue4<T>(g, m, nb + 8 * q, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            epilogue_tile32<T>(g, m, nb, hi, acc[i][j]);
         }
     }
 }
@@ -404,9 +445,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
 #pragma unroll
         for (int j = 0; j < TN; j++) {
             const int nb = n0 + (wn * TN + j) * 32 + 4 * hi;
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                epilogue4<T>(g, m, nb + 8 * q, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            epilogue_tile32<T>(g, m, nb, hi, acc[i][j]);
         }
     }
 }

@@ -31,7 +31,10 @@
 // reuse its private 16 KiB (TM = 4) / 8 KiB (TM = 2) region of the ring for the output transpose.
 // The flavour is a COMPILE-TIME parameter: with run-time switches inside the 128-accumulator loops the compiler emitted
 // ~1000 register copies and ~100 branches per wave (measured 13-45k cycles per tile against a 43k-cycle K=1024 main loop).
-enum { EPK_RESID = 0, EPK_STORE = 1, EPK_GELU = 2, EPK_QKV = 3, EPK_CONVT = 4, EPK_UV = 5, EPK_RELU = 6 };
+enum { EPK_RESID = 0, EPK_STORE = 1, EPK_GELU = 2, EPK_QKV = 3, EPK_CONVT = 4, EPK_UV = 5, EPK_RELU = 6,
+       EPK_GELU_LN = 7, EPK_QKV_LN = 8 };        // _LN: consumer of a folded LayerNorm (GemmArgs::ln_mr), otherwise as GELU / QKV
+template <int EPK> struct EpkBase { static constexpr int K = EPK == EPK_GELU_LN ? EPK_GELU : (EPK == EPK_QKV_LN ? EPK_QKV : EPK);
+                                    static constexpr bool FOLD = EPK == EPK_GELU_LN || EPK == EPK_QKV_LN; };
 
 // ---- stage 2: LDS staging region (row-major, 128 B per row, 16-byte chunks XOR-swizzled by row & 7) -> global memory ----
 template <int WROWS>
@@ -53,7 +56,17 @@ __device__ __forceinline__ void pp_resid_rows(const GemmArgs& g, const char* R, 
         const int row = it * 8 + rr;
         const int m = mw + row;
         const f32x4 v = *reinterpret_cast<const f32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
-        if (m < M) *reinterpret_cast<f32x4*>(xres + (size_t)m * ldc + ncol + cc * 4) = xv[it] + v;
+        const f32x4 xnew = xv[it] + v;
+        if (m < M) *reinterpret_cast<f32x4*>(xres + (size_t)m * ldc + ncol + cc * 4) = xnew;
+        if (g.x16) {          // LN fold producer: fp16 copy + (sum, sum of squares) of this row's 32-column group (8 lanes, butterfly 1-2-4)
+            if (m < M) *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(g.x16) + (size_t)m * ldc + ncol + cc * 4) =
+                f16x4{(f16)xnew[0], (f16)xnew[1], (f16)xnew[2], (f16)xnew[3]};
+            float s1, s2;
+            ln_quad_sums(xnew, s1, s2);
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            if (cc == 0 && m < M) *reinterpret_cast<f32x2*>(g.ln_part + ((size_t)m * (g.N >> 5) + (ncol >> 5)) * 2) = f32x2{s1, s2};
+        }
     }
 }
 
@@ -111,12 +124,13 @@ __device__ __forceinline__ void pp_store_rows(const GemmArgs& g, const char* R, 
 }
 
 // the per-quad arithmetic shared by both accumulator layouts: 4 consecutive columns n .. n+3 of one output row
-template <int EPK>
-__device__ __forceinline__ f16x4 pp_quad_f16(const f32x4& a, const f32x4& b, float scale, const f32x4& wu, float u, const f32x4& wv, float vv) {
+template <int EPK, bool FOLD = false>
+__device__ __forceinline__ f16x4 pp_quad_f16(const f32x4& a, const f32x4& b, float scale, const f32x4& wu, float u, const f32x4& wv, float vv,
+                                             float mean = 0.f, float rstd = 1.f, const f32x4& lc = f32x4{0.f, 0.f, 0.f, 0.f}) {
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        v[e] = a[e] + b[e];
+        v[e] = FOLD ? ln_fold_term(a[e], mean, rstd, lc[e], b[e]) : a[e] + b[e];
         if constexpr (EPK == EPK_QKV) v[e] *= scale;
         if constexpr (EPK == EPK_UV) v[e] = uv_term_add(v[e], wu[e], u, wv[e], vv);
         if constexpr (EPK == EPK_RELU) v[e] = fmaxf(v[e], 0.f);
@@ -129,8 +143,10 @@ __device__ __forceinline__ f16x4 pp_quad_f16(const f32x4& a, const f32x4& b, flo
 }
 
 // ---- 32x32x16 accumulators: tile (i, j), register quad q: row i*32 + (lane & 31), columns j*32 + 8q + 4*(lane >> 5) .. +3 ----
-template <int TM, int EPK>
+template <int TM, int EPKX>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][2], char* smem, int wave, int lane, int mw, int nw) {
+    constexpr int EPK = EpkBase<EPKX>::K;
+    constexpr bool FOLD = EpkBase<EPKX>::FOLD;
     constexpr int TN = 2;
     constexpr int WROWS = TM * 32;
     const int hi = lane >> 5, l31 = lane & 31;
@@ -175,6 +191,18 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM]
             }
         }
         const bool has_bias = g.bias != nullptr;
+        float mu[TM], rs[TM];               // LN fold: (mean, rstd) of this lane's rows
+#pragma unroll
+        for (int i = 0; i < TM; i++) { mu[i] = 0.f; rs[i] = 1.f; }
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                int m = mw + i * 32 + l31;
+                m = m < M ? m : M - 1;
+                const f32x2 t = *reinterpret_cast<const f32x2*>(g.ln_mr + 2 * (size_t)m);
+                mu[i] = t[0]; rs[i] = t[1];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TN; j++)
 #pragma unroll
@@ -182,6 +210,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM]
                 const int n = nw + j * 32 + 8 * q + 4 * hi;
                 f32x4 b = {0.f, 0.f, 0.f, 0.f};
                 if (has_bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+                f32x4 lc = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (FOLD) lc = *reinterpret_cast<const f32x4*>(g.ln_c + n);
                 f32x4 wu = {0.f, 0.f, 0.f, 0.f}, wv = wu;
                 if constexpr (EPK == EPK_UV) {
                     wu = *reinterpret_cast<const f32x4*>(g.uv.wu + n);
@@ -191,7 +221,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM]
                 for (int i = 0; i < TM; i++) {
                     const int row = i * 32 + l31;
                     const f32x4 a = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    const f16x4 hv = pp_quad_f16<EPK>(a, b, scale, wu, u[i], wv, vv[i]);
+                    const f16x4 hv = pp_quad_f16<EPK, FOLD>(a, b, scale, wu, u[i], wv, vv[i], mu[i], rs[i], lc);
                     *reinterpret_cast<f16x4*>(R + row * 128 + ((((j * 4 + q) ^ (row & 7)) << 4) | (hi << 3))) = hv;
                 }
             }
@@ -1096,6 +1126,11 @@ static int launch_pp_cfg(const GemmArgs& g, hipStream_t st) {
 // Shapes / epilogues the ping-pong kernel takes (f16, LINEAR mode only).  bn256 = prefer the 256-wide tile.
 bool gemm_pp_eligible(const GemmArgs& g) {
     if (g.relu_in || g.add) return false;
+    if (g.ln_mr) {          // LN-fold consumer: QKV / GELU flavours of the 256x256 kernel
+        if ((g.N % 256) || (g.K & 63) || !g.ln_c || !g.bias) return false;
+        if (!(g.epi == EPI_QKV ? (g.D % 256) == 0 : (g.epi == EPI_STORE && g.act == ACT_GELU && !g.uv.wu))) return false;
+    }
+    if (g.x16 && (g.epi != EPI_RESID || !g.ln_part || (g.N & 31))) return false;
     if (g.K < 64 || (g.K & 31) || (g.N & 127) || g.M < 256) return false;
     if ((g.lda & 7) || (g.ldw & 7)) return false;
     switch (g.epi) {
@@ -1110,12 +1145,12 @@ bool gemm_pp_eligible(const GemmArgs& g) {
 static int epilogue_kind(const GemmArgs& g) {
     switch (g.epi) {
     case EPI_RESID: return EPK_RESID;
-    case EPI_QKV: return EPK_QKV;
+    case EPI_QKV: return g.ln_mr ? EPK_QKV_LN : EPK_QKV;
     case EPI_CONVT: return EPK_CONVT;
     default: break;
     }
     if (g.uv.wu) return EPK_UV;
-    if (g.act == ACT_GELU) return EPK_GELU;
+    if (g.act == ACT_GELU) return g.ln_mr ? EPK_GELU_LN : EPK_GELU;
     if (g.act == ACT_RELU) return EPK_RELU;
     return EPK_STORE;
 }
@@ -1138,6 +1173,8 @@ int launch_gemm_pp(const GemmArgs& g0, hipStream_t st) {
     case EPK_CONVT: return launch_pp_any<EPK_CONVT>(g, wide, st);
     case EPK_UV: return launch_pp_any<EPK_UV>(g, wide, st);
     case EPK_GELU: return launch_pp_any<EPK_GELU>(g, wide, st);
+    case EPK_GELU_LN: return launch_pp128_cfg<EPK_GELU_LN, 1>(g, st);       // LN-fold consumers: the 256x256 kernel only (gemm_pp_eligible)
+    case EPK_QKV_LN: return launch_pp128_cfg<EPK_QKV_LN, 1>(g, st);
     case EPK_RELU: return launch_pp_any<EPK_RELU>(g, wide, st);
     default: return launch_pp_any<EPK_STORE>(g, wide, st);
     }

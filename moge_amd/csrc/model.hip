@@ -133,6 +133,11 @@ static void build_tables(moge_handle* h) {
         padd(h, S("blk%d.proj", i), (int64_t)D * D);
         padd(h, S("blk%d.fc1", i), (int64_t)4 * D * D);
         padd(h, S("blk%d.fc2", i), (int64_t)4 * D * D);
+        // LN fold (fp16 path): norm1 folded into qkv, norm2 into fc1:  W' = g (.) W,  c = row sums of W',  b' = b + W beta
+        padd(h, S("blk%d.qkvf", i), (int64_t)3 * D * D);
+        padd(h, S("blk%d.fc1f", i), (int64_t)4 * D * D);
+        aadd(h, S("blk%d.qkv.c", i), 3 * D); aadd(h, S("blk%d.qkv.bf", i), 3 * D);
+        aadd(h, S("blk%d.fc1.c", i), 4 * D); aadd(h, S("blk%d.fc1.bf", i), 4 * D);
     }
     tadd(h, bb + "norm.weight", D); tadd(h, bb + "norm.bias", D);
     for (int k = 0; k < c.n_taps; k++) {
@@ -315,6 +320,12 @@ static int pack_weights(moge_handle* h, hipStream_t st) {
         LCHK((launch_convert<float, T>(M(h, p + "attn.proj.weight"), Pm<T>(h, S("blk%d.proj", i)), (long)D * D, st)));
         LCHK((launch_convert<float, T>(M(h, p + "mlp.fc1.weight"), Pm<T>(h, S("blk%d.fc1", i)), (long)4 * D * D, st)));
         LCHK((launch_convert<float, T>(M(h, p + "mlp.fc2.weight"), Pm<T>(h, S("blk%d.fc2", i)), (long)4 * D * D, st)));
+        if constexpr (std::is_same<T, f16>::value) {
+            LCHK(launch_fold_ln<f16>(M(h, p + "attn.qkv.weight"), M(h, p + "norm1.weight"), M(h, p + "norm1.bias"), M(h, p + "attn.qkv.bias"),
+                                     Pm<T>(h, S("blk%d.qkvf", i)), A(h, S("blk%d.qkv.c", i)), A(h, S("blk%d.qkv.bf", i)), 3 * D, D, st));
+            LCHK(launch_fold_ln<f16>(M(h, p + "mlp.fc1.weight"), M(h, p + "norm2.weight"), M(h, p + "norm2.bias"), M(h, p + "mlp.fc1.bias"),
+                                     Pm<T>(h, S("blk%d.fc1f", i)), A(h, S("blk%d.fc1.c", i)), A(h, S("blk%d.fc1.bf", i)), 4 * D, D, st));
+        }
     }
     // output projections: [c0][D] x n_taps -> [c0][n_taps*D]
     for (int k = 0; k < c.n_taps; k++)
@@ -361,6 +372,7 @@ struct Plan {
     size_t total = 0;
     size_t base = 0;          // byte offset of this plan inside the workspace arena (batch-split mode places two plans side by side)
     size_t patches, x, xn, q, k, vT, attn, hidden, tapcat, cls, mlp1, mlp2, metric, feat, neck[MOGE_LEVELS], scratch[3];
+    size_t ln_part, ln_mr;    // LN fold: (sum, sum of squares) per row and 32-column group; (mean, rstd) per row
     size_t maskprob, focal, shift, intr, pts_tmp, nrm_tmp, post_end;
     int B, H, W, rows, cols, Np, Ntok, Npad;
     size_t scratch_elems;
@@ -390,6 +402,8 @@ static Plan make_plan(const moge_config& c, int prec, int B, int H, int W, int r
     p.patches = take(p, BP * KPATCH_PAD * s);
     p.x = take(p, BN * D * 4);
     p.xn = take(p, BN * D * s);
+    p.ln_part = take(p, BN * (size_t)(D / 32) * 8);
+    p.ln_mr = take(p, BN * 8);
     p.q = take(p, BN * D * s);
     p.k = take(p, BN * D * s);
     p.vT = take(p, (size_t)B * D * p.Npad * s);
@@ -588,18 +602,32 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     if (!attn_pp) HIPCHK(hipMemsetAsync(vT, 0, (size_t)B * D * Npad * sizeof(T), st));      // zero the key padding of V^T
 
     // ---- ViT blocks (block.py:110-112) -----------------------------------------------------------------------------
+    // LN fold (fp16 path): norm1 / norm2 never run as kernels.  LN(x) W^T + b = rstd (x W'^T - mean c) + b' with W' = g (.) W: the qkv and
+    // fc1 GEMMs read the fp16 COPY of the raw residual (written by the previous RESID epilogue next to its (sum, sum of squares) partials)
+    // and apply (mean, rstd) in their epilogues.  Removes 2 x 0.7 GB of LayerNorm traffic per block; the final-norm taps still run
+    // layernorm_kernel on the fp32 residual.  The statistics' summation tree is the same in gemm.hip and gemm_pp.hip (batch invariance).
+    const bool ln_fold = std::is_same<T, f16>::value && (D % 64) == 0 && moge_tune_get("LN_FOLD", 1) != 0;
+    float* ln_part = (float*)(ws + pl.ln_part);
+    float* ln_mr = (float*)(ws + pl.ln_mr);
     int tap_k = 0;
     for (int i = 0; i < L; i++) {
         const std::string p = bb + S("blocks.%d.", i);
-        {
+        if (!ln_fold) {
             ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * D * (4 + sizeof(T)));
             LCHK(launch_layernorm<T>(x, M(h, p + "norm1.weight"), M(h, p + "norm1.bias"), xn, nullptr, BN, D, D, 0, 0, Ntok, st));
+        } else if (i == 0) {
+            ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * D * (4 + sizeof(T)));
+            LCHK(launch_ln_raw<f16>(x, xn, ln_mr, BN, D, st));          // tokens0 come from the patch-embed epilogue: copy + statistics
+        } else {
+            ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * (D / 32) * 8);
+            LCHK(launch_ln_finalize(ln_part, ln_mr, BN, D / 32, D, st));   // partials of block i-1's fc2 epilogue
         }
         {
             GemmArgs g = gemm_args();
-            g.a = xn; g.lda = D; g.w = P<T>(h, S("blk%d.qkv", i)); g.ldw = D;
+            g.a = xn; g.lda = D; g.w = P<T>(h, S(ln_fold ? "blk%d.qkvf" : "blk%d.qkv", i)); g.ldw = D;
             g.M = (int)BN; g.N = 3 * D; g.K = D;
             g.epi = EPI_QKV; g.bias = M(h, p + "attn.qkv.bias"); g.q = qb; g.k = kb; g.vT = vT;
+            if (ln_fold) { g.bias = A(h, S("blk%d.qkv.bf", i)); g.ln_mr = ln_mr; g.ln_c = A(h, S("blk%d.qkv.c", i)); }
             g.nh = nh; g.Npad = Npad; g.D = D; g.Ntok = Ntok; g.v_rowmajor = attn_pp ? 1 : 0;
             g.qscale = 0.125f * 1.4426950408889634f;       // 1/sqrt(64) * log2(e): attention works in exp2
             CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
@@ -614,17 +642,22 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
             g.a = attn; g.lda = D; g.w = P<T>(h, S("blk%d.proj", i)); g.ldw = D;
             g.M = (int)BN; g.N = D; g.K = D;
             g.epi = EPI_RESID; g.bias = M(h, p + "attn.proj.bias"); g.xres = x; g.ldc = D; g.gamma = M(h, p + "ls1.gamma");
+            if (ln_fold) { g.x16 = xn; g.ln_part = ln_part; }
             CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
         }
-        {
+        if (!ln_fold) {
             ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * D * (4 + sizeof(T)));
             LCHK(launch_layernorm<T>(x, M(h, p + "norm2.weight"), M(h, p + "norm2.bias"), xn, nullptr, BN, D, D, 0, 0, Ntok, st));
+        } else {
+            ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * (D / 32) * 8);
+            LCHK(launch_ln_finalize(ln_part, ln_mr, BN, D / 32, D, st));
         }
         {
             GemmArgs g = gemm_args();
-            g.a = xn; g.lda = D; g.w = P<T>(h, S("blk%d.fc1", i)); g.ldw = D;
+            g.a = xn; g.lda = D; g.w = P<T>(h, S(ln_fold ? "blk%d.fc1f" : "blk%d.fc1", i)); g.ldw = D;
             g.M = (int)BN; g.N = 4 * D; g.K = D;
             g.epi = EPI_STORE; g.act = ACT_GELU; g.bias = M(h, p + "mlp.fc1.bias"); g.out = hidden; g.ldc = 4 * D;
+            if (ln_fold) { g.bias = A(h, S("blk%d.fc1.bf", i)); g.ln_mr = ln_mr; g.ln_c = A(h, S("blk%d.fc1.c", i)); }
             CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
         }
         {
@@ -632,6 +665,7 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
             g.a = hidden; g.lda = 4 * D; g.w = P<T>(h, S("blk%d.fc2", i)); g.ldw = 4 * D;
             g.M = (int)BN; g.N = D; g.K = 4 * D;
             g.epi = EPI_RESID; g.bias = M(h, p + "mlp.fc2.bias"); g.xres = x; g.ldc = D; g.gamma = M(h, p + "ls2.gamma");
+            if (ln_fold && i + 1 < L) { g.x16 = xn; g.ln_part = ln_part; }
             CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
         }
         for (int k = 0; k < c.n_taps; k++)
