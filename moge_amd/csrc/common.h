@@ -210,6 +210,7 @@ struct GemmArgs {
     float* ln_part;
     const float* ln_mr;
     const float* ln_c;
+    int nt_store;          // gemm_pp: non-temporal stores for the f16 output rows (streaming activations; keeps the residual in the Infinity Cache)
     unsigned long long* dbg_ts;   // gemm_pp128: optional s_memtime stamps of one block (tools/kbench)
     int stagger;           // gemm_pp128: number of start-phase classes (0/1 = off)
     int dbg;               // gemm_pp ablation bits (tools/kbench only): 1 no DMA, 2 no LDS reads, 4 no MFMA, 8 no barriers

@@ -91,7 +91,7 @@ __device__ __forceinline__ void pp_store_rows(const GemmArgs& g, const char* R, 
             f16* p = obase + (size_t)b0 * bstride + (size_t)t0 * 64;
             t0 += 8;
             if (t0 >= Ntok) { t0 -= Ntok; b0 += 1; }
-            if (mw + row < M) *reinterpret_cast<u32x4*>(p) = v;
+            if (mw + row < M) { if (g.nt_store) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); else *reinterpret_cast<u32x4*>(p) = v; }
         }
     } else if constexpr (EPK == EPK_CONVT) {
         const int Cout = g.Cout, pixW = g.pixW, pixH = g.pixH;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void pp_store_rows(const GemmArgs& g, const char* R, 
             const int row = it * 8 + rr;
             const int m = mw + row;
             const u32x4 v = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
-            if (m < M) *reinterpret_cast<u32x4*>(obase + (size_t)m * ldc) = v;
+            if (m < M) { if (g.nt_store) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(obase + (size_t)m * ldc)); else *reinterpret_cast<u32x4*>(obase + (size_t)m * ldc) = v; }
         }
     }
 }
@@ -1166,6 +1166,10 @@ int launch_gemm_pp(const GemmArgs& g0, hipStream_t st) {
     GemmArgs g = g0;
     g.dbg = moge_tune_get("PP_DBG", 0);
     g.stagger = moge_tune_get("PP_STAGGER", 0);
+    {
+        const int nt = moge_tune_get("NT_STORE", 0);        // bit 0: GELU (MLP hidden), bit 1: QKV, bit 2: plain stores
+        g.nt_store = (g.epi == EPI_QKV) ? (nt >> 1) & 1 : (g.act == ACT_GELU ? nt & 1 : (nt >> 2) & 1);
+    }
     const bool wide = (g.N % 256) == 0 && !(g.epi == EPI_QKV && (g.D % 256) != 0);
     switch (epilogue_kind(g)) {
     case EPK_RESID: return launch_pp_any<EPK_RESID>(g, wide, st);
