@@ -163,7 +163,7 @@ def main():
         if prof is not None:
             gm = prof["gemm"]
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
-            res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp128_kernel (ViT qkv/proj/fc1/fc2 + out-proj ping-pong MFMA GEMMs)",
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp128m16_kernel (ViT qkv/proj/fc1/fc2 + out-proj ping-pong MFMA GEMMs, v_mfma_f32_16x16x32_f16)",
                                "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4),
                                "traffic": None, "avg_launch_ms": round(gm["ms"] / max(gm["launches"], 1), 4), "launches": gm["launches"],
                                "algorithmic_bytes_per_launch": round(gm["bytes"] / max(gm["launches"], 1))}

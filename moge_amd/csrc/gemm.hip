@@ -159,6 +159,43 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, int m, int nb
     for (int q = 0; q < 4; q++) epilogue4<T>(g, m, nb + 8 * q, a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
 }
 
+// 16x16x32 accumulators (fp16 LINEAR kernels): two tiles of the same 16 rows covering one 32-column group.  Lane: row m = .. + (lane & 15),
+// columns nb32 + jh*16 + 4*(lane >> 4) .. +3.  The LN-fold producer's summation tree is the one of gemm_pp.hip / epilogue_tile32: quad index
+// c = jh*4 + (lane >> 4); pairs (c, c^1) across lanes +-16, (c, c^2) across lanes +-32, then the two tiles.
+template <typename T>
+__device__ __forceinline__ void epilogue_pair16(const GemmArgs& g, int m, int nb32, int g4, const f32x4& a0, const f32x4& a1) {
+    if (g.epi == EPI_RESID && g.x16) {
+        const bool ok = m < g.M;
+        float u1[2], u2[2];
+#pragma unroll
+        for (int jh = 0; jh < 2; jh++) {
+            const f32x4& a = jh ? a1 : a0;
+            const int n = nb32 + jh * 16 + 4 * g4;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                float* p = g.xres + (size_t)m * g.ldc + n;
+                x = *reinterpret_cast<f32x4*>(p);
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (g.bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[i] = x[i] + resid_term(gm[i], a[i], b[i]);
+                *reinterpret_cast<f32x4*>(p) = x;
+                *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(g.x16) + (size_t)m * g.ldc + n) = f16x4{(f16)x[0], (f16)x[1], (f16)x[2], (f16)x[3]};
+            }
+            float s1, s2;
+            ln_quad_sums(x, s1, s2);
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            u1[jh] = s1; u2[jh] = s2;
+        }
+        if (g4 == 0 && ok) *reinterpret_cast<f32x2*>(g.ln_part + ((size_t)m * (g.N >> 5) + (nb32 >> 5)) * 2) = f32x2{u1[0] + u1[1], u2[0] + u2[1]};
+        return;
+    }
+    epilogue4<T>(g, m, nb32 + 4 * g4, a0[0], a0[1], a0[2], a0[3]);
+    epilogue4<T>(g, m, nb32 + 16 + 4 * g4, a1[0], a1[1], a1[2], a1[3]);
+}
+
 template <typename T, int WM, int WN, int TM, int TN, int AMODE>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     constexpr int NT = 64 * WM * WN;
@@ -374,17 +411,48 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
             __builtin_amdgcn_global_load_lds(GLDS_GPTR(w_src[i] + (size_t)kt * 8 * CH), GLDS_LPTR(dW + i * RSTEP * 128), 16, 0, 0);
     };
 
+    // fp16: v_mfma_f32_16x16x32_f16 (the same instruction and K grouping as gemm_pp128m16: a GEMM's result does not depend on which of the
+    // two kernels its batch size selects); fp32: v_mfma_f32_32x32x2_f32
+    constexpr bool M16 = TT<T>::PREC == 1;
     f32x16 acc[TM][TN];
+    f32x4 acc16[2 * TM][2 * TN];
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * TM; i++)
+#pragma unroll
+        for (int j = 0; j < 2 * TN; j++) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, g4 = lane >> 4;
 
     auto compute = [&](int buf) {
         const char* cA = sA + buf * BM * 128;
         const char* cW = sW + buf * BN * 128;
+        if constexpr (M16) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int cs = 4 * ks + g4;
+                u32x4 af[2 * TM], wf[2 * TN];
+#pragma unroll
+                for (int i = 0; i < 2 * TM; i++) {
+                    const int row = (wm * 2 * TM + i) * 16 + l15;
+                    af[i] = *reinterpret_cast<const u32x4*>(cA + row * 128 + (swz<8>(row, cs) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < 2 * TN; j++) {
+                    const int row = (wn * 2 * TN + j) * 16 + l15;
+                    wf[j] = *reinterpret_cast<const u32x4*>(cW + row * 128 + (swz<8>(row, cs) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 2 * TM; i++)
+#pragma unroll
+                    for (int j = 0; j < 2 * TN; j++) mma16<f16>(acc16[i][j], wf[j], af[i]);
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int cs = 2 * s + hi;
@@ -438,6 +506,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
             compute(cur);
             cur = cur == 2 ? 0 : cur + 1;
         }
+    }
+    if constexpr (M16) {
+#pragma unroll
+        for (int i = 0; i < 2 * TM; i++) {
+            const int m = m0 + (wm * 2 * TM + i) * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < TN; j++) epilogue_pair16<T>(g, m, n0 + (wn * TN + j) * 32, g4, acc16[i][2 * j], acc16[i][2 * j + 1]);
+        }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < TM; i++) {

@@ -230,8 +230,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM]
 }
 
 // ---- 16x16x32 accumulators acc[i][j0 + jj] (128 rows x 64 columns of the wave's tile): row i*16 + (lane & 15), columns jj*16 + 4*(lane >> 4) .. +3 ----
-template <int EPK>
-__device__ __forceinline__ void pp_epilogue16(const GemmArgs& g, f32x4 (&acc)[8][8], int j0, char* smem, int wave, int lane, int mw, int nw) {
+template <int EPKX, int NJT = 8>
+__device__ __forceinline__ void pp_epilogue16(const GemmArgs& g, f32x4 (&acc)[8][NJT], int j0, char* smem, int wave, int lane, int mw, int nw) {
+    constexpr int EPK = EpkBase<EPKX>::K;
+    constexpr bool FOLD = EpkBase<EPKX>::FOLD;
     constexpr int WROWS = 128;
     const int l15 = lane & 15, g4 = lane >> 4;
     char* R = smem + wave * (WROWS * 128);
@@ -273,11 +275,25 @@ __device__ __forceinline__ void pp_epilogue16(const GemmArgs& g, f32x4 (&acc)[8]
             }
         }
         const bool has_bias = g.bias != nullptr;
+        float mu[8], rs[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { mu[i] = 0.f; rs[i] = 1.f; }
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int m = mw + i * 16 + l15;
+                m = m < M ? m : M - 1;
+                const f32x2 t = *reinterpret_cast<const f32x2*>(g.ln_mr + 2 * (size_t)m);
+                mu[i] = t[0]; rs[i] = t[1];
+            }
+        }
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
             const int n = nw + jj * 16 + 4 * g4;
             f32x4 b = {0.f, 0.f, 0.f, 0.f};
             if (has_bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+            f32x4 lc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (FOLD) lc = *reinterpret_cast<const f32x4*>(g.ln_c + n);
             f32x4 wu = {0.f, 0.f, 0.f, 0.f}, wv = wu;
             if constexpr (EPK == EPK_UV) {
                 wu = *reinterpret_cast<const f32x4*>(g.uv.wu + n);
@@ -286,7 +302,7 @@ __device__ __forceinline__ void pp_epilogue16(const GemmArgs& g, f32x4 (&acc)[8]
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int row = i * 16 + l15;
-                const f16x4 hv = pp_quad_f16<EPK>(acc[i][j0 + jj], b, scale, wu, u[i], wv, vv[i]);
+                const f16x4 hv = pp_quad_f16<EPK, FOLD>(acc[i][j0 + jj], b, scale, wu, u[i], wv, vv[i], mu[i], rs[i], lc);
                 *reinterpret_cast<f16x4*>(R + row * 128 + ((((jj * 2 + (g4 >> 1)) ^ (row & 7)) << 4) | ((g4 & 1) << 3))) = hv;
             }
         }
@@ -1084,6 +1100,164 @@ static int launch_pp4w(const GemmArgs& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// gemm_pp128 (A3 rings, 8 waves, ping-pong) with v_mfma_f32_16x16x32_f16: per phase 4 row blocks x 4 column blocks x 2 K-steps of 32
+// = 32 MFMAs (16 cycles each), 8 + 8 fragment reads - the same LDS layout, DMA pieces, waits and barriers as the 32x32x16 kernel;
+// only the fragment addressing (row = block*16 + (lane & 15), chunk = 4*kstep + (lane >> 4)) and the accumulator layout change.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int EPK>
+__global__ __launch_bounds__(512, 2) void gemm_pp128m16_kernel(const GemmArgs g) {
+    constexpr int WN = 4, BM = 256, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * 32 KiB (A ring) + 2 * 32 KiB (W ring)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nbn = g.N / BN;
+    int wg;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    int bm, bn;
+    {
+        const int nbm = (g.M + BM - 1) / BM;
+        const int grp_cols = 4, per_grp = nbm * grp_cols;
+        const int cg = wg / per_grp, rem = wg - cg * per_grp;
+        const int cols = min(grp_cols, nbn - cg * grp_cols);
+        bm = rem / cols;
+        bn = cg * grp_cols + (rem - bm * cols);
+    }
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int nkt = g.K >> 6;
+
+    const int prow = lane >> 3;
+    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) + (lane >> 4));
+    const char* baseW = reinterpret_cast<const char*>(g.w) + (size_t)n0 * g.ldw * 2;
+    const char* baseA = reinterpret_cast<const char*>(g.a) + (size_t)m0 * g.lda * 2;
+    unsigned offW[4], offA[4];     // A: 0,1 = lo rows (8w, 128+8w)   2,3 = hi rows (64+8w, 192+8w)
+    const int mlast = g.M - 1 - m0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        offW[k] = (unsigned)(((wave + 8 * k) * 8 + prow) * g.ldw * 2 + lchunk * 16);
+        int arow = (k & 1) * 128 + (k >> 1) * 64 + wave * 8 + prow;
+        arow = arow < mlast ? arow : mlast;
+        offA[k] = (unsigned)(arow * g.lda * 2 + lchunk * 16);
+    }
+    auto issue_w = [&](int t) {
+        char* base = smem + 98304 + (t & 1) * 32768;
+        const char* gw = uniform_ptr(baseW + (size_t)t * 128);
+#pragma unroll
+        for (int kw = 0; kw < 4; kw++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[kw]), PP_LPTR(base + (wave + 8 * kw) * 1024), 16, 0, 0);
+    };
+    auto issue_a = [&](int t, int slot, int hi_rows) {
+        char* base = smem + slot * 32768;
+        const char* ga = uniform_ptr(baseA + (size_t)t * 128);
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + offA[hi_rows * 2 + k]), PP_LPTR(base + (k * 128 + hi_rows * 64 + wave * 8) * 128), 16, 0, 0);
+    };
+
+    const int sx = (l15 >> 1) & 7;
+    const int a_off = (wm * 128 + l15) * 128 + ((g4 ^ sx) << 4);             // K-step ks (32 halves): a_off ^ (ks * 64); 16-row block i: + i * 2048
+    const int w_off = (wn * 64 + l15) * 128 + ((g4 ^ sx) << 4);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue_w(0); issue_a(0, 0, 0); issue_a(0, 0, 1);
+    if (nkt > 1) { issue_a(1, 1, 0); issue_a(1, 1, 1); issue_w(1); }
+    if (nkt > 2) {
+        issue_a(2, 2, 0);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    } else if (nkt > 1) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x4 af[4][2], wf[4][2];
+    int sa = 0;
+    for (int t = 0; t < nkt; t++) {
+        const char* sl = smem + sa * 32768;
+        const char* slw = smem + 98304 + (t & 1) * 32768;
+        const int sa2 = sa == 0 ? 2 : sa - 1;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            // ======== load segment ========
+            if (half == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) wf[j][ks] = *reinterpret_cast<const u32x4*>(slw + (w_off ^ (ks * 64)) + j * 2048);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 64)) + (half * 4 + i) * 2048);
+            if (half == 0) {
+                if (t + 2 < nkt) issue_a(t + 2, sa2, 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+                if (t + 3 < nkt) {
+                    issue_w(t + 2);
+                    issue_a(t + 3, sa, 0);
+                    asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+                } else if (t + 2 < nkt) {
+                    issue_w(t + 2);
+                    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // ======== compute segment ========
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) mma16<f16>(acc[half * 4 + i][j], wf[j][ks], af[i][ks]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            if (!(grp == 1 && half == 1 && t == nkt - 1)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sa = sa == 2 ? 0 : sa + 1;
+    }
+    pp_epilogue16<EPK, 4>(g, acc, 0, smem, wave, lane, m0 + wm * 128, n0 + wn * 64);
+}
+
+template <int EPK>
+static int launch_pp128m16(const GemmArgs& g, hipStream_t st) {
+    constexpr int smem = 163840;
+    static bool attr_set = false;
+    auto kern = gemm_pp128m16_kernel<EPK>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long nbm = (g.M + 255) / 256, nbn = g.N / 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(512), smem, st, g);
+    return (int)hipGetLastError();
+}
+
 template <int EPK, int A3>
 static int launch_pp128_cfg(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = A3 ? 163840 : 2 * 65536;
@@ -1101,6 +1275,7 @@ static int launch_pp128_cfg(const GemmArgs& g, hipStream_t st) {
 template <int EPK>
 static int launch_pp128(const GemmArgs& g, hipStream_t st) {
     const int w4 = moge_tune_get("PP_4W", 0);
+    if (w4 == 3 || (w4 == 0 && moge_tune_get("PP_M16", 1))) return launch_pp128m16<EPK>(g, st);
     if (w4 == 2) return launch_pp4w<EPK, 1>(g, st);
     if (w4) return launch_pp4w<EPK, 0>(g, st);
     const int a3 = moge_tune_get("PP_A3", 1);
@@ -1126,6 +1301,10 @@ static int launch_pp_cfg(const GemmArgs& g, hipStream_t st) {
 // Shapes / epilogues the ping-pong kernel takes (f16, LINEAR mode only).  bn256 = prefer the 256-wide tile.
 bool gemm_pp_eligible(const GemmArgs& g) {
     if (g.relu_in || g.add) return false;
+    // PP_M16 (default): the 256x256 kernel runs on v_mfma_f32_16x16x32_f16, like the 128x128 latency-regime kernel of gemm.hip.  The
+    // 64-byte-row kernels (N % 256 != 0 or K % 64 != 0) still accumulate in the 32x32x16 order, so they are left out: those shapes go to
+    // gemm.hip at every batch size and a GEMM's result never depends on the batch-size-driven kernel choice.
+    if (moge_tune_get("PP_M16", 1) && ((g.N % 256) || (g.K & 63) || (g.epi == EPI_QKV && (g.D % 256)))) return false;
     if (g.ln_mr) {          // LN-fold consumer: QKV / GELU flavours of the 256x256 kernel
         if ((g.N % 256) || (g.K & 63) || !g.ln_c || !g.bias) return false;
         if (!(g.epi == EPI_QKV ? (g.D % 256) == 0 : (g.epi == EPI_STORE && g.act == ACT_GELU && !g.uv.wu))) return false;
@@ -1177,8 +1356,9 @@ int launch_gemm_pp(const GemmArgs& g0, hipStream_t st) {
     case EPK_CONVT: return launch_pp_any<EPK_CONVT>(g, wide, st);
     case EPK_UV: return launch_pp_any<EPK_UV>(g, wide, st);
     case EPK_GELU: return launch_pp_any<EPK_GELU>(g, wide, st);
-    case EPK_GELU_LN: return launch_pp128_cfg<EPK_GELU_LN, 1>(g, st);       // LN-fold consumers: the 256x256 kernel only (gemm_pp_eligible)
-    case EPK_QKV_LN: return launch_pp128_cfg<EPK_QKV_LN, 1>(g, st);
+    case EPK_GELU_LN:       // LN-fold consumers: the 256x256 kernels only (gemm_pp_eligible)
+        return moge_tune_get("PP_M16", 1) ? launch_pp128m16<EPK_GELU_LN>(g, st) : launch_pp128_cfg<EPK_GELU_LN, 1>(g, st);
+    case EPK_QKV_LN: return moge_tune_get("PP_M16", 1) ? launch_pp128m16<EPK_QKV_LN>(g, st) : launch_pp128_cfg<EPK_QKV_LN, 1>(g, st);
     case EPK_RELU: return launch_pp_any<EPK_RELU>(g, wide, st);
     default: return launch_pp_any<EPK_STORE>(g, wide, st);
     }

@@ -150,9 +150,9 @@ static int bench_gemm(const char* filter, int iters) {
         {"b4.fc2", 4 * Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
     };
     struct Variant { const char* name; int pp, glds, dbg, row128, stagger; int a3 = 1; int w4 = 0; };
-    std::vector<Variant> variants = {{"old-glds2", 0, 2, 0, 0}, {"pp64", 1, 2, 0, 0}, {"pp128", 1, 2, 0, 1}};
+    std::vector<Variant> variants = {{"glds2-m16", 0, 2, 0, 0}, {"pp64", 1, 2, 0, 0}, {"pp128-a3", 1, 2, 0, 1}, {"pp128-m16", 1, 2, 0, 1, 0, 1, 3}};
     if (getenv("KB_A3")) variants = {{"pp128-2buf", 1, 2, 0, 1, 0, 0}, {"pp128-a3", 1, 2, 0, 1, 0, 1}, {"pp128-a3c", 1, 2, 0, 1, 0, 2}};
-    if (getenv("KB_4W")) variants = {{"pp128-a3", 1, 2, 0, 1, 0, 1, 0}, {"pp4w", 1, 2, 0, 1, 0, 1, 1}, {"pp4w-16", 1, 2, 0, 1, 0, 1, 2}};
+    if (getenv("KB_4W")) variants = {{"pp128-a3", 1, 2, 0, 1, 0, 1, 0}, {"pp4w", 1, 2, 0, 1, 0, 1, 1}, {"pp4w-16", 1, 2, 0, 1, 0, 1, 2}, {"pp128-m16", 1, 2, 0, 1, 0, 1, 3}};
     if (getenv("KB_NARROW")) variants = {{"pp128", 1, 2, 0, 1, 0}, {"pp64-2wg", 1, 2, 0, 1, 100}};
     if (getenv("KB_STAGGER")) variants = {{"pp128", 1, 2, 0, 1, 0}, {"pp128-stg2", 1, 2, 0, 1, 2}, {"pp128-stg4", 1, 2, 0, 1, 4}, {"pp128-stg8", 1, 2, 0, 1, 8}};
     if (getenv("KB_ABLATE")) {
@@ -215,6 +215,7 @@ static int bench_gemm(const char* filter, int iters) {
             moge_tune_set("PP_NARROW", v.stagger == 100 ? 1 : 0);
             moge_tune_set("PP_A3", v.a3);
             moge_tune_set("PP_4W", v.w4);
+            moge_tune_set("PP_M16", v.w4 == 3 ? 1 : 0);
             // correctness: one launch on fresh buffers
             CK(hipMemsetAsync(out, 0, out_elems * 2, st));
             if (x) CK(hipMemcpyAsync(x, x0, M * N * 4, hipMemcpyDeviceToDevice, st));
@@ -253,7 +254,7 @@ static int bench_gemm(const char* filter, int iters) {
                     const Variant& v = variants[vi];
                     moge_tune_set("GEMM_PP", v.pp); moge_tune_set("GLDS_VARIANT", v.glds); moge_tune_set("PP_DBG", v.dbg); moge_tune_set("PP_ROW128", v.row128);
                     moge_tune_set("PP_STAGGER", v.stagger == 100 ? 0 : v.stagger); moge_tune_set("PP_NARROW", v.stagger == 100 ? 1 : 0);
-                    moge_tune_set("PP_A3", v.a3); moge_tune_set("PP_4W", v.w4);
+                    moge_tune_set("PP_A3", v.a3); moge_tune_set("PP_4W", v.w4); moge_tune_set("PP_M16", v.w4 == 3 ? 1 : 0);
                     const double ms = time_launches(g, iters, st);
                     sum[vi] += ms; mn[vi] = ms < mn[vi] ? ms : mn[vi];
                 }
