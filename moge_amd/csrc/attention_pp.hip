@@ -284,6 +284,269 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && QT == 1) ? 3 : 2) void attn_pp
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same kernel on v_mfma_f32_16x16x32_f16 (tools/mfma_power: the cheaper instruction per FLOP on this power-limited chip).
+// A wave still owns 32 queries, now as two 16-query column blocks; lane = (query l15, key/d group g4 = lane >> 4):
+//   S^T tile (kb, qb) = K[16 keys] Q[16 queries]^T over d in two K-steps of 32;  D: lane holds keys 4*g4 + r of key block kb.
+//   Key block kb, row rho = 4*g + r  <->  key 32*(kb >> 1) + 8*g + 4*(kb & 1) + r  (a row permutation applied when the K fragment is
+//   read), so that tiles (2s, 2s+1) of a lane are exactly keys 32s + 8*g4 + 0..7: converted to fp16 they ARE the B operand of the
+//   O^T += V^T P^T step s (16 queries x 32 keys, lane = query, 8 keys per lane) - no cross-lane movement, as in the 32x32 kernel.
+//   V^T operand (16 d x 32 keys): two ds_read_b64_tr_b16 per lane (keys 8*g4 + 0..3 / + 4..7 of the step, the group's 16 d's).
+// LDS swizzles (rows of 128 B, 16-byte chunks): K: chunk ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1));  V: chunk ^ ((((row >> 1) & 1) << 1) |
+// (((row >> 3) & 1) << 2)) - both reads conflict-free for these lane patterns.  Softmax state is per (lane, query block); the four lanes
+// of a query combine their partial sums / maxima with two shuffles where the exact path needs them.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
+                                                           f16* __restrict__ out, int Ntok, int nh) {
+    constexpr int NW = 4, NPW = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * AP_STAGE
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int bh = blockIdx.y;
+    const int b = bh / nh, head = bh - b * nh;
+    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+
+    // ---- Q fragments (B operand of S^T): lane = query, d = 32*ks + 8*g4 .. + 7 ----------------------------------------------
+    u32x4 qf[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+        const int qrow = q0 + qb * 16 + l15;
+        const f16* qp = q + ((size_t)bh * Ntok + (qrow < Ntok ? qrow : Ntok - 1)) * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) qf[qb][ks] = *reinterpret_cast<const u32x4*>(qp + 32 * ks + 8 * g4);
+    }
+
+    // ---- DMA sources (as attn_pp_kernel; the swizzles differ) ----------------------------------------------------------------
+    const char* kbase = reinterpret_cast<const char*>(k + (size_t)bh * Ntok * 64);
+    const char* vbase = reinterpret_cast<const char*>(v + (size_t)bh * Ntok * 64);
+    const int prow = lane >> 3, pch = lane & 7;
+    int drow[NPW];
+    unsigned doff[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; i++) {
+        const int p = wave + NW * i;                     // 0..15: K pieces 0-7, V pieces 8-15
+        const int row = (p & 7) * 8 + prow;
+        drow[i] = row;
+        const int ksw = ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
+        const int vsw = (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
+        doff[i] = (unsigned)(row * 128 + ((pch ^ (p >= 8 ? vsw : ksw)) << 4));
+    }
+    const int ntiles = (Ntok + 63) >> 6;
+    auto issue = [&](int t) {
+        char* st = smem + (t % 3) * AP_STAGE;
+        const char* kt = uniform_ptr(kbase + (size_t)t * 8192);
+        const char* vt = uniform_ptr(vbase + (size_t)t * 8192);
+        if (t < ntiles - 1) {
+#pragma unroll
+            for (int i = 0; i < NPW; i++) {
+                const int p = wave + NW * i;
+                __builtin_amdgcn_global_load_lds(AP_GPTR((p >= 8 ? vt : kt) + doff[i]), AP_LPTR(st + p * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPW; i++) {
+                const int p = wave + NW * i;
+                const int over = t * 64 + drow[i] - (Ntok - 1);
+                const unsigned off = doff[i] - (over > 0 ? (unsigned)over * 128u : 0u);
+                __builtin_amdgcn_global_load_lds(AP_GPTR((p >= 8 ? vt : kt) + off), AP_LPTR(st + p * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- LDS read addresses (bytes inside a stage) -----------------------------------------------------------------------
+    // K fragment (kb, ks): row = 32*(kb >> 1) + 4*(kb & 1) + 8*(l15 >> 2) + (l15 & 3) [immediate part: (32*(kb>>1) + 4*(kb&1)) * 128], chunk (4*ks + g4) ^ ksw
+    const int kswl = ((l15 >> 1) & 1) | ((l15 >> 2) << 1);
+    int kaddr[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) kaddr[ks] = (8 * (l15 >> 2) + (l15 & 3)) * 128 + (((4 * ks + g4) ^ kswl) << 4);
+    // V^T fragment (s, db), half h: supplier lane li of group g4: key row 32*s + 8*g4 + 4*h + (li >> 2), bytes 32*db + 8*(li & 3) .. + 7
+    const int vswl = (((l15 >> 3) & 1) << 1) | ((g4 & 1) << 2);
+    int vaddr[4];
+#pragma unroll
+    for (int db = 0; db < 4; db++)
+        vaddr[db] = 8192 + (8 * g4 + (l15 >> 2)) * 128 + ((((2 * db) ^ vswl) | ((l15 & 3) >> 1)) << 4) + (l15 & 1) * 8;
+
+    f32x4 o[4][2];                      // [d block][query block]
+    f32x4 negs[2];                      // -m splat per query block (C operand of the first MFMA of a K Q^T chain)
+    float m_run[2], l_run[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+#pragma unroll
+        for (int db = 0; db < 4; db++) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        negs[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m_run[qb] = -1e30f; l_run[qb] = 0.f;
+    }
+
+    issue(0);
+    if (ntiles > 1) issue(1);
+
+    // Control flow: the hot loop contains ONLY the fast path; the first tile, the last tile and a tile whose lane sum trips the overflow
+    // guard leave it for the exact body (written once, outside).  With the exact body inside the loop the register allocator kept two
+    // copies of O / l / -m / S and paid ~60 register moves per tile on the fast edge.  Every path executes exactly one barrier per tile.
+    int stage = 0;
+    const char* ka[2];
+    const char* va[4];
+    f32x4 sc[4][2];                  // [key block][query block]
+    float psum[2];
+    auto tile_head = [&](int t) {         // tile t landed for every wave; every wave is done with tile t-1; keep two tiles in flight
+        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntiles) issue(t + 2);
+        const int so = stage * AP_STAGE;
+        stage = stage == 2 ? 0 : stage + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) ka[ks] = smem + (kaddr[ks] + so);
+#pragma unroll
+        for (int db = 0; db < 4; db++) va[db] = smem + (vaddr[db] + so);
+    };
+    auto pv = [&]() {                // O^T += V^T P^T: two steps of 32 keys; the P^T operand of step s is tiles (2s, 2s+1) of the lane
+#pragma unroll
+        for (int qb = 0; qb < 2; qb++) l_run[qb] += psum[qb];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            u32x4 pf[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; qb++) {
+                f16x8 hp;
+#pragma unroll
+                for (int r = 0; r < 4; r++) { hp[r] = (f16)sc[2 * s2][qb][r]; hp[4 + r] = (f16)sc[2 * s2 + 1][qb][r]; }
+                pf[qb] = __builtin_bit_cast(u32x4, hp);
+            }
+#pragma unroll
+            for (int db = 0; db < 4; db++) {
+                const u32x4 vf = tr_pair(va[db] + (32 * s2) * 128, va[db] + (32 * s2 + 4) * 128);
+#pragma unroll
+                for (int qb = 0; qb < 2; qb++) mma16<f16>(o[db][qb], vf, pf[qb]);
+            }
+        }
+    };
+    auto exact_body = [&](int t, bool last) {      // raise m to the true running max, rescale O and l, P = exp2(s - m)
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) {
+            const int koff = (32 * (kb >> 1) + 4 * (kb & 1)) * 128;
+            const u32x4 kf0 = *reinterpret_cast<const u32x4*>(ka[0] + koff), kf1 = *reinterpret_cast<const u32x4*>(ka[1] + koff);
+#pragma unroll
+            for (int qb = 0; qb < 2; qb++) {
+                sc[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                mma16<f16>(sc[kb][qb], kf0, qf[qb][0]);
+                mma16<f16>(sc[kb][qb], kf1, qf[qb][1]);
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; qb++) {
+            if (last) {
+#pragma unroll
+                for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int key = t * 64 + 32 * (kb >> 1) + 8 * g4 + 4 * (kb & 1) + r;
+                        if (key >= Ntok) sc[kb][qb][r] = -1e30f;
+                    }
+            }
+            float mx = sc[0][qb][0];
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) mx = fmaxf(mx, sc[kb][qb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[qb], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+            m_run[qb] = m_new;
+            l_run[qb] *= alpha;
+#pragma unroll
+            for (int db = 0; db < 4; db++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[db][qb][r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 4; r++) negs[qb][r] = -m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    sc[kb][qb][r] = __builtin_amdgcn_exp2f(sc[kb][qb][r] - m_new);
+                    ps += sc[kb][qb][r];
+                }
+            psum[qb] = ps;
+        }
+        pv();
+    };
+
+    tile_head(0);
+    exact_body(0, ntiles == 1);
+    int t = 1;
+    for (;;) {
+        bool hit = false;
+        for (; t < ntiles - 1; t++) {                // ---- hot loop: S^T - m = K Q^T + (-m);  P = exp2(.) ----
+            tile_head(t);
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++) {
+                const int koff = (32 * (kb >> 1) + 4 * (kb & 1)) * 128;
+                const u32x4 kf0 = *reinterpret_cast<const u32x4*>(ka[0] + koff), kf1 = *reinterpret_cast<const u32x4*>(ka[1] + koff);
+#pragma unroll
+                for (int qb = 0; qb < 2; qb++) {
+                    sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf0), __builtin_bit_cast(f16x8, qf[qb][0]), negs[qb], 0, 0, 0);
+                    mma16<f16>(sc[kb][qb], kf1, qf[qb][1]);
+                }
+            }
+            bool trig = false;
+#pragma unroll
+            for (int qb = 0; qb < 2; qb++) {
+                float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        sc[kb][qb][r] = __builtin_amdgcn_exp2f(sc[kb][qb][r]);
+                        if (kb & 1) ps1 += sc[kb][qb][r]; else ps0 += sc[kb][qb][r];
+                    }
+                psum[qb] = ps0 + ps1;
+                trig |= !(psum[qb] < AP_PSUM_LIMIT);
+            }
+            if (__builtin_expect(__any(trig), 0)) { hit = true; break; }
+            pv();
+        }
+        if (!hit) break;
+        exact_body(t, false);                        // tile t again from LDS (its barrier and DMA issue are done)
+        t++;
+    }
+    if (ntiles > 1) {
+        tile_head(ntiles - 1);
+        exact_body(ntiles - 1, true);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+        float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 16);
+        l_tot += __shfl_xor(l_tot, 32);
+        const float inv = 1.f / l_tot;
+        const int qrow = q0 + qb * 16 + l15;
+        if (qrow < Ntok) {
+            f16* op = out + ((size_t)b * Ntok + qrow) * ((size_t)nh * 64) + head * 64;
+#pragma unroll
+            for (int db = 0; db < 4; db++)
+                store4(op + 16 * db + 4 * g4, o[db][qb][0] * inv, o[db][qb][1] * inv, o[db][qb][2] * inv, o[db][qb][3] * inv);
+        }
+    }
+}
+
+static int launch_attn_pp16(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
+    constexpr int smem = 3 * AP_STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((Ntok + 127) / 128, B * nh);
+    hipLaunchKernelGGL(attn_pp16_kernel, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
+    return (int)hipGetLastError();
+}
+
 template <int NW, int QT>
 static int launch_attn_pp_cfg(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
     constexpr int smem = 3 * AP_STAGE;
@@ -302,6 +565,7 @@ static int launch_attn_pp_cfg(const void* q, const void* k, const void* v, void*
 // q, k, v: (B, nh, Ntok, 64) fp16 (q pre-scaled by log2(e)/8); out: (B, Ntok, nh*64) fp16
 int launch_attention_pp(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
     if (Ntok < 1) return -1;
+    if (moge_tune_get("ATTN_M16", 1)) return launch_attn_pp16(q, k, v, out, B, nh, Ntok, st);
     if (moge_tune_get("ATTN_QT", 1) == 2) return launch_attn_pp_cfg<4, 2>(q, k, v, out, B, nh, Ntok, st);
     if (moge_tune_get("ATTN_NW", 4) == 8) return launch_attn_pp_cfg<8, 1>(q, k, v, out, B, nh, Ntok, st);
     return launch_attn_pp_cfg<4, 1>(q, k, v, out, B, nh, Ntok, st);
