@@ -25,12 +25,12 @@ def main(tag):
     W = load(os.path.join(ROOT, "profiles", f"{tag}_pmc_WRITE_SIZE.csv"))
     calls = fb = wb = 0
     for k, (c, f) in F.items():
-        if "gemm_pp128" in k[0] and k[1] >= 1000 and k in W:
+        if "gemm_pp128" in k[0] and k[1] >= 1000 and k in W:      # gemm_pp128m16_kernel<EPK> (and the 32x32x16 gemm_pp128_kernel of earlier rounds)
             calls += c
             fb += c * f * 1024 * 2
             wb += c * W[k][1] * 1024
     out = {
-        "kernel": "gemm_pp128_kernel", "launches": calls,
+        "kernel": "gemm_pp128m16_kernel", "launches": calls,
         "fetch_bytes_per_launch": round(fb / calls), "write_bytes_per_launch": round(wb / calls),
         "traffic_bytes_per_launch": round((fb + wb) / calls),
         "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs, --kernel-trace only) of `python bench.py --steps 3 "
