@@ -296,6 +296,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && QT == 1) ? 3 : 2) void attn_pp
 // (((row >> 3) & 1) << 2)) - both reads conflict-free for these lane patterns.  Softmax state is per (lane, query block); the four lanes
 // of a query combine their partial sums / maxima with two shuffles where the exact path needs them.
 // ------------------------------------------------------------------------------------------------------------------------
+template <int ABL>      // ABL (tools/kbench only): 1 = the hot loop's exp2 replaced by one multiply (what the transcendental costs)
 __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
                                                            f16* __restrict__ out, int Ntok, int nh) {
     constexpr int NW = 4, NPW = 4;
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
                 for (int kb = 0; kb < 4; kb++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        sc[kb][qb][r] = __builtin_amdgcn_exp2f(sc[kb][qb][r]);
+                        sc[kb][qb][r] = ABL == 1 ? sc[kb][qb][r] * 1e-3f : __builtin_amdgcn_exp2f(sc[kb][qb][r]);
                         if (kb & 1) ps1 += sc[kb][qb][r]; else ps0 += sc[kb][qb][r];
                     }
                 psum[qb] = ps0 + ps1;
@@ -538,12 +539,17 @@ static int launch_attn_pp16(const void* q, const void* k, const void* v, void* o
     constexpr int smem = 3 * AP_STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((Ntok + 127) / 128, B * nh);
-    hipLaunchKernelGGL(attn_pp16_kernel, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
+    if (moge_tune_get("ATTN_ABL", 0) == 1)
+        hipLaunchKernelGGL(attn_pp16_kernel<1>, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
+    else
+        hipLaunchKernelGGL(attn_pp16_kernel<0>, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
     return (int)hipGetLastError();
 }
 
