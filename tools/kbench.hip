@@ -364,7 +364,7 @@ static int bench_attn(int iters) {
         ref_attn<<<ns, 256, 0, st>>>(q, k, v, dbh, dq, c.Ntok, ref);
         CK(hipStreamSynchronize(st));
         struct Var { const char* name; int kind, nw, qt, m16, abl; };
-        const Var vars[] = {{"old(vT)", 0, 0, 1, 0, 0}, {"pp nw4", 1, 4, 1, 0, 0}, {"pp16", 1, 4, 1, 1, 0}, {"pp16-noexp", 1, 4, 1, 1, 1}, {"pp16", 1, 4, 1, 1, 0}, {"pp16-noexp", 1, 4, 1, 1, 1}};
+        const Var vars[] = {{"old(vT)", 0, 0, 1, 0, 0}, {"pp nw4", 1, 4, 1, 0, 0}, {"pp16", 1, 4, 1, 1, 0}, {"pp16-noexp", 1, 4, 1, 1, 1}};
         for (const Var& va : vars) {
             moge_tune_set("ATTN_NW", va.nw);
             moge_tune_set("ATTN_QT", va.qt);
