@@ -606,6 +606,10 @@ int launch_gemm(const GemmArgs& g, int amode, hipStream_t st) {
             }
         }
         if (g.N > 64 && !g.relu_in && (g.K % (8 * TT<T>::CH)) == 0 && !g_disable_glds) {
+            // latency regime: when 128x128 tiles do not even give every CU two workgroups, halve the tile rows (64x128, 48 KiB LDS: up to three
+            // co-resident workgroups per CU hide each other's DMA / LDS latency).  Same MFMA and K order: results are bit-identical.
+            const long blocks128 = ((long)(g.M + 127) / 128) * ((g.N + 127) / 128);
+            if (blocks128 < moge_tune_get("GLDS_SMALL_BLOCKS", 512) && moge_tune_get("GLDS_VARIANT", 2) == 2) return launch_glds<T, 2, 2, 1, 2, 2>(g, st);
             switch (moge_tune_get("GLDS_VARIANT", 2)) {
             case 1: return launch_glds<T, 2, 2, 2, 2, 1>(g, st);       // 128x128, single buffer
             case 2: return launch_glds<T, 2, 2, 2, 2, 2>(g, st);       // 128x128, double buffer
