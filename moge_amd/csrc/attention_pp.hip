@@ -541,14 +541,8 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
 
 static int launch_attn_pp16(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
     constexpr int smem = 3 * AP_STAGE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc = set_dyn_lds<attn_pp16_kernel<0>>(smem)) return rc;
+    if (int rc = set_dyn_lds<attn_pp16_kernel<1>>(smem)) return rc;
     dim3 grid((Ntok + 127) / 128, B * nh);
     if (moge_tune_get("ATTN_ABL", 0) == 1)
         hipLaunchKernelGGL(attn_pp16_kernel<1>, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
@@ -560,13 +554,8 @@ static int launch_attn_pp16(const void* q, const void* k, const void* v, void* o
 template <int NW, int QT>
 static int launch_attn_pp_cfg(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
     constexpr int smem = 3 * AP_STAGE;
-    static bool attr_set = false;
-    auto kern = attn_pp_kernel<NW, QT>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    constexpr auto kern = attn_pp_kernel<NW, QT>;
+    if (int rc = set_dyn_lds<kern>(smem)) return rc;
     dim3 grid((Ntok + NW * 32 * QT - 1) / (NW * 32 * QT), B * nh);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
     return (int)hipGetLastError();

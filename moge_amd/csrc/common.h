@@ -216,6 +216,22 @@ struct GemmArgs {
     int dbg;               // gemm_pp ablation bits (tools/kbench only): 1 no DMA, 2 no LDS reads, 4 no MFMA, 8 no barriers
 };
 
+// Opt a kernel into more than 64 KiB of dynamic LDS.  The attribute is per DEVICE and a process may drive several (one host thread per
+// GPU is a supported deployment): remember it per (kernel, device), not per process.
+template <auto Kern>
+inline int set_dyn_lds(int bytes) {
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+    return 0;
+}
+
 // host-side launchers (gemm.hip, gemm_pp.hip)
 template <typename T> int launch_gemm(const GemmArgs& g, int amode, hipStream_t st);
 bool gemm_pp_eligible(const GemmArgs& g);

@@ -331,13 +331,8 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
 template <int BN, int TW, int NH, int EPI>
 int launch_conv_cfg(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = NH * Halo<TW>::BYTES + 4 * BN * 128;
-    static bool attr_set = false;
-    auto kern = conv_pp_kernel<BN, TW, NH, EPI>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    constexpr auto kern = conv_pp_kernel<BN, TW, NH, EPI>;
+    if (int rc = set_dyn_lds<kern>(smem)) return rc;
     const long B = (long)g.M / ((long)g.H * g.W);
     const long tiles = B * ((g.H + 15) / 16) * ((g.W + TW - 1) / TW) * (g.N / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), smem, st, g);

@@ -531,13 +531,8 @@ template <typename T, int WM, int WN, int TM, int TN, int NSTAGE>
 static int launch_glds(const GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int smem = NSTAGE * (BM + BN) * 128;
-    static bool attr_set = false;
-    auto kern = gemm_glds_kernel<T, WM, WN, TM, TN, NSTAGE>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    constexpr auto kern = gemm_glds_kernel<T, WM, WN, TM, TN, NSTAGE>;
+    if (int rc = set_dyn_lds<kern>(smem)) return rc;
     const long nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(64 * WM * WN), smem, st, g);
     return (int)hipGetLastError();
@@ -547,13 +542,8 @@ template <typename T, int WM, int WN, int TM, int TN, int AMODE>
 static int launch_cfg(const GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int smem = 2 * (BM + BN) * 128;
-    static bool attr_set = false;
-    auto kern = gemm_kernel<T, WM, WN, TM, TN, AMODE>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    constexpr auto kern = gemm_kernel<T, WM, WN, TM, TN, AMODE>;
+    if (int rc = set_dyn_lds<kern>(smem)) return rc;
     const long nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(64 * WM * WN), smem, st, g);
     return (int)hipGetLastError();

@@ -1088,13 +1088,8 @@ __global__ __launch_bounds__(256, 1) void gemm_pp4w16_kernel(const GemmArgs g) {
 template <int EPK, int MF16>
 static int launch_pp4w(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = 163840;
-    static bool attr_set = false;
-    auto kern = MF16 ? gemm_pp4w16_kernel<EPK> : gemm_pp4w_kernel<EPK>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    constexpr auto kern = MF16 ? gemm_pp4w16_kernel<EPK> : gemm_pp4w_kernel<EPK>;
+    if (int rc = set_dyn_lds<kern>(smem)) return rc;
     const long nbm = (g.M + 255) / 256, nbn = g.N / 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(256), smem, st, g);
     return (int)hipGetLastError();
@@ -1246,13 +1241,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128m16_kernel(const GemmArgs g)
 template <int EPK>
 static int launch_pp128m16(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = 163840;
-    static bool attr_set = false;
-    auto kern = gemm_pp128m16_kernel<EPK>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    constexpr auto kern = gemm_pp128m16_kernel<EPK>;
+    if (int rc = set_dyn_lds<kern>(smem)) return rc;
     const long nbm = (g.M + 255) / 256, nbn = g.N / 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(512), smem, st, g);
     return (int)hipGetLastError();
@@ -1261,13 +1251,8 @@ static int launch_pp128m16(const GemmArgs& g, hipStream_t st) {
 template <int EPK, int A3>
 static int launch_pp128_cfg(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = A3 ? 163840 : 2 * 65536;
-    static bool attr_set = false;
-    auto kern = gemm_pp128_kernel<EPK, A3>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    constexpr auto kern = gemm_pp128_kernel<EPK, A3>;
+    if (int rc = set_dyn_lds<kern>(smem)) return rc;
     const long nbm = (g.M + 255) / 256, nbn = g.N / 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(512), smem, st, g);
     return (int)hipGetLastError();
@@ -1286,13 +1271,8 @@ template <int WM, int WN, int TM, int EPK, int NS = 4>
 static int launch_pp_cfg(const GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * 64;
     constexpr int smem = NS * (BM + BN) * 64;
-    static bool attr_set = false;
-    auto kern = gemm_pp_kernel<WM, WN, TM, EPK, NS>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    constexpr auto kern = gemm_pp_kernel<WM, WN, TM, EPK, NS>;
+    if (int rc = set_dyn_lds<kern>(smem)) return rc;
     const long nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(512), smem, st, g);
     return (int)hipGetLastError();
