@@ -51,6 +51,10 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm() { asm volatile("
 template <int BN, int TW, int NH, int EPI>
 __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) void conv_pp_kernel(const GemmArgs g) {
     constexpr bool CONVT = (EPI & 2) != 0, HAS_UV = (EPI & 1) != 0, RELU_IN = (EPI & 4) != 0;
+    // EPI bit 3: v_mfma_f32_16x16x32_f16 (as gemm_pp128m16): a 16-pixel block is one row of the 16-wide tile (pixel = lane & 15, channel group
+    // lane >> 4), accumulators f32x4[2*TM][4]; the halo / weight LDS layouts, DMA, waits and barriers are unchanged.  TW = 16 only.
+    constexpr bool M16 = (EPI & 8) != 0;
+    static_assert(!M16 || TW == 16, "16x16x32 path: 16-pixel-wide tiles");
     constexpr int WN = BN / 64, WM = 8 / WN, TM = TW * 16 / 32 / WM, TN = 2;
     constexpr int HALO_W = Halo<TW>::W, HALO_PX = Halo<TW>::PX, HALO_PIECES = Halo<TW>::PIECES, HALO_BYTES = Halo<TW>::BYTES, HPW = Halo<TW>::HPW;
     constexpr int LOG_TW = TW == 16 ? 4 : 5;
@@ -149,14 +153,22 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     }
     const int sxw = (l31 >> 1) & 7;
     const int w_off = (wn * 64 + l31) * 128 + ((hi ^ sxw) << 4);          // weight row (wn*64 + j*32 + l31); k-step ks: ^ (ks * 32)
+    // 16x16x32: pixel block i (one tile row): halo pixel (wm*2*TM + i + 1) * HALO_W + (l15 + 1); weight row wn*64 + j*16 + l15; chunk 4*ks + g4
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int w_off16 = (wn * 64 + l15) * 128 + ((g4 ^ ((l15 >> 1) & 7)) << 4);
 
     f32x16 acc[TM][TN];
+    f32x4 acc16[2 * TM][4];
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * TM; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue -----------------------------------------------------------------------------------------------------
     issue_halo(0);
@@ -176,7 +188,21 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     int kt = 0, halo_age = 2;
     auto kstep = [&](const char* halo, int dy, int dx, bool first_of_image, int image, bool relu) {
         const char* wsl = smem + LDS_W + (kt & 3) * WSLOT;
-        u32x4 af[TM][4], wf[TN][4];
+        u32x4 af[TM][4], wf[TN][4];          // M16: viewed as af16[2*TM][2] / wf16[4][2] (same register count)
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < 2 * TM; i++) {
+                const int hx = l15 + 1 + dx;
+                const int hp = (wm * 2 * TM + i + 1 + dy) * HALO_W + hx;
+                const int a0 = hp * 128 + ((g4 ^ ((hx >> 1) & 7)) << 4);
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) af[i >> 1][(i & 1) * 2 + ks] = *reinterpret_cast<const u32x4*>(halo + (a0 ^ (ks * 64)));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) wf[j >> 1][(j & 1) * 2 + ks] = *reinterpret_cast<const u32x4*>(wsl + (w_off16 ^ (ks * 64)) + j * 2048);
+        } else {
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int hp = hp0[i] + dy * HALO_W + dx;
@@ -188,6 +214,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) wf[j][ks] = *reinterpret_cast<const u32x4*>(wsl + (w_off ^ (ks * 32)) + j * 4096);
+        }
         // DMA: the next halo image (the other halo buffer was last read one barrier ago), weights 3 steps ahead
         const bool halo_now = NH > 1 && first_of_image && image + 1 < ntot;
         if (halo_now) { issue_halo(image + 1); halo_age = 0; }
@@ -220,12 +247,21 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (M16) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int i = 0; i < 2 * TM; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) mma16<f16>(acc16[i][j], wf[j >> 1][(j & 1) * 2 + ks], af[i >> 1][(i & 1) * 2 + ks]);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ks++)
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) mma_step<f16>(acc[i][j], wf[j][ks], af[i][ks]);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
@@ -245,6 +281,59 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     char* R = smem + wave * (WROWS * 128);
     const int rr = lane >> 3, cc = lane & 7;
     const int nw = n0 + wn * 64;
+    const float lo = g.act == ACT_RELU ? 0.f : -3.0e38f;        // branch-free optional ReLU
+    const bool has_bias = g.bias != nullptr;
+    if constexpr (M16) {
+        // 16x16x32 accumulators: block i = tile row wm*2*TM + i, lane: pixel x0 + l15, channels nw + jj*16 + 4*g4 .. +3
+        float u0[2 * TM], u1[2 * TM], v0[2 * TM], v1[2 * TM];
+        if constexpr (HAS_UV) {
+#pragma unroll
+            for (int i = 0; i < 2 * TM; i++) {
+                int y = y0 + wm * 2 * TM + i, x = x0 + l15;
+                y = y < H ? y : H - 1; x = x < W ? x : W - 1;
+                if constexpr (CONVT) {
+                    u0[i] = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, 2 * W, 2 * x);
+                    u1[i] = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, 2 * W, 2 * x + 1);
+                    v0[i] = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, 2 * H, 2 * y);
+                    v1[i] = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, 2 * H, 2 * y + 1);
+                } else {
+                    u0[i] = u1[i] = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, W, x);
+                    v0[i] = v1[i] = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, H, y);
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int n = nw + jj * 16 + 4 * g4;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (has_bias) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+            f32x4 wu = {0.f, 0.f, 0.f, 0.f}, wv = wu;
+            int pdy = 0, pdx = 0;
+            if constexpr (HAS_UV) {
+                int nco = n;
+                if constexpr (CONVT) { const int qd = n / g.Cout; nco = n - qd * g.Cout; pdy = qd >> 1; pdx = qd & 1; }
+                wu = *reinterpret_cast<const f32x4*>(g.uv.wu + nco);
+                wv = *reinterpret_cast<const f32x4*>(g.uv.wv + nco);
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * TM; i++) {
+                const int row = i * 16 + l15;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = acc16[i][jj][e] + bv[e];
+                if constexpr (HAS_UV) {
+                    const float uu = pdx ? u1[i] : u0[i];
+                    const float vq = pdy ? v1[i] : v0[i];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] += wu[e] * uu + wv[e] * vq;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], lo);
+                const f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                *reinterpret_cast<f16x4*>(R + row * 128 + ((((jj * 2 + (g4 >> 1)) ^ (row & 7)) << 4) | ((g4 & 1) << 3))) = hv;
+            }
+        }
+    } else {
     float u0[TM], u1[TM], v0[TM], v1[TM];          // separate arrays: a [TM][2] array indexed by the parity goes to scratch
     if constexpr (HAS_UV) {
 #pragma unroll
@@ -264,8 +353,6 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
             }
         }
     }
-    const float lo = g.act == ACT_RELU ? 0.f : -3.0e38f;        // branch-free optional ReLU
-    const bool has_bias = g.bias != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; j++)
 #pragma unroll
@@ -299,6 +386,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
                 *reinterpret_cast<f16x4*>(R + row * 128 + ((((j * 4 + q) ^ (row & 7)) << 4) | (hi << 3))) = hv;
             }
         }
+    }
     f16* const outp = reinterpret_cast<f16*>(g.out);
     const f16* const addp = reinterpret_cast<const f16*>(g.add);
 #pragma unroll
@@ -358,6 +446,18 @@ bool conv_pp_eligible(const GemmArgs& g) {
 template <int BN, int TW, int NH>
 static int launch_conv_epi(const GemmArgs& g, hipStream_t st) {
     const int e = (g.uv.wu ? 1 : 0) | (g.epi == EPI_CONVT ? 2 : 0) | (g.relu_in ? 4 : 0);
+    if constexpr (TW == 16) {
+        if (moge_tune_get("CONV_M16", 1)) {
+            switch (e) {
+            case 0: return launch_conv_cfg<BN, TW, NH, 8>(g, st);
+            case 1: return launch_conv_cfg<BN, TW, NH, 9>(g, st);
+            case 2: return launch_conv_cfg<BN, TW, NH, 10>(g, st);
+            case 3: return launch_conv_cfg<BN, TW, NH, 11>(g, st);
+            case 4: return launch_conv_cfg<BN, TW, NH, 12>(g, st);
+            default: return -1;
+            }
+        }
+    }
     switch (e) {
     case 0: return launch_conv_cfg<BN, TW, NH, 0>(g, st);
     case 1: return launch_conv_cfg<BN, TW, NH, 1>(g, st);
