@@ -102,7 +102,8 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
         // chunk swizzle by the halo COLUMN: sw = (hx >> 1) & 7.  A 16-lane ds_read_b128 group covers 16 consecutive columns (split over
         // two image rows for the 16-wide tile); with an even row pitch the LDS half-row bit is hx & 1, so (hx & 1, (hx >> 1) & 7) = hx mod 16
         // is distinct for every lane of the group at every tap shift: conflict-free (the linear-index swizzle was 2-way on 4 lanes)
-        const int sw = ((hp % HALO_W) >> 1) & 7;                        // padding pixels of the last piece: any consistent value
+        // (16x16x32 form: keyed on the column itself, hx & 7 - conflict-free for all three tap shifts of its 16-lane fragment groups, found by search)
+        const int sw = ((EPI & 8) ? (hp % HALO_W) : ((hp % HALO_W) >> 1)) & 7;      // padding pixels of the last piece: any consistent value
         hp = hp < HALO_PX ? hp : HALO_PX - 1;
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
         int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
             for (int i = 0; i < 2 * TM; i++) {
                 const int hx = l15 + 1 + dx;
                 const int hp = (wm * 2 * TM + i + 1 + dy) * HALO_W + hx;
-                const int a0 = hp * 128 + ((g4 ^ ((hx >> 1) & 7)) << 4);
+                const int a0 = hp * 128 + ((g4 ^ (hx & 7)) << 4);
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) af[i >> 1][(i & 1) * 2 + ks] = *reinterpret_cast<const u32x4*>(halo + (a0 ^ (ks * 64)));
             }
