@@ -23,38 +23,41 @@ __device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1
 template <typename TIn, typename TOut>
 __global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict__ out, int B, int H, int W, int rows, int cols,
                                   int ldk, int nchw_out, float m0, float m1, float m2, float s0, float s1, float s2) {
+    // one thread per output PIXEL: the filter ranges and weight sums depend on (oy, ox) only and serve the three channels
+    // (per-channel arithmetic and its order are unchanged: horizontal pass first, then vertical, fp32)
     const int OH = rows * 14, OW = cols * 14;
-    const long total = (long)B * 3 * OH * OW;
+    const long total = (long)B * OH * OW;
     const float scale_y = (float)H / (float)OH, scale_x = (float)W / (float)OW;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int ox = idx % OW;
         long t = idx / OW;
-        const int oy = t % OH; t /= OH;
-        const int c = t % 3;
-        const int b = t / 3;
+        const int oy = t % OH;
+        const int b = t / OH;
         int ylo, yn, xlo, xn; float yc, yis, ysup, xc, xis, xsup;
         aa_range(oy, scale_y, H, ylo, yn, yc, yis, ysup);
         aa_range(ox, scale_x, W, xlo, xn, xc, xis, xsup);
         float wysum = 0.f, wxsum = 0.f;
         for (int j = 0; j < yn; j++) wysum += tri((j + ylo - yc + 0.5f) * yis);
         for (int i = 0; i < xn; i++) wxsum += tri((i + xlo - xc + 0.5f) * xis);
-        const TIn* src = img + ((size_t)b * 3 + c) * H * W;
-        // horizontal pass first, then vertical (ATen's separable order), fp32 accumulation
-        float acc = 0.f;
+        float acc[3] = {0.f, 0.f, 0.f};
         for (int j = 0; j < yn; j++) {
             const float wy = tri((j + ylo - yc + 0.5f) * yis) / wysum;
-            const TIn* rowp = src + (size_t)(ylo + j) * W + xlo;
-            float h = 0.f;
-            for (int i = 0; i < xn; i++) h += (tri((i + xlo - xc + 0.5f) * xis) / wxsum) * (float)rowp[i];
-            acc += wy * h;
+            float h[3] = {0.f, 0.f, 0.f};
+            for (int i = 0; i < xn; i++) {
+                const float wx = tri((i + xlo - xc + 0.5f) * xis) / wxsum;
+#pragma unroll
+                for (int c = 0; c < 3; c++) h[c] += wx * (float)img[(((size_t)b * 3 + c) * H + (ylo + j)) * W + xlo + i];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc[c] += wy * h[c];
         }
-        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
-        const float v = (acc - mean) / sd;
-        if (nchw_out) {
-            out[idx] = (TOut)v;
-        } else {
-            const int py = oy / 14, iy = oy - py * 14, px = ox / 14, ix = ox - px * 14;
-            out[((size_t)b * rows * cols + (size_t)py * cols + px) * ldk + c * 196 + iy * 14 + ix] = (TOut)v;
+        const int py = oy / 14, iy = oy - py * 14, px = ox / 14, ix = ox - px * 14;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+            const float v = (acc[c] - mean) / sd;
+            if (nchw_out) out[(((size_t)b * 3 + c) * OH + oy) * OW + ox] = (TOut)v;
+            else out[((size_t)b * rows * cols + (size_t)py * cols + px) * ldk + c * 196 + iy * 14 + ix] = (TOut)v;
         }
     }
 }
@@ -62,7 +65,7 @@ __global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict_
 template <typename TIn, typename TOut>
 int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out,
                       const float* mean, const float* std_, hipStream_t st) {
-    const long total = (long)B * 3 * rows * 14 * cols * 14;
+    const long total = (long)B * rows * 14 * cols * 14;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL((preprocess_kernel<TIn, TOut>), dim3(blocks), dim3(256), 0, st, (const TIn*)img, (TOut*)out, B, H, W, rows, cols,
