@@ -264,3 +264,24 @@ def test_odd_shapes_and_token_grids_match_the_oracle_fp32(MoGeModel, tmp_path_fa
     ref = O.infer(cfg, sd, x, num_tokens=tokens)
     assert out["mask"].shape == (2, H, W) and out["points"].shape == (2, H, W, 3)
     compare(out, ref, FP32_TOL)
+
+
+@pytest.mark.parametrize("kind", ["black", "white", "flat_gray"])
+def test_fp16_mode_on_constant_images_stays_in_band(MoGeModel, tmp_path_factory, kind):
+    """Degenerate inputs for the folded LayerNorm (fp16 path: row statistics from partial sums, raw residual in fp16): a constant image gives
+    every patch the same embedding, so the token rows differ by the position embedding only.  Outputs must stay finite and within the fp16 band
+    of the fp32 oracle, like any other image."""
+    from oracle import moge_oracle as O
+    model, cfg, sd = get_model(MoGeModel, "tiny-vits-normal", 0, True, tmp_path_factory)
+    val = {"black": 0.0, "white": 1.0, "flat_gray": 0.5}[kind]
+    x = torch.full((2, 3, 84, 112), val)
+    model.half()
+    try:
+        out = model.infer(x, num_tokens=108, apply_mask=False)
+    finally:
+        model.float()
+    ref = O.infer(cfg, sd, x, num_tokens=108, apply_mask=False)
+    for k in ("points", "depth", "intrinsics"):
+        a = out[k].float().cpu().numpy()
+        assert np.isfinite(a).all(), k
+    compare({k: out[k] for k in ref}, ref, 3e-2, mask_frac=0.02)
