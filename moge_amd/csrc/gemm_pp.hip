@@ -59,8 +59,14 @@ __device__ __forceinline__ void pp_resid_rows(const GemmArgs& g, const char* R, 
         const f32x4 xnew = xv[it] + v;
         if (m < M) *reinterpret_cast<f32x4*>(xres + (size_t)m * ldc + ncol + cc * 4) = xnew;
         if (g.x16) {          // LN fold producer: fp16 copy + (sum, sum of squares) of this row's 32-column group (8 lanes, butterfly 1-2-4)
-            if (m < M) *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(g.x16) + (size_t)m * ldc + ncol + cc * 4) =
-                f16x4{(f16)xnew[0], (f16)xnew[1], (f16)xnew[2], (f16)xnew[3]};
+            {   // lane pairs (cc, cc ^ 1) share one 16-byte store of 8 columns
+                const f16x4 h4 = {(f16)xnew[0], (f16)xnew[1], (f16)xnew[2], (f16)xnew[3]};
+                const f32x2 mine = __builtin_bit_cast(f32x2, h4);
+                f32x2 other;
+                other[0] = __shfl_xor(mine[0], 1); other[1] = __shfl_xor(mine[1], 1);
+                if (m < M && !(cc & 1))
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<f16*>(g.x16) + (size_t)m * ldc + ncol + cc * 4) = f32x4{mine[0], mine[1], other[0], other[1]};
+            }
             float s1, s2;
             ln_quad_sums(xnew, s1, s2);
 #pragma unroll
