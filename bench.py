@@ -11,9 +11,14 @@ the fp32 master weight blob is broadcast once over xGMI, then every rank runs in
 shard (weak scaling: per-GPU batch fixed; no steady-state collective - SURVEY.md 8(e)).
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline      dominant kernel class (the MFMA GEMM of the ViT linears), HIP-event timed inside the timed region
-  cpu_baseline  the CPU oracle (oracle/moge_oracle.py, a restatement pinned to the reference) on ONE image of the
-                same workload on this box's host cores (rank 0, N=1 only)
+  roofline        dominant kernel class (the MFMA GEMMs of the ViT linears): algorithmic FLOPs / HIP-event time on the launch stream over the
+                  same K steps run single-stream right after the timed region; `traffic` = fabric bytes per launch from the committed
+                  rocprofv3 PMC passes (moge_amd/pmc_traffic.json, default workload only)
+  kernel_classes  per-class ms/step, TFLOP/s, GB/s of that profiled pass;  whole_path: end-to-end MFMA fraction
+  pcie_inclusive  images/s of the caller-side pipeline (host uint8 in, all maps back to pinned host memory) - N=1 only, never `value`
+  load_seconds    from_pretrained(.pt) vs from_blob(packed master blob) to a ready model
+  cpu_baseline    the CPU oracle (oracle/moge_oracle.py, a restatement pinned to the reference) on ONE image of the
+                  same workload on this box's host cores (rank 0, N=1 only)
 """
 import argparse
 import json
