@@ -131,7 +131,8 @@ int moge_workspace_bytes(moge_handle* h, int B, int H, int W, int token_rows, in
 /* replaces MoGeModel.forward (v2.py:138-192).  image: device, (B,3,H,W), fp32 (img_dtype 0) or fp16 (1),
  * values in [0,1]; or img_dtype 2: uint8 (B,H,W,3) as decoded from a file - the library then does the caller's
  * `image / 255` + HWC->CHW + cast to the model dtype (scripts/infer.py:98, v2.py:229) on the device (4x / 2x less
- * PCIe traffic than uploading floats).  token_rows/cols = base_h/base_w computed by the host exactly as v2.py:142-147.
+ * PCIe traffic than uploading floats); or img_dtype 3: fp32 (B,3,H,W) whose values are rounded to fp16 as they are read - the
+ * `image.to(dtype=self.dtype)` of a .half() model (v2.py:229) without a separate cast pass.  token_rows/cols = base_h/base_w computed by the host exactly as v2.py:142-147.
  * Writes points (remapped), normal (unit), mask_prob, metric_scale. */
 int moge_forward(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int token_rows, int token_cols,
                  const moge_outputs* out, void* stream);
@@ -175,6 +176,30 @@ void moge_tune_set(const char* key, int value);
 /* C[M,N] = A[M,K] * W[N,K]^T + bias, fp32 in/out on device; computed in `precision`. act: 0 none 1 relu 2 gelu */
 int moge_test_gemm(int precision, const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
                    int act, void* stream);
+/* The same GEMM through every fused epilogue of the ViT / decoder linear layers (gemm.hip + gemm_pp.hip), so that the production fp16
+ * throughput kernel (gemm_pp128m16_kernel: selected when N % 256 == 0, K % 64 == 0 and the problem has >= PP_MIN_TILES 256x256 tiles, or forced
+ * with moge_tune_set("PP_MIN_TILES", 0)) and the latency-regime kernels (moge_tune_set("GEMM_PP", 0)) can each be compared with a plain
+ * fp32 reference and with each other.  All pointers are DEVICE fp32 unless noted; acc = A W^T.
+ *   MOGE_TG_STORE  out[m][n]  = act(lnfold(acc) + bias[n] (+ wu[n] u(x) + wv[n] v(y)))            attention.py:72, mlp.py:35, modules.py:128-131
+ *   MOGE_TG_RESID  xres[m][n] += gamma[n] (acc + bias[n]); optional x16_out (fp16 copy, returned as fp32) and ln_part_out[m][N/32][2]
+ *                  = (sum, sum of squares) of every 32-column group of the updated row               block.py:111-112, layer_scale.py:27
+ *   MOGE_TG_QKV    q/k/v_out (B,nh,Ntok,64) = head-major split of lnfold(acc) + bias, q scaled by qscale          attention.py:72-74
+ *   MOGE_TG_CONVT  out (B,2 pixH,2 pixW,Cout): n = (dy*2+dx)*Cout + co of pixel m = (b*pixH + y)*pixW + x goes to (2y+dy, 2x+dx)   modules.py:162
+ * lnfold(acc) = ln_mr[m][1] * (acc - ln_mr[m][0] * ln_c[n]) when ln_mr != NULL (LayerNorm folded into the consumer GEMM), else acc.
+ * u(x) = linspace(u0,u1,pixW)[m % pixW], v(y) = linspace(v0,v1,pixH)[(m / pixW) % pixH] when wu != NULL. */
+enum { MOGE_TG_STORE = 0, MOGE_TG_RESID = 1, MOGE_TG_QKV = 2, MOGE_TG_CONVT = 3 };
+typedef struct moge_test_gemm_args {
+    int32_t precision, kind, act;            /* act: 0 none 1 relu 2 gelu (STORE only) */
+    int32_t M, N, K;
+    const float* A; const float* W; const float* bias;
+    float* out;                              /* STORE: [M][N]; CONVT: (B,2pixH,2pixW,Cout) */
+    const float* ln_mr; const float* ln_c;   /* [M][2] (mean, rstd), [N] */
+    const float* wu; const float* wv; float u0, u1, v0, v1;
+    int32_t pixW, pixH, Cout;
+    float* xres; const float* gamma; float* x16_out; float* ln_part_out;      /* RESID */
+    float* q_out; float* k_out; float* v_out; int32_t nh, Ntok; float qscale; /* QKV: M = B*Ntok, N = 3*nh*64 */
+} moge_test_gemm_args;
+int moge_test_gemm_ex(const moge_test_gemm_args* args, void* stream);
 /* LayerNorm rows of x[rows, D], eps 1e-6 */
 int moge_test_layernorm(int precision, const float* x, const float* w, const float* b, float* y, int rows, int D, void* stream);
 /* softmax(q k^T / 8) v for q,k,v (B,nh,N,64) fp32 -> o (B,N,nh*64) */

@@ -41,6 +41,16 @@ class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 7), ("flops", C.c_double * 7), ("bytes", C.c_double * 7), ("launches", C.c_int64 * 7)]
 
 
+class TestGemmArgs(C.Structure):
+    """moge_test_gemm_args (tests only): one GEMM through a chosen fused epilogue."""
+    _fields_ = [("precision", C.c_int32), ("kind", C.c_int32), ("act", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("ln_mr", C.c_void_p), ("ln_c", C.c_void_p),
+                ("wu", C.c_void_p), ("wv", C.c_void_p), ("u0", C.c_float), ("u1", C.c_float), ("v0", C.c_float), ("v1", C.c_float),
+                ("pixW", C.c_int32), ("pixH", C.c_int32), ("Cout", C.c_int32),
+                ("xres", C.c_void_p), ("gamma", C.c_void_p), ("x16_out", C.c_void_p), ("ln_part_out", C.c_void_p),
+                ("q_out", C.c_void_p), ("k_out", C.c_void_p), ("v_out", C.c_void_p), ("nh", C.c_int32), ("Ntok", C.c_int32), ("qscale", C.c_float)]
+
+
 class MogeError(RuntimeError):
     pass
 
@@ -72,6 +82,7 @@ def _load() -> C.CDLL:
         "moge_debug_tap": (C.c_int, [vp, C.c_char_p, vp, i64, C.POINTER(i64), vp]),
         "moge_tune_set": (None, [C.c_char_p, i32]),
         "moge_test_gemm": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, vp]),
+        "moge_test_gemm_ex": (C.c_int, [C.POINTER(TestGemmArgs), vp]),
         "moge_test_layernorm": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, vp]),
         "moge_test_attention": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, vp]),
         "moge_test_conv3x3": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, vp]),
@@ -93,7 +104,7 @@ lib = _load()
 EXPORTS = ["moge_abi_version", "moge_last_error", "moge_create", "moge_destroy", "moge_load_weights", "moge_alloc_master",
            "moge_master_blob", "moge_master_ready", "moge_set_precision", "moge_workspace_bytes", "moge_forward", "moge_infer",
            "moge_postprocess", "moge_depth_edge_mask", "moge_sync", "moge_profile_enable", "moge_profile_read", "moge_debug_tap", "moge_tune_set", "moge_test_gemm",
-           "moge_test_layernorm", "moge_test_attention", "moge_test_conv3x3", "moge_test_convt2x2", "moge_test_preprocess",
+           "moge_test_gemm_ex", "moge_test_layernorm", "moge_test_attention", "moge_test_conv3x3", "moge_test_convt2x2", "moge_test_preprocess",
            "moge_test_posembed", "moge_test_recover"]
 
 

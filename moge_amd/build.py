@@ -32,12 +32,25 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, experiments: bool = False) -> str:
+    """experiments=True adds -DMOGE_EXPERIMENTS: the superseded / rejected kernel variants under csrc/experiments/ are compiled in and become
+    selectable through MOGE_PP_EXP / MOGE_ATTN_EXP / ... (tools/kbench A-B timing only; the product library is built without them)."""
     hipcc = _hipcc()
+    flags = FLAGS + (["-DMOGE_EXPERIMENTS"] if experiments else [])
+    stamp = os.path.join(LIBDIR, "obj", ".experiments")
+    os.makedirs(os.path.join(LIBDIR, "obj"), exist_ok=True)
+    if os.path.exists(stamp) != experiments:                # switching flavour rebuilds everything
+        force = True
+        if experiments:
+            open(stamp, "w").close()
+        else:
+            os.remove(stamp)
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    if experiments:
+        hdrs += [os.path.join(CSRC, "experiments", f) for f in os.listdir(os.path.join(CSRC, "experiments"))]
     jobs = []
     objs = []
     for src in SOURCES:
@@ -45,7 +58,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + flags + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -78,6 +91,6 @@ def build_tools(verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv))
     if "--tools" in sys.argv:
         print(build_tools())

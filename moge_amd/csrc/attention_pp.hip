@@ -47,242 +47,9 @@ __device__ __forceinline__ u32x4 pack8(const f32x16& p, int s) {
 constexpr int AP_STAGE = 16384;          // K tile 8 KiB + V tile 8 KiB
 constexpr float AP_PSUM_LIMIT = 16384.f;
 
-// QT = 32-query tiles per wave.  QT = 2: the two tiles are independent softmax chains inside one wave (the scheduler can put one
-// tile's MFMAs next to the other's exponentials) and share every K / V fragment read; 2 waves per SIMD instead of 3.
-template <int NW, int QT>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && QT == 1) ? 3 : 2) void attn_pp_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
-                                                          f16* __restrict__ out, int Ntok, int nh) {
-    constexpr int NPW = 16 / NW;                // DMA pieces (8 rows x 128 B) per wave per tile: K pieces then V pieces
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * AP_STAGE
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi = lane >> 5, l31 = lane & 31;
-    const int bh = blockIdx.y;
-    const int b = bh / nh, head = bh - b * nh;
-    const int q0 = blockIdx.x * (NW * 32 * QT) + wave * 32 * QT;
-
-    // ---- Q fragments (B-operand of S^T = K Q^T): lane = query, 8 d per half and k-step --------------------------------
-    u32x4 qf[QT][4];
-#pragma unroll
-    for (int a = 0; a < QT; a++) {
-        const int qrow = q0 + a * 32 + l31;
-        const f16* qp = q + ((size_t)bh * Ntok + (qrow < Ntok ? qrow : Ntok - 1)) * 64;
-#pragma unroll
-        for (int s = 0; s < 4; s++) qf[a][s] = *reinterpret_cast<const u32x4*>(qp + (2 * s + hi) * 8);
-    }
-
-    // ---- DMA sources: piece p of a tile = rows 8p..8p+7 of K (p < 8) or V (p >= 8) ------------------------------------
-    const char* kbase = reinterpret_cast<const char*>(k + (size_t)bh * Ntok * 64);
-    const char* vbase = reinterpret_cast<const char*>(v + (size_t)bh * Ntok * 64);
-    const int prow = lane >> 3, pch = lane & 7;
-    // piece i of this wave: K rows (p < 8) or V rows (p >= 8), 8 rows x 128 B; per-lane byte offset inside the 64-key tile is a
-    // constant, the tile advance stays on the scalar unit.  Only the last tile clamps its key index (rows >= Ntok repeat row
-    // Ntok-1: masked for K, multiplied by P = 0 for V).
-    int drow[NPW];
-    unsigned doff[NPW];
-#pragma unroll
-    for (int i = 0; i < NPW; i++) {
-        const int p = wave + NW * i;                     // 0..15
-        const int row = (p & 7) * 8 + prow;
-        drow[i] = row;
-        // K: chunk ^ ((row >> 1) & 7) (conflict-free ds_read_b128);  V: chunk ^ (((key >> 1) & 1) << 2) (conflict-free tr reads)
-        const int lch = p >= 8 ? (pch ^ (((row >> 1) & 1) << 2)) : (pch ^ ((row >> 1) & 7));
-        doff[i] = (unsigned)(row * 128 + lch * 16);
-    }
-    const int ntiles = (Ntok + 63) >> 6;
-    auto issue = [&](int t) {
-        char* st = smem + (t % 3) * AP_STAGE;
-        const char* kt = uniform_ptr(kbase + (size_t)t * 8192);
-        const char* vt = uniform_ptr(vbase + (size_t)t * 8192);
-        if (t < ntiles - 1) {
-#pragma unroll
-            for (int i = 0; i < NPW; i++) {
-                const int p = wave + NW * i;
-                __builtin_amdgcn_global_load_lds(AP_GPTR((p >= 8 ? vt : kt) + doff[i]), AP_LPTR(st + p * 1024), 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NPW; i++) {
-                const int p = wave + NW * i;
-                const int over = t * 64 + drow[i] - (Ntok - 1);              // rows past the end step back to the last valid row
-                const unsigned off = doff[i] - (over > 0 ? (unsigned)over * 128u : 0u);
-                __builtin_amdgcn_global_load_lds(AP_GPTR((p >= 8 ? vt : kt) + off), AP_LPTR(st + p * 1024), 16, 0, 0);
-            }
-        }
-    };
-
-    // ---- LDS read addresses (bytes inside a stage) -----------------------------------------------------------------------
-    // K fragment (h, s): row = h*32 + perm(l31), chunk 2s+hi;  perm swaps bits 2/3 (accumulator regs == next B-operand)
-    const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-    int kaddr[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) kaddr[s] = krow * 128 + (((2 * s + hi) ^ ((krow >> 1) & 7)) << 4);
-    // V^T fragment (dt, h, s) = two transposed reads of 4 keys x 16 d per 16-lane group:
-    //   supplier lane i (of its group): key (i>>2), d-offset (i&3)*4 inside the group's 16 d's;  group g = lane>>4: d-block (g&1)*16, keys +8*(g>>1)
-    const int li = lane & 15;
-    const int vsw = ((li >> 3) & 1) << 2;                                    // ((key >> 1) & 1) << 2 with key = (li >> 2) + multiples of 4
-    const int vrow = 8 * hi + (li >> 2);
-    const int vch = (((lane >> 4) & 1) << 1) | ((li & 3) >> 1);              // 16-byte chunk inside the 32-d half-row (dt selects the half)
-    int vaddr[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; dt++) vaddr[dt] = 8192 + vrow * 128 + ((((dt << 2) | vch) ^ vsw) << 4) + (li & 1) * 8;
-
-    f32x16 o[QT][2];
-    f32x16 negs[QT];                    // -m splat: the C operand of the first MFMA of every K Q^T chain (changes only when m does)
-    float m_run[QT], l_run[QT];
-#pragma unroll
-    for (int a = 0; a < QT; a++) {
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) o[a][i][r] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) negs[a][r] = 0.f;
-        m_run[a] = -1e30f; l_run[a] = 0.f;
-    }
-
-    issue(0);
-    if (ntiles > 1) issue(1);
-
-    int stage = 0;                                // t % 3
-    for (int t = 0; t < ntiles; t++) {
-        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();             // tile t landed for every wave; every wave is done reading tile t-1
-        asm volatile("" ::: "memory");
-        if (t + 2 < ntiles) issue(t + 2);
-        const int so = stage * AP_STAGE;
-        stage = stage == 2 ? 0 : stage + 1;
-        const char* ka[4];
-        const char* va[2];
-#pragma unroll
-        for (int s = 0; s < 4; s++) ka[s] = smem + (kaddr[s] + so);
-#pragma unroll
-        for (int dt = 0; dt < 2; dt++) va[dt] = smem + (vaddr[dt] + so);
-        const bool last = t == ntiles - 1;
-        const bool exact = (t == 0) | last;       // tiles that always take the exact path (first: m unknown; last: key mask)
-
-        f32x16 sc[QT][2];
-        float psum[QT];
-        bool trig = false;
-        if (!exact) {
-            // ---- fast path: S^T - m = K Q^T + (-m);  P = exp2(.)  (all eight K fragments are requested before the first MFMA) ----
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                u32x4 kf[4];
-#pragma unroll
-                for (int s = 0; s < 4; s++) kf[s] = *reinterpret_cast<const u32x4*>(ka[s] + h * 4096);
-                // first MFMA of the chain reads its C operand from the resident -m splat (srcC != vDst): no per-tile accumulator init
-#pragma unroll
-                for (int a = 0; a < QT; a++)
-                    sc[a][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf[0]), __builtin_bit_cast(f16x8, qf[a][0]), negs[a], 0, 0, 0);
-#pragma unroll
-                for (int s = 1; s < 4; s++)
-#pragma unroll
-                    for (int a = 0; a < QT; a++) mma_step<f16>(sc[a][h], kf[s], qf[a][s]);
-            }
-#pragma unroll
-            for (int a = 0; a < QT; a++) {
-                float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; r++) { sc[a][0][r] = __builtin_amdgcn_exp2f(sc[a][0][r]); ps0 += sc[a][0][r]; }
-#pragma unroll
-                for (int r = 0; r < 16; r++) { sc[a][1][r] = __builtin_amdgcn_exp2f(sc[a][1][r]); ps1 += sc[a][1][r]; }
-                psum[a] = ps0 + ps1;
-                trig |= !(psum[a] < AP_PSUM_LIMIT);
-            }
-        }
-        if (exact || __any(trig)) {
-            // ---- exact path: raise m to the true running max, rescale O and l (first / last tile; rare otherwise) ------
-#pragma unroll
-            for (int a = 0; a < QT; a++) {
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) sc[a][h][r] = 0.f;
-#pragma unroll
-                    for (int s = 0; s < 4; s++) {
-                        const u32x4 kf = *reinterpret_cast<const u32x4*>(ka[s] + h * 4096);
-                        mma_step<f16>(sc[a][h], kf, qf[a][s]);
-                    }
-                }
-                if (last) {
-#pragma unroll
-                    for (int h = 0; h < 2; h++)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int i = acc_row(r, hi);
-                            const int key = t * 64 + h * 32 + ((i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1));
-                            if (key >= Ntok) sc[a][h][r] = -1e30f;
-                        }
-                }
-                float mx = sc[a][0][0];
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) mx = fmaxf(mx, sc[a][h][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float m_new = fmaxf(m_run[a], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[a] - m_new);
-                m_run[a] = m_new;
-                l_run[a] *= alpha;
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) o[a][i][r] *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; r++) negs[a][r] = -m_new;
-                float ps = 0.f;
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        sc[a][h][r] = __builtin_amdgcn_exp2f(sc[a][h][r] - m_new);
-                        ps += sc[a][h][r];
-                    }
-                psum[a] = ps;
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < QT; a++) l_run[a] += psum[a];
-        // ---- O^T += V^T P^T  (the four V^T operands of a 32-key half are requested together, shared by the query tiles) ----------
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            u32x4 vf[2][2];
-#pragma unroll
-            for (int s = 0; s < 2; s++)
-#pragma unroll
-                for (int dt = 0; dt < 2; dt++) {
-                    const int koff = (h * 32 + 16 * s) * 128;
-                    vf[s][dt] = tr_pair(va[dt] + koff, va[dt] + koff + 4 * 128);
-                }
-#pragma unroll
-            for (int a = 0; a < QT; a++)
-#pragma unroll
-                for (int s = 0; s < 2; s++) {
-                    const u32x4 pf = pack8(sc[a][h], s);
-#pragma unroll
-                    for (int dt = 0; dt < 2; dt++) mma_step<f16>(o[a][dt], vf[s][dt], pf);
-                }
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < QT; a++) {
-        const float l_tot = l_run[a] + __shfl_xor(l_run[a], 32);
-        const float inv = 1.f / l_tot;
-        const int qrow = q0 + a * 32 + l31;
-        if (qrow < Ntok) {
-            f16* op = out + ((size_t)b * Ntok + qrow) * ((size_t)nh * 64) + head * 64;
-#pragma unroll
-            for (int dt = 0; dt < 2; dt++)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; g4++)
-                    store4(op + dt * 32 + 8 * g4 + 4 * hi, o[a][dt][4 * g4] * inv, o[a][dt][4 * g4 + 1] * inv, o[a][dt][4 * g4 + 2] * inv,
-                           o[a][dt][4 * g4 + 3] * inv);
-        }
-    }
-}
+#ifdef MOGE_EXPERIMENTS
+#include "experiments/attention_pp_exp.inc"     // the v_mfma_f32_32x32x16_f16 form of this kernel (tools/kbench A-B builds only)
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------------
 // The same kernel on v_mfma_f32_16x16x32_f16 (tools/mfma_power: the cheaper instruction per FLOP on this power-limited chip).
@@ -542,15 +309,19 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
 static int launch_attn_pp16(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
     constexpr int smem = 3 * AP_STAGE;
     if (int rc = set_dyn_lds<attn_pp16_kernel<0>>(smem)) return rc;
-    if (int rc = set_dyn_lds<attn_pp16_kernel<1>>(smem)) return rc;
     dim3 grid((Ntok + 127) / 128, B * nh);
-    if (moge_tune_get("ATTN_ABL", 0) == 1)
+#ifdef MOGE_EXPERIMENTS
+    if (moge_tune_get("ATTN_ABL", 0) == 1) {           // ablation: the hot loop's exp2 replaced by one multiply (wrong results; timing only)
+        if (int rc = set_dyn_lds<attn_pp16_kernel<1>>(smem)) return rc;
         hipLaunchKernelGGL(attn_pp16_kernel<1>, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
-    else
-        hipLaunchKernelGGL(attn_pp16_kernel<0>, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
+        return (int)hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL(attn_pp16_kernel<0>, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
     return (int)hipGetLastError();
 }
 
+#ifdef MOGE_EXPERIMENTS
 template <int NW, int QT>
 static int launch_attn_pp_cfg(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
     constexpr int smem = 3 * AP_STAGE;
@@ -560,12 +331,18 @@ static int launch_attn_pp_cfg(const void* q, const void* k, const void* v, void*
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
     return (int)hipGetLastError();
 }
+#endif
 
 // q, k, v: (B, nh, Ntok, 64) fp16 (q pre-scaled by log2(e)/8); out: (B, Ntok, nh*64) fp16
 int launch_attention_pp(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
     if (Ntok < 1) return -1;
-    if (moge_tune_get("ATTN_M16", 1)) return launch_attn_pp16(q, k, v, out, B, nh, Ntok, st);
-    if (moge_tune_get("ATTN_QT", 1) == 2) return launch_attn_pp_cfg<4, 2>(q, k, v, out, B, nh, Ntok, st);
-    if (moge_tune_get("ATTN_NW", 4) == 8) return launch_attn_pp_cfg<8, 1>(q, k, v, out, B, nh, Ntok, st);
-    return launch_attn_pp_cfg<4, 1>(q, k, v, out, B, nh, Ntok, st);
+#ifdef MOGE_EXPERIMENTS
+    switch (moge_tune_get("ATTN_EXP", 0)) {            // tools/kbench A-B only
+    case 1: return launch_attn_pp_cfg<4, 1>(q, k, v, out, B, nh, Ntok, st);
+    case 2: return launch_attn_pp_cfg<4, 2>(q, k, v, out, B, nh, Ntok, st);
+    case 3: return launch_attn_pp_cfg<8, 1>(q, k, v, out, B, nh, Ntok, st);
+    default: break;
+    }
+#endif
+    return launch_attn_pp16(q, k, v, out, B, nh, Ntok, st);
 }

@@ -447,33 +447,38 @@ bool conv_pp_eligible(const GemmArgs& g) {
 template <int BN, int TW, int NH>
 static int launch_conv_epi(const GemmArgs& g, hipStream_t st) {
     const int e = (g.uv.wu ? 1 : 0) | (g.epi == EPI_CONVT ? 2 : 0) | (g.relu_in ? 4 : 0);
-    if constexpr (TW == 16) {
-        if (moge_tune_get("CONV_M16", 1)) {
-            switch (e) {
-            case 0: return launch_conv_cfg<BN, TW, NH, 8>(g, st);
-            case 1: return launch_conv_cfg<BN, TW, NH, 9>(g, st);
-            case 2: return launch_conv_cfg<BN, TW, NH, 10>(g, st);
-            case 3: return launch_conv_cfg<BN, TW, NH, 11>(g, st);
-            case 4: return launch_conv_cfg<BN, TW, NH, 12>(g, st);
-            default: return -1;
-            }
+#ifdef MOGE_EXPERIMENTS
+    if (TW == 32 || moge_tune_get("CONV_M16", 1) == 0) {       // the v_mfma_f32_32x32x16_f16 form (tools/kbench A-B only)
+        switch (e) {
+        case 0: return launch_conv_cfg<BN, TW, NH, 0>(g, st);
+        case 1: return launch_conv_cfg<BN, TW, NH, 1>(g, st);
+        case 2: return launch_conv_cfg<BN, TW, NH, 2>(g, st);
+        case 3: return launch_conv_cfg<BN, TW, NH, 3>(g, st);
+        case 4: return launch_conv_cfg<BN, TW, NH, 4>(g, st);
+        default: return -1;
         }
     }
-    switch (e) {
-    case 0: return launch_conv_cfg<BN, TW, NH, 0>(g, st);
-    case 1: return launch_conv_cfg<BN, TW, NH, 1>(g, st);
-    case 2: return launch_conv_cfg<BN, TW, NH, 2>(g, st);
-    case 3: return launch_conv_cfg<BN, TW, NH, 3>(g, st);
-    case 4: return launch_conv_cfg<BN, TW, NH, 4>(g, st);     // ReLU prologue: plain store only (residual blocks, modules.py:52,58)
-    default: return -1;
+#endif
+    if constexpr (TW == 16) {
+        switch (e) {                                             // EPI bit 3: v_mfma_f32_16x16x32_f16
+        case 0: return launch_conv_cfg<BN, TW, NH, 8>(g, st);
+        case 1: return launch_conv_cfg<BN, TW, NH, 9>(g, st);
+        case 2: return launch_conv_cfg<BN, TW, NH, 10>(g, st);
+        case 3: return launch_conv_cfg<BN, TW, NH, 11>(g, st);
+        case 4: return launch_conv_cfg<BN, TW, NH, 12>(g, st);     // ReLU prologue: plain store only (residual blocks, modules.py:52,58)
+        default: return -1;
+        }
     }
+    return -1;
 }
 
 int launch_conv_pp(const GemmArgs& g, hipStream_t st) {
     const bool one_image = g.C == 64 && !g.a2;           // a single halo image: one buffer
     if (g.N == 64) {
         // 32-pixel-wide tiles (64 px x 64 ch per wave) when the image is wide enough to fill them
+#ifdef MOGE_EXPERIMENTS
         if (one_image && g.W >= 32 && moge_tune_get("CONV_TW32", 0)) return launch_conv_epi<64, 32, 1>(g, st);
+#endif
         return one_image ? launch_conv_epi<64, 16, 1>(g, st) : launch_conv_epi<64, 16, 2>(g, st);
     }
     return one_image ? launch_conv_epi<128, 16, 1>(g, st) : launch_conv_epi<128, 16, 2>(g, st);

@@ -22,7 +22,9 @@ __device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1
 
 template <typename TIn, typename TOut>
 __global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict__ out, int B, int H, int W, int rows, int cols,
-                                  int ldk, int nchw_out, float m0, float m1, float m2, float s0, float s1, float s2) {
+                                  int ldk, int nchw_out, int round16, float m0, float m1, float m2, float s0, float s1, float s2) {
+    // round16: fp32 input whose values are first rounded to fp16 - the reference's `image.to(dtype=self.dtype)` for a .half() model
+    // (v2.py:229) - done here on load instead of as a separate cast pass over the image
     // one thread per output PIXEL: the filter ranges and weight sums depend on (oy, ox) only and serve the three channels
     // (per-channel arithmetic and its order are unchanged: horizontal pass first, then vertical, fp32)
     const int OH = rows * 14, OW = cols * 14;
@@ -46,7 +48,11 @@ __global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict_
             for (int i = 0; i < xn; i++) {
                 const float wx = tri((i + xlo - xc + 0.5f) * xis) / wxsum;
 #pragma unroll
-                for (int c = 0; c < 3; c++) h[c] += wx * (float)img[(((size_t)b * 3 + c) * H + (ylo + j)) * W + xlo + i];
+                for (int c = 0; c < 3; c++) {
+                    float pv = (float)img[(((size_t)b * 3 + c) * H + (ylo + j)) * W + xlo + i];
+                    if (round16) pv = (float)(f16)pv;
+                    h[c] += wx * pv;
+                }
             }
 #pragma unroll
             for (int c = 0; c < 3; c++) acc[c] += wy * h[c];
@@ -63,19 +69,19 @@ __global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict_
 }
 
 template <typename TIn, typename TOut>
-int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out,
+int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out, int round16,
                       const float* mean, const float* std_, hipStream_t st) {
     const long total = (long)B * rows * 14 * cols * 14;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL((preprocess_kernel<TIn, TOut>), dim3(blocks), dim3(256), 0, st, (const TIn*)img, (TOut*)out, B, H, W, rows, cols,
-                       ldk, nchw_out, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2]);
+                       ldk, nchw_out, round16, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2]);
     return (int)hipGetLastError();
 }
-template int launch_preprocess<float, f16>(const void*, void*, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
-template int launch_preprocess<float, float>(const void*, void*, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
-template int launch_preprocess<f16, f16>(const void*, void*, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
-template int launch_preprocess<f16, float>(const void*, void*, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+template int launch_preprocess<float, f16>(const void*, void*, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+template int launch_preprocess<float, float>(const void*, void*, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+template int launch_preprocess<f16, f16>(const void*, void*, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+template int launch_preprocess<f16, float>(const void*, void*, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
 
 // Caller-side ingest (scripts/infer.py:98: `torch.tensor(image / 255, dtype=torch.float32).permute(2, 0, 1)`, then v2.py:229 casts to the model
 // dtype): uint8 (B,H,W,3) -> T (B,3,H,W).  numpy divides in float64 and the tensor constructor rounds to float32 once: same here.
@@ -363,100 +369,21 @@ int launch_fold_ln(const float* W, const float* g, const float* beta, const floa
 }
 template int launch_fold_ln<f16>(const float*, const float*, const float*, const float*, void*, float*, float*, int, int, hipStream_t);
 
-#define LR_LD2(base, off) (*reinterpret_cast<const __attribute__((address_space(1))) f32x2*>((const __attribute__((address_space(1))) char*)(base) + (off)))
-#define LR_LD(base, off) (*reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((const __attribute__((address_space(1))) char*)(base) + (off)))
-// Low-register variant (<= 32 VGPRs, no LDS): the same arithmetic in the same order, but the row is re-read from L1/L2 in each of the
-// three passes instead of being held in registers, and weight / bias are fetched where they are used.  Purpose: CO-RESIDENCY.  The MFMA
-// kernels leave 32 (gemm_pp128: 2 x 240 of 512 registers per SIMD), 56 (attn_pp) or 96 (conv_pp) registers per SIMD unused, so one wave
-// of this kernel per SIMD runs NEXT TO them when the other half-batch stream is inside a GEMM / attention / conv (model.hip,
-// forward_dispatch): the HBM-bound LayerNorm would then cost no wall time of its own.  MEASURED (bench.py, vitl B=32): it does not pay - the
-// norm class goes 7.1 -> 10.6 ms (three passes, one row in flight per wave) and the step 161.1 -> 164.1 ms, i.e. the two half-batch streams did
-// not overlap it any better than the fast kernel's tails already do.  Kept behind MOGE_LN_LOWREG=1 (default off) as the record of the experiment.
-template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void layernorm_lr_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                                                const float* __restrict__ bias, T* __restrict__ out,
-                                                                                                float* __restrict__ cls_out, long rowsN, int D, int ldo,
-                                                                                                int coloff, int tap_mode, int Ntok) {
-    // wave-uniform row / weight / output bases live in SGPRs (uniform_ptr), the lane contributes one 32-bit byte offset: the loads and
-    // stores use the saddr + voffset form and no 64-bit per-lane address survives a pass
-    constexpr int LN_RPW = 4;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long row0 = (blockIdx.x * 4L + wave) * LN_RPW;
-    if (row0 >= rowsN) return;
-    const int nit = (D + 255) >> 8;
-    const float invD = 1.f / (float)D;
-    const int loff = lane * 16;                       // byte offset of this lane's 4 fp32 columns inside a 1-KiB segment
-    const int ncols = D - lane * 4;                   // column i*256 + 4*lane is in range iff i*256 < ncols
-    for (int r = 0; r < LN_RPW; r++) {
-        const long row = row0 + r;
-        if (row >= rowsN) break;
-        const char* xr = uniform_ptr(reinterpret_cast<const char*>(x + row * (long)D));
-        float s = 0.f;
-#pragma unroll 1
-        for (int i = 0; i < nit; i++) {
-            if (i * 256 < ncols) { const f32x4 v = LR_LD(xr, i * 1024 + loff); s += (v[0] + v[1]) + (v[2] + v[3]); }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float mean = s * invD;
-        float q = 0.f;
-#pragma unroll 1
-        for (int i = 0; i < nit; i++) {
-            if (i * 256 < ncols) {
-                const f32x4 v = LR_LD(xr, i * 1024 + loff);
-#pragma unroll
-                for (int e = 0; e < 4; e++) { const float a = v[e] - mean; q += a * a; }
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-        const float rstd = rsqrtf(q * invD + 1e-6f);
-        const char* op = nullptr; const char* cp = nullptr;
-        if (tap_mode) {
-            const long b = row / Ntok; const int t = (int)(row - b * Ntok);
-            if (t == 0) { if (!cls_out) continue; cp = uniform_ptr(reinterpret_cast<const char*>(cls_out + b * D)); }
-            else op = uniform_ptr(reinterpret_cast<const char*>(out + (b * (Ntok - 1) + t - 1) * (long)ldo + coloff));
-        } else {
-            op = uniform_ptr(reinterpret_cast<const char*>(out + row * (long)ldo + coloff));
-        }
-        const char* wp = reinterpret_cast<const char*>(w);
-        const char* bp = reinterpret_cast<const char*>(bias);
-#pragma unroll 1
-        for (int i = 0; i < nit; i++) {
-            if (i * 256 < ncols) {
-                const f32x4 v = LR_LD(xr, i * 1024 + loff);
-                float y[4];
-#pragma unroll
-                for (int h2 = 0; h2 < 2; h2++) {          // weight / bias in 8-byte halves: 4 fewer live registers, same fma as layernorm_kernel
-                    const f32x2 ww = LR_LD2(wp, i * 1024 + loff + 8 * h2), bb = LR_LD2(bp, i * 1024 + loff + 8 * h2);
-#pragma unroll
-                    for (int e = 0; e < 2; e++) y[2 * h2 + e] = fmaf((v[2 * h2 + e] - mean) * rstd, ww[e], bb[e]);
-                    asm volatile("" : "+v"(y[2 * h2]), "+v"(y[2 * h2 + 1]));
-                }
-                if (cp) {
-                    *reinterpret_cast<__attribute__((address_space(1))) f32x4*>((__attribute__((address_space(1))) char*)cp + (i * 1024 + loff)) = f32x4{y[0], y[1], y[2], y[3]};
-                } else if constexpr (sizeof(T) == 2) {
-                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                    *reinterpret_cast<__attribute__((address_space(1))) h4*>((__attribute__((address_space(1))) char*)op + (i * 512 + lane * 8)) =
-                        h4{(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
-                } else {
-                    *reinterpret_cast<__attribute__((address_space(1))) f32x4*>((__attribute__((address_space(1))) char*)op + (i * 1024 + loff)) = f32x4{y[0], y[1], y[2], y[3]};
-                }
-            }
-        }
-    }
-}
+#ifdef MOGE_EXPERIMENTS
+#include "experiments/layernorm_lr_exp.inc"     // low-register LayerNorm (a measured, rejected co-residency experiment)
+#endif
 
 template <typename T>
 int launch_layernorm(const float* x, const float* w, const float* b, void* out, float* cls_out, long rowsN, int D, int ldo, int coloff,
                      int tap_mode, int Ntok, hipStream_t st) {
     if (D % 4 != 0 || D > 1024 || (ldo & 3) || (coloff & 3)) return -1;
+#ifdef MOGE_EXPERIMENTS
     if (sizeof(T) == 2 && moge_tune_get("LN_LOWREG", 0)) {
         hipLaunchKernelGGL(layernorm_lr_kernel<T>, dim3((unsigned)((rowsN + 15) / 16)), dim3(256), 0, st, x, w, b, (T*)out, cls_out, rowsN, D, ldo, coloff,
                            tap_mode, Ntok);
         return (int)hipGetLastError();
     }
+#endif
     hipLaunchKernelGGL(layernorm_kernel<T>, dim3((unsigned)((rowsN + 15) / 16)), dim3(256), 0, st, x, w, b, (T*)out, cls_out, rowsN, D, ldo, coloff,
                        tap_mode, Ntok);
     return (int)hipGetLastError();

@@ -550,21 +550,32 @@ static int launch_cfg(const GemmArgs& g, hipStream_t st) {
 }
 
 // ---- runtime tuning switches: environment (MOGE_<KEY>) overridden by moge_tune_set(key, value) -------------------------
+// Process-global and shared by every handle: guarded by a mutex (two handles on two host threads = one GPU each is a supported
+// deployment).  A switch that the ENVIRONMENT moves off its default is announced once on stderr: production must not be re-routed
+// to a non-default kernel silently.
 #include <map>
+#include <mutex>
 #include <string>
 #include <type_traits>
+#include <cstdio>
 static std::map<std::string, int>& tune_table() { static std::map<std::string, int> t; return t; }
+static std::mutex& tune_mutex() { static std::mutex m; return m; }
 int moge_tune_get(const char* key, int dflt) {
+    std::lock_guard<std::mutex> lk(tune_mutex());
     auto& t = tune_table();
     auto it = t.find(key);
     if (it != t.end()) return it->second;
     const std::string env = std::string("MOGE_") + key;
     const char* e = getenv(env.c_str());
     const int v = e ? atoi(e) : dflt;
+    if (e && v != dflt) fprintf(stderr, "[libmoge_hip] %s=%d overrides the tuned default (%d): non-default kernel selection\n", env.c_str(), v, dflt);
     t[key] = v;                        // cache: launches look switches up on every call
     return v;
 }
-extern "C" void moge_tune_set(const char* key, int value) { tune_table()[key] = value; }
+extern "C" void moge_tune_set(const char* key, int value) {
+    std::lock_guard<std::mutex> lk(tune_mutex());
+    tune_table()[key] = value;
+}
 
 template <typename T, int AMODE>
 static int launch_by_n(const GemmArgs& g, hipStream_t st) {

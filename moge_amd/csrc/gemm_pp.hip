@@ -148,92 +148,9 @@ __device__ __forceinline__ f16x4 pp_quad_f16(const f32x4& a, const f32x4& b, flo
     return f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
 }
 
-// ---- 32x32x16 accumulators: tile (i, j), register quad q: row i*32 + (lane & 31), columns j*32 + 8q + 4*(lane >> 5) .. +3 ----
-template <int TM, int EPKX>
-__device__ __forceinline__ void pp_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][2], char* smem, int wave, int lane, int mw, int nw) {
-    constexpr int EPK = EpkBase<EPKX>::K;
-    constexpr bool FOLD = EpkBase<EPKX>::FOLD;
-    constexpr int TN = 2;
-    constexpr int WROWS = TM * 32;
-    const int hi = lane >> 5, l31 = lane & 31;
-    char* R = smem + wave * (WROWS * 128);
-    const int M = g.M;
-
-    if constexpr (EPK == EPK_RESID) {
-        // x[m][n] += gamma[n] * (acc + bias[n])  on the fp32 residual stream (block.py:111-112, layer_scale.py:27)
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int n = nw + j * 32 + 8 * q + 4 * hi;
-                const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
-#pragma unroll
-                for (int i = 0; i < TM; i++) {
-                    const int row = i * 32 + l31;
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = resid_term(gm[e], acc[i][j][4 * q + e], b[e]);
-                    *reinterpret_cast<f32x4*>(R + row * 128 + (((2 * q + hi) ^ (row & 7)) << 4)) = v;
-                }
-            }
-            pp_resid_rows<WROWS>(g, R, lane, mw, nw + j * 32);
-        }
-    } else {
-        // bias (+ uv rank-2 term) (+ q scale) (+ activation) in registers, pack to f16, transpose through LDS, 16-byte row stores
-        float scale = 1.f;
-        if constexpr (EPK == EPK_QKV) scale = nw < g.D ? g.qscale : 1.f;
-        float u[TM], vv[TM];
-#pragma unroll
-        for (int i = 0; i < TM; i++) { u[i] = 0.f; vv[i] = 0.f; }
-        if constexpr (EPK == EPK_UV) {
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                int m = mw + i * 32 + l31;
-                m = m < M ? m : M - 1;
-                const int x = m % g.pixW, y = (m / g.pixW) % g.pixH;
-                u[i] = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, g.pixW, x);
-                vv[i] = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, g.pixH, y);
-            }
-        }
-        const bool has_bias = g.bias != nullptr;
-        float mu[TM], rs[TM];               // LN fold: (mean, rstd) of this lane's rows
-#pragma unroll
-        for (int i = 0; i < TM; i++) { mu[i] = 0.f; rs[i] = 1.f; }
-        if constexpr (FOLD) {
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                int m = mw + i * 32 + l31;
-                m = m < M ? m : M - 1;
-                const f32x2 t = *reinterpret_cast<const f32x2*>(g.ln_mr + 2 * (size_t)m);
-                mu[i] = t[0]; rs[i] = t[1];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int n = nw + j * 32 + 8 * q + 4 * hi;
-                f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (has_bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
-                f32x4 lc = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (FOLD) lc = *reinterpret_cast<const f32x4*>(g.ln_c + n);
-                f32x4 wu = {0.f, 0.f, 0.f, 0.f}, wv = wu;
-                if constexpr (EPK == EPK_UV) {
-                    wu = *reinterpret_cast<const f32x4*>(g.uv.wu + n);
-                    wv = *reinterpret_cast<const f32x4*>(g.uv.wv + n);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; i++) {
-                    const int row = i * 32 + l31;
-                    const f32x4 a = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    const f16x4 hv = pp_quad_f16<EPK, FOLD>(a, b, scale, wu, u[i], wv, vv[i], mu[i], rs[i], lc);
-                    *reinterpret_cast<f16x4*>(R + row * 128 + ((((j * 4 + q) ^ (row & 7)) << 4) | (hi << 3))) = hv;
-                }
-            }
-        pp_store_rows<WROWS, EPK>(g, R, lane, mw, nw);
-    }
-}
+#ifdef MOGE_EXPERIMENTS
+#include "experiments/gemm_pp_exp.inc"     // 32x32x16-form kernels, 64-byte-row kernels: tools/kbench A-B builds only
+#endif
 
 // ---- 16x16x32 accumulators acc[i][j0 + jj] (128 rows x 64 columns of the wave's tile): row i*16 + (lane & 15), columns jj*16 + 4*(lane >> 4) .. +3 ----
 template <int EPKX, int NJT = 8>
@@ -314,632 +231,6 @@ __device__ __forceinline__ void pp_epilogue16(const GemmArgs& g, f32x4 (&acc)[8]
         }
         pp_store_rows<WROWS, EPK>(g, R, lane, mw, nw);
     }
-}
-
-// NS = ring slots (prefetch distance NS-1 phases).  <4,2,2,*,3>: 256x128 tile, 72 KiB LDS, <= 128 VGPRs -> TWO workgroups per
-// CU, whose epilogues / prologues overlap each other's main loops (the 256x256 kernel owns the CU and idles the MFMA pipe there)
-template <int WM, int WN, int TM, int EPK, int NS>
-__global__ __launch_bounds__(512, (TM == 2 && NS == 3) ? 4 : 2) void gemm_pp_kernel(const GemmArgs g) {
-    constexpr int TN = 2;
-    constexpr int D = NS - 1;
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    static_assert(WM * WN == 8 && BM == 256, "8 waves, 256-row tiles");
-    constexpr int SLOT = (BM + BN) * 64;          // bytes per ring slot (one phase)
-    constexpr int NPW = (BM + BN) / 128;          // DMA pieces (16 rows x 64 B) per wave per phase
-    constexpr int NPA = BM / 128;                 // the first NPA of them are A rows, the rest W rows
-    constexpr int WROWS = TM * 32;                // output rows per wave
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 * SLOT (ring), reused by the epilogue
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;                    // wave group: waves w and w+4 share a SIMD
-    const int hi = lane >> 5, l31 = lane & 31;
-    const int wm = wave / WN, wn = wave % WN;
-
-    // XCD-aware bijective remap (block b runs on XCD b % 8): every XCD owns a contiguous range of tile ids, so the
-    // 32 tiles in flight on one XCD share A row-panels / W column-panels through that XCD's L2.
-    const int nbn = g.N / BN;
-    int wg;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    }
-    const int bm = wg / nbn, bn = wg - bm * nbn;
-    const int m0 = bm * BM, n0 = bn * BN;
-    const int nph = g.K >> 5;
-
-    // ---- DMA source pointers: piece i of this wave covers ring rows [(wave + 8 i) * 16, +16) -------------------
-    const int prow = lane >> 2;
-    const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);          // logical 16-byte chunk this lane fetches
-    const f16* src[NPW];
-#pragma unroll
-    for (int i = 0; i < NPW; i++) {
-        const int r = (wave + 8 * i) * 16 + prow;
-        if (i < NPA) {
-            int m = m0 + r;
-            m = m < g.M ? m : g.M - 1;
-            src[i] = reinterpret_cast<const f16*>(g.a) + (size_t)m * g.lda + lchunk * 8;
-        } else {
-            const int n = n0 + r - BM;
-            src[i] = reinterpret_cast<const f16*>(g.w) + (size_t)n * g.ldw + lchunk * 8;
-        }
-    }
-    auto issue = [&](int ph) {
-        char* dst = smem + (ph % NS) * SLOT + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < NPW; i++)
-            __builtin_amdgcn_global_load_lds(PP_GPTR(src[i] + (size_t)ph * 32), PP_LPTR(dst + i * 8192), 16, 0, 0);
-    };
-
-    // ---- fragment read offsets (bytes inside a slot) --------------------------------------------------------------
-    const int sx = (l31 >> 2) & 3;
-    const int a_off = (wm * WROWS + l31) * 64 + ((hi ^ sx) << 4);            // k-step 0; k-step 1 is a_off ^ 32
-    const int w_off = (BM + wn * 64 + l31) * 64 + ((hi ^ sx) << 4);
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    // ---- prologue: three phases in flight, phase 0 landed for everybody, then stagger the groups ------------------
-    issue(0);
-    if (nph > 1) issue(1);
-    if (D > 2 && nph > 2) issue(2);
-    {
-        const int infl = (nph < D ? nph : D) - 1;          // phases allowed to stay in flight behind phase 0
-        if (infl >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
-        else if (infl == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1 && !(g.dbg & 8)) __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-
-    const int dbg = g.dbg;
-    u32x4 af[TM][2], wf[TN][2];
-    for (int ph = 0; ph < nph; ph++) {
-        // ======== load segment ========
-        const char* sl = smem + (ph % NS) * SLOT;
-        if (!(dbg & 2) || ph == 0) {
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            af[i][0] = *reinterpret_cast<const u32x4*>(sl + a_off + i * 2048);
-            af[i][1] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ 32) + i * 2048);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-            wf[j][0] = *reinterpret_cast<const u32x4*>(sl + w_off + j * 2048);
-            wf[j][1] = *reinterpret_cast<const u32x4*>(sl + (w_off ^ 32) + j * 2048);
-        }
-        }
-        // refill the slot phase ph-1 vacated (every wave finished reading it before the barrier that opened this segment)
-        if (dbg & 1) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        } else {
-            if (ph + D < nph) issue(ph + D);
-            // phase ph+1 must have landed (this wave's pieces); phases ph+2 .. min(ph+D, nph-1) may stay in flight
-            const int last = ph + D < nph - 1 ? ph + D : nph - 1;
-            const int infl = last - (ph + 1);
-            if (infl >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NPW) : "memory");
-            else if (infl == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        }
-        if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // ======== compute segment ========
-        __builtin_amdgcn_s_setprio(1);
-        if (!(dbg & 4))
-#pragma unroll
-        for (int s = 0; s < 2; s++)
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) mma_step<f16>(acc[i][j], wf[j][s], af[i][s]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" ::: "memory");
-        if (!(grp == 1 && ph == nph - 1) && !(dbg & 8)) __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // Every wave has passed 2*nph + 1 barriers; all LDS reads and all DMA writes of the ring are complete, so each wave
-    // may now reuse its private 16 KiB (TM = 4) / 8 KiB (TM = 2) region of the ring for the output transpose.
-
-    pp_epilogue<TM, EPK>(g, acc, smem, wave, lane, m0 + wm * WROWS, n0 + wn * 64);
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// 256 x 256 tile, full-line DMA.  The 64-byte row segments of the kernel above are served by the L2 as half-line
-// requests (measured: the DMA stream saturates the L2 request rate at ~55 % MFMA utilisation), so this variant stages
-// whole K-tiles of 64 halves = 128-byte rows (one L2 line per row) and splits a K-tile's work by OUTPUT rows instead:
-//   phase a: A rows {0-63 of the wave's 128} x W (all 64 columns) x K=64   (16 reads: 8 A + 8 W, 16 MFMAs)
-//   phase b: A rows {64-127}                 x W fragments kept in VGPRs   ( 8 reads,             16 MFMAs)
-// so W and the "lo" A rows of a K-tile are dead after phase a and the "hi" A rows after phase b; with two buffers per
-// operand every DMA piece still has three phases (six barrier intervals) to land.  DMA issue order per wave:
-//   X1(t) = {W pieces 0,1; A_lo pieces 0,1}   X2(t) = {W pieces 2,3; A_hi pieces 0,1}
-//   X1(0) X2(0) X1(1) | L_a(0): X2(1) | L_b(0): X1(2) | L_a(1): X2(2) | ...
-// counted waits: vmcnt(8) after L_a (X2(t) = A_hi(t) landed), vmcnt(6) after L_b (X1(t+1) and the W half of X2(t+1)).
-// LDS: [parity][A 256 rows x 128 B | W 256 rows x 128 B], chunk swizzle c ^ ((row >> 1) & 7).
-// ------------------------------------------------------------------------------------------------------------------------
-//
-// A3 = 1 (default): the A operand (activations: first touch comes from HBM / the Infinity Cache, ~2 us under load) gets a THREE-deep ring
-// and W (L2-resident) a two-deep one: 3 x 32 KiB + 2 x 32 KiB = all 160 KiB of LDS.  DMA issue order per wave
-//   prologue: W(0) A_lo(0) A_hi(0) A_lo(1) A_hi(1) W(1) A_lo(2)      L_a(t): A_hi(t+2)      L_b(t): W(t+2) A_lo(t+3)
-// so every A piece has two full K-tiles (four phases) to land and every W piece one full K-tile (the two-buffer order above gives
-// W pieces 2,3 a single phase).  The only counted wait is in L_b(t): everything up to W(t+1) has landed (vmcnt(10): A_lo(t+2), A_hi(t+2),
-// W(t+2), A_lo(t+3) may still be in flight); loads return in order, so A_lo(t+1) and A_hi(t+1) - issued earlier - are covered by it.
-// Measured with kbench (K = 4096, N = 1024): cache-resident A panel +12 %, no DMA at all +44 %: the main loop is latency-exposed.
-template <int EPK, int A3>
-__global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(const GemmArgs g) {
-    constexpr int TM = 4, TN = 2, WN = 4, BM = 256, BN = 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 * 64 KiB, or 3 * 32 KiB (A ring) + 2 * 32 KiB (W ring)
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int hi = lane >> 5, l31 = lane & 31;
-    const int wm = wave / WN, wn = wave % WN;
-
-    const int nbn = g.N / BN;
-    int wg;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    }
-    // tile order: column groups of 4 tiles, rows fastest inside a group -> the 32 tiles an XCD has in flight are 8 row panels
-    // x 4 column panels, and the group's W panels (4 x 256 rows x K) stay in that XCD's 4 MiB L2 while it walks down the rows
-    int bm, bn;
-    {
-        const int nbm = (g.M + BM - 1) / BM;
-        const int grp_cols = 4, per_grp = nbm * grp_cols;
-        const int cg = wg / per_grp, rem = wg - cg * per_grp;
-        const int cols = min(grp_cols, nbn - cg * grp_cols);
-        bm = rem / cols;
-        bn = cg * grp_cols + (rem - bm * cols);
-    }
-    const int m0 = bm * BM, n0 = bn * BN;
-    const int nkt = g.K >> 6;
-    const int dbg = g.dbg;
-    unsigned long long* ts = (g.dbg_ts && blockIdx.x == 777 && lane == 0) ? g.dbg_ts + wave * 8 : nullptr;
-    if (ts) { ts[0] = __builtin_amdgcn_s_memtime(); ts[5] = __builtin_readcyclecounter(); ts[6] = wall_clock64(); }
-    // Phase stagger: every CU's first block starts delayed by a fraction of a tile's main-loop time, so that the epilogue
-    // store / read-modify-write bursts of the CUs (all tiles take the same time) do not hit HBM at the same instant.
-    if (g.stagger > 1 && blockIdx.x < 256) {
-        const int cls = (blockIdx.x >> 3) % g.stagger;
-        const int units = (cls * nkt * 2) / (5 * g.stagger);        // x 8128 cycles (main loop ~ 3300 cycles per K-tile)
-        for (int i = 0; i < units; i++) __builtin_amdgcn_s_sleep(127);
-    }
-
-    // ---- DMA sources.  A piece = 8 rows x 128 B; this wave's pieces start at rows 8*wave (+ region offsets), so the
-    // swizzle term ((row >> 1) & 7) = 4*(wave & 1) + (lane >> 4) is the same for all of them.
-    const int prow = lane >> 3;
-    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) + (lane >> 4));
-    // uniform 64-bit tile bases (SGPRs) + per-lane 32-bit byte offsets: the DMA uses the saddr + voffset form and the
-    // load segment carries no 64-bit VALU address arithmetic
-    const char* baseW = reinterpret_cast<const char*>(g.w) + (size_t)((dbg & 128) ? 0 : n0) * g.ldw * 2;     // dbg 64 / 128: every tile reads
-    const char* baseA = reinterpret_cast<const char*>(g.a) + (size_t)((dbg & 64) ? 0 : m0) * g.lda * 2;      // panel 0 (cache-resident operand)
-    unsigned offW[4], offA[4];     // A: 0,1 = lo rows (8w, 128+8w)   2,3 = hi rows (64+8w, 192+8w)
-    const int mlast = g.M - 1 - m0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        offW[k] = (unsigned)(((wave + 8 * k) * 8 + prow) * g.ldw * 2 + lchunk * 16);
-        int arow = (k & 1) * 128 + (k >> 1) * 64 + wave * 8 + prow;
-        arow = arow < mlast ? arow : mlast;
-        offA[k] = (unsigned)(arow * g.lda * 2 + lchunk * 16);
-    }
-    // X1(t): W pieces 0,1 + A lo; X2(t): W pieces 2,3 + A hi   (W first inside X2: the vmcnt(6) count relies on it)
-    auto issue = [&](int t, int second) {
-        char* base = smem + (t & 1) * 65536;
-        const char* gw = uniform_ptr(baseW + (size_t)t * 128);       // keep the K advance on the scalar unit (defeats LSR's
-        const char* ga = uniform_ptr(baseA + (size_t)t * 128);       // per-lane 64-bit pointer induction variables)
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int kw = second * 2 + k;
-            __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[kw]), PP_LPTR(base + 32768 + (wave + 8 * kw) * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int ka = second * 2 + k;
-            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + offA[ka]), PP_LPTR(base + (k * 128 + second * 64 + wave * 8) * 128), 16, 0, 0);
-        }
-    };
-    // A3 layout: A slot s at s * 32 KiB (s = t mod 3), W buffer at 96 KiB + (t & 1) * 32 KiB
-    auto issue_w = [&](int t) {
-        char* base = smem + 98304 + (t & 1) * 32768;
-        const char* gw = uniform_ptr(baseW + (size_t)t * 128);
-#pragma unroll
-        for (int kw = 0; kw < 4; kw++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[kw]), PP_LPTR(base + (wave + 8 * kw) * 1024), 16, 0, 0);
-    };
-    auto issue_a = [&](int t, int slot, int hi_rows) {
-        char* base = smem + slot * 32768;
-        const char* ga = uniform_ptr(baseA + (size_t)t * 128);
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + offA[hi_rows * 2 + k]), PP_LPTR(base + (k * 128 + hi_rows * 64 + wave * 8) * 128), 16, 0, 0);
-    };
-
-    const int sx = (l31 >> 1) & 7;
-    const int a_off = (wm * 128 + l31) * 128 + ((hi ^ sx) << 4);             // k-step ks: a_off ^ (ks * 32)
-    const int w_off = (A3 ? 0 : 32768) + (wn * 64 + l31) * 128 + ((hi ^ sx) << 4);
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    if constexpr (A3) {
-        issue_w(0); issue_a(0, 0, 0); issue_a(0, 0, 1);
-        if (nkt > 1) { issue_a(1, 1, 0); issue_a(1, 1, 1); issue_w(1); }
-        if (nkt > 2) {
-            issue_a(2, 2, 0);
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        } else if (nkt > 1) {
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    } else {
-        issue(0, 0);
-        issue(0, 1);
-        if (nkt > 1) {
-            issue(1, 0);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        }
-    }
-    __builtin_amdgcn_s_barrier();
-    u32x4 af[2][4], wf[TN][4];
-    if constexpr (A3 == 2) {                      // fragments of phase a(0): W(0), A_lo(0)
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-#pragma unroll
-            for (int j = 0; j < TN; j++) wf[j][ks] = *reinterpret_cast<const u32x4*>(smem + 98304 + (w_off ^ (ks * 32)) + j * 4096);
-#pragma unroll
-            for (int i = 0; i < 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(smem + (a_off ^ (ks * 32)) + i * 4096);
-        }
-    }
-    if (grp == 1 && !(dbg & 8)) __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-
-    if (ts) ts[1] = __builtin_amdgcn_s_memtime();
-    int sa = 0;                                   // t mod 3 (A3)
-    if constexpr (A3 == 2) {
-        // Fragment reads live in the COMPUTE segments: the registers of K-step ks are reloaded right after the four MFMAs that used them
-        // (phase a: A_hi(t) for phase b; phase b: W(t+1), A_lo(t+1) for the next phase a), so the LDS traffic is spread evenly, its latency is
-        // covered by the remaining MFMAs and the "load" segment is only DMA issue + counted wait + barrier.  Segment clock (one barrier
-        // interval each): group 0 runs L_a(t) C_a(t) L_b(t) C_b(t) in intervals 4t .. 4t+3, group 1 one interval later.  W(t+1) / A_lo(t+1) are
-        // read from interval 4t+3 on, so EVERY wave confirms its pieces of them before the barrier that ends interval 4t+2: group 0 in
-        // L_b(t) (vmcnt(10): A_lo(t+2) A_hi(t+2) W(t+2) A_lo(t+3) may be in flight), group 1 at the end of C_a(t) (vmcnt(4): A_lo(t+2) A_hi(t+2)).
-        // Ring slots are rewritten only after the barrier that follows the lgkmcnt(0) of their last reader (see the issue points).
-        for (int t = 0; t < nkt; t++) {
-            const char* sl = smem + sa * 32768;
-            const int sn = sa == 2 ? 0 : sa + 1;
-            const char* sl_n = smem + sn * 32768;                                          // A slot of K-tile t+1
-            const char* slw_n = smem + 98304 + ((t + 1) & 1) * 32768;                      // W buffer of K-tile t+1
-            const int sa2 = sa == 0 ? 2 : sa - 1;                                          // (t + 2) mod 3
-            // ======== L_a ========
-            if (t + 2 < nkt) issue_a(t + 2, sa2, 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            // ======== C_a ========
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int j = 0; j < TN; j++) mma_step<f16>(acc[i][j], wf[j][ks], af[i][ks]);
-#pragma unroll
-                for (int i = 0; i < 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 32)) + (2 + i) * 4096);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            if (grp == 1) {
-                if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            // ======== L_b ========
-            if (t + 3 < nkt) {
-                issue_w(t + 2);
-                issue_a(t + 3, sa, 0);
-                if (grp == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            } else if (t + 2 < nkt) {
-                issue_w(t + 2);
-                if (grp == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            } else {
-                if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            // ======== C_b ========
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int j = 0; j < TN; j++) mma_step<f16>(acc[2 + i][j], wf[j][ks], af[i][ks]);
-#pragma unroll
-                for (int j = 0; j < TN; j++) wf[j][ks] = *reinterpret_cast<const u32x4*>(slw_n + (w_off ^ (ks * 32)) + j * 4096);
-#pragma unroll
-                for (int i = 0; i < 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl_n + (a_off ^ (ks * 32)) + i * 4096);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            asm volatile("" ::: "memory");
-            if (!(grp == 1 && t == nkt - 1)) __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            sa = sn;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the (unused) fragment reads of the last phase b
-    } else
-    for (int t = 0; t < nkt; t++) {
-        const char* sl = A3 ? smem + sa * 32768 : smem + (t & 1) * 65536;                  // A rows of this K-tile
-        const char* slw = A3 ? smem + 98304 + (t & 1) * 32768 : sl;                        // W rows
-        const int sa2 = sa == 0 ? 2 : sa - 1;                                              // (t + 2) mod 3
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            // ======== load segment ========
-            if (!(dbg & 2) || t == 0) {
-                if (half == 0) {
-#pragma unroll
-                    for (int j = 0; j < TN; j++)
-#pragma unroll
-                        for (int ks = 0; ks < 4; ks++) wf[j][ks] = *reinterpret_cast<const u32x4*>(slw + (w_off ^ (ks * 32)) + j * 4096);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ks++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 32)) + (half * 2 + i) * 4096);
-            }
-            if (dbg & 1) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            } else if (A3) {
-                if (half == 0) {
-                    if (t + 2 < nkt) issue_a(t + 2, sa2, 1);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                } else {
-                    if (t + 3 < nkt) {
-                        issue_w(t + 2);
-                        issue_a(t + 3, sa, 0);
-                        asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-                    } else if (t + 2 < nkt) {
-                        issue_w(t + 2);
-                        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                    } else {
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    }
-                }
-            } else if (half == 0) {
-                if (t + 1 < nkt) {
-                    issue(t + 1, 1);
-                    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                }
-            } else {
-                if (t + 2 < nkt) {
-                    issue(t + 2, 0);
-                    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-                } else if (t + 1 < nkt) {
-                    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                }
-            }
-            if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            // ======== compute segment ========
-            __builtin_amdgcn_s_setprio(1);
-            if (!(dbg & 4))
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++)
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int j = 0; j < TN; j++) mma_step<f16>(acc[half * 2 + i][j], wf[j][ks], af[i][ks]);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" ::: "memory");
-            if (!(grp == 1 && half == 1 && t == nkt - 1) && !(dbg & 8)) __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        sa = sa == 2 ? 0 : sa + 1;
-    }
-    if (ts) ts[2] = __builtin_amdgcn_s_memtime();
-    if (dbg & 32) {          // ablation: no epilogue (keep the accumulators alive)
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
-    pp_epilogue<TM, EPK>(g, acc, smem, wave, lane, m0 + wm * 128, n0 + wn * 64);
-    if (ts) {
-        ts[3] = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ts[4] = __builtin_amdgcn_s_memtime();
-        ts[7] = wall_clock64();                                  // constant 100 MHz: (ts[4] - ts[0]) / (ts[7] - ts[6]) * 100 = shader clock in MHz
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// 256 x 256 tile, FOUR waves (one per SIMD), 128 x 128 per wave: 16 accumulator tiles = 256 registers, W fragments of a whole
-// K-tile (4 column blocks x 4 K-steps = 64 registers) + one row half of A (32) resident.  Against the 8-wave kernel above: one
-// third less LDS fragment traffic per MFMA (each A fragment feeds 4 MFMAs, each W fragment 4), half the wave-instruction issue
-// for the DMA, no partner wave - the fragment reloads and the DMA issue sit BETWEEN the MFMAs of the same wave:
-//   C_a(t): rows 0-63 of the wave (blocks i = 0,1): per K-step ks 8 MFMAs, then reload af[.][ks] <- A_hi(t), then 4 DMA pieces
-//   C_b(t): rows 64-127:                            per K-step ks 8 MFMAs, then reload wf[.][ks] <- W(t+1), af[.][ks] <- A_lo(t+1)
-// and ONE synchronisation point per K-tile, where the fragments read during C_b(t-1) are needed anyway:
-//   L(t): lgkmcnt(0); vmcnt(8) = everything up to W(t+1) has landed (A_hi(t+1), A_lo(t+2) may be in flight); s_barrier
-// after which W(t)'s buffer, A_lo(t) and A_hi(t-1) are dead in every wave and receive W(t+2), A_lo(t+3), A_hi(t+2) (issued during
-// C_a(t)): A pieces have two K-tiles to land, W pieces one.  LDS: A ring 3 x 32 KiB (slot = t mod 3), W ring 2 x 32 KiB.
-// ------------------------------------------------------------------------------------------------------------------------
-template <int EPK>
-__global__ __launch_bounds__(256, 1) void gemm_pp4w_kernel(const GemmArgs g) {
-    constexpr int BM = 256, BN = 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 160 KiB
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi = lane >> 5, l31 = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int nbn = g.N / BN;
-    int wg;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    }
-    int bm, bn;
-    {
-        const int nbm = (g.M + BM - 1) / BM;
-        const int grp_cols = 4, per_grp = nbm * grp_cols;
-        const int cg = wg / per_grp, rem = wg - cg * per_grp;
-        const int cols = min(grp_cols, nbn - cg * grp_cols);
-        bm = rem / cols;
-        bn = cg * grp_cols + (rem - bm * cols);
-    }
-    const int m0 = bm * BM, n0 = bn * BN;
-    const int nkt = g.K >> 6;
-
-    // DMA pieces (8 rows x 128 B).  W: rows (wave + 4 kw) * 8, kw = 0..7.  A lo / hi (k = 0..3): rows (k >> 1) * 128 [+ 64] + (k & 1) * 32 + wave * 8.
-    // All piece bases are multiples of 8 with (base >> 1) & 7 = 4 * (wave & 1): one swizzle term per lane.
-    const int prow = lane >> 3;
-    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) + (lane >> 4));
-    const char* baseW = reinterpret_cast<const char*>(g.w) + (size_t)n0 * g.ldw * 2;
-    const char* baseA = reinterpret_cast<const char*>(g.a) + (size_t)m0 * g.lda * 2;
-    unsigned offW[8], offAlo[4], offAhi[4];
-    const int mlast = g.M - 1 - m0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) offW[k] = (unsigned)(((wave + 4 * k) * 8 + prow) * g.ldw * 2 + lchunk * 16);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int r0 = (k >> 1) * 128 + (k & 1) * 32 + wave * 8 + prow, r1 = r0 + 64;
-        r0 = r0 < mlast ? r0 : mlast;
-        r1 = r1 < mlast ? r1 : mlast;
-        offAlo[k] = (unsigned)(r0 * g.lda * 2 + lchunk * 16);
-        offAhi[k] = (unsigned)(r1 * g.lda * 2 + lchunk * 16);
-    }
-    auto issue_w = [&](int t, int k0) {           // 4 of the 8 W pieces of K-tile t
-        char* base = smem + 98304 + (t & 1) * 32768;
-        const char* gw = uniform_ptr(baseW + (size_t)t * 128);
-#pragma unroll
-        for (int k = k0; k < k0 + 4; k++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[k]), PP_LPTR(base + (wave + 4 * k) * 1024), 16, 0, 0);
-    };
-    auto issue_a = [&](int t, int slot, int hi_rows) {
-        char* base = smem + slot * 32768 + hi_rows * 8192;
-        const char* ga = uniform_ptr(baseA + (size_t)t * 128);
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + (hi_rows ? offAhi[k] : offAlo[k])), PP_LPTR(base + ((k >> 1) * 128 + (k & 1) * 32 + wave * 8) * 128), 16, 0, 0);
-    };
-
-    const int sx = (l31 >> 1) & 7;
-    const int a_off = (wm * 128 + l31) * 128 + ((hi ^ sx) << 4);             // K-step ks: a_off ^ (ks * 32); 32-row block i: + i * 4096
-    const int w_off = (wn * 128 + l31) * 128 + ((hi ^ sx) << 4);
-
-    f32x16 accL[4][2], accR[4][2];               // columns 0-63 / 64-127 of the wave's 128 (the epilogue takes 64-column halves)
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) { accL[i][j][r] = 0.f; accR[i][j][r] = 0.f; }
-
-    // prologue: the issue order continues the steady-state queue  L(s): W(s+2) A_hi(s+2) A_lo(s+3)
-    issue_a(0, 0, 0); issue_w(0, 0); issue_w(0, 4); issue_a(0, 0, 1);
-    if (nkt > 1) { issue_a(1, 1, 0); issue_w(1, 0); issue_w(1, 4); issue_a(1, 1, 1); }
-    if (nkt > 2) issue_a(2, 2, 0);
-    if (nkt > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");          // A_lo(0), W(0) landed
-    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    u32x4 af[2][4], wf[4][4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) wf[j][ks] = *reinterpret_cast<const u32x4*>(smem + 98304 + (w_off ^ (ks * 32)) + j * 4096);
-#pragma unroll
-        for (int i = 0; i < 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(smem + (a_off ^ (ks * 32)) + i * 4096);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    int sa = 0;                                   // t mod 3
-    for (int t = 0; t < nkt; t++) {
-        const char* sl = smem + sa * 32768;
-        const int sn = sa == 2 ? 0 : sa + 1;
-        const int sa2 = sa == 0 ? 2 : sa - 1;                                              // (t + 2) mod 3
-        const char* sl_n = smem + sn * 32768;
-        const char* slw_n = smem + 98304 + ((t + 1) & 1) * 32768;
-        // ======== L(t) ========
-        if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // ======== C_a(t) ========
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-#pragma unroll
-                for (int j = 0; j < 2; j++) mma_step<f16>(accL[i][j], wf[j][ks], af[i][ks]);
-#pragma unroll
-                for (int j = 0; j < 2; j++) mma_step<f16>(accR[i][j], wf[2 + j][ks], af[i][ks]);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 32)) + (2 + i) * 4096);
-            if (ks < 2) { if (t + 2 < nkt) issue_w(t + 2, ks * 4); }
-            else if (ks == 2) { if (t + 2 < nkt) issue_a(t + 2, sa2, 1); }
-            else { if (t + 3 < nkt) issue_a(t + 3, sa, 0); }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ======== C_b(t) ========
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-#pragma unroll
-                for (int j = 0; j < 2; j++) mma_step<f16>(accL[2 + i][j], wf[j][ks], af[i][ks]);
-#pragma unroll
-                for (int j = 0; j < 2; j++) mma_step<f16>(accR[2 + i][j], wf[2 + j][ks], af[i][ks]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) wf[j][ks] = *reinterpret_cast<const u32x4*>(slw_n + (w_off ^ (ks * 32)) + j * 4096);
-#pragma unroll
-            for (int i = 0; i < 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl_n + (a_off ^ (ks * 32)) + i * 4096);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        sa = sn;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the (unused) fragment reads of the last C_b
-    __builtin_amdgcn_s_barrier();                            // every wave is done with the rings: private epilogue regions
-    asm volatile("" ::: "memory");
-    pp_epilogue<4, EPK>(g, accL, smem, wave, lane, m0 + wm * 128, n0 + wn * 128);
-    pp_epilogue<4, EPK>(g, accR, smem, wave, lane, m0 + wm * 128, n0 + wn * 128 + 64);
 }
 
 template <int EPK>
@@ -1091,10 +382,10 @@ __global__ __launch_bounds__(256, 1) void gemm_pp4w16_kernel(const GemmArgs g) {
     pp_epilogue16<EPK>(g, acc, 4, smem, wave, lane, m0 + wm * 128, n0 + wn * 128 + 64);
 }
 
-template <int EPK, int MF16>
-static int launch_pp4w(const GemmArgs& g, hipStream_t st) {
+template <int EPK>
+static int launch_pp4w16(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = 163840;
-    constexpr auto kern = MF16 ? gemm_pp4w16_kernel<EPK> : gemm_pp4w_kernel<EPK>;
+    constexpr auto kern = gemm_pp4w16_kernel<EPK>;
     if (int rc = set_dyn_lds<kern>(smem)) return rc;
     const long nbm = (g.M + 255) / 256, nbn = g.N / 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(256), smem, st, g);
@@ -1254,6 +545,7 @@ static int launch_pp128m16(const GemmArgs& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+#ifdef MOGE_EXPERIMENTS
 template <int EPK, int A3>
 static int launch_pp128_cfg(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = A3 ? 163840 : 2 * 65536;
@@ -1264,15 +556,14 @@ static int launch_pp128_cfg(const GemmArgs& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 template <int EPK>
-static int launch_pp128(const GemmArgs& g, hipStream_t st) {
-    const int w4 = moge_tune_get("PP_4W", 0);
-    if (w4 == 3 || (w4 == 0 && moge_tune_get("PP_M16", 1))) return launch_pp128m16<EPK>(g, st);
-    if (w4 == 2) return launch_pp4w<EPK, 1>(g, st);
-    if (w4) return launch_pp4w<EPK, 0>(g, st);
-    const int a3 = moge_tune_get("PP_A3", 1);
-    return a3 == 2 ? launch_pp128_cfg<EPK, 2>(g, st) : a3 ? launch_pp128_cfg<EPK, 1>(g, st) : launch_pp128_cfg<EPK, 0>(g, st);
+static int launch_pp4w32(const GemmArgs& g, hipStream_t st) {
+    constexpr int smem = 163840;
+    constexpr auto kern = gemm_pp4w_kernel<EPK>;
+    if (int rc = set_dyn_lds<kern>(smem)) return rc;
+    const long nbm = (g.M + 255) / 256, nbn = g.N / 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(256), smem, st, g);
+    return (int)hipGetLastError();
 }
-
 template <int WM, int WN, int TM, int EPK, int NS = 4>
 static int launch_pp_cfg(const GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * 64;
@@ -1283,25 +574,25 @@ static int launch_pp_cfg(const GemmArgs& g, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(512), smem, st, g);
     return (int)hipGetLastError();
 }
+#endif
 
-// Shapes / epilogues the ping-pong kernel takes (f16, LINEAR mode only).  bn256 = prefer the 256-wide tile.
+// Shapes / epilogues the ping-pong kernels take (f16, LINEAR mode only): 256 x 256 tiles of full 128-byte K rows.  Both product kernels
+// (gemm_pp128m16_kernel: 8 waves; gemm_pp4w16_kernel: 4 waves) and the latency-regime kernels of gemm.hip issue v_mfma_f32_16x16x32_f16 over the
+// same K grouping and share the epilogue arithmetic, so a GEMM's result does not depend on which of them its size selects
+// (tests/test_hip_gemm_pp.py compares them bit for bit, every epilogue flavour).
 bool gemm_pp_eligible(const GemmArgs& g) {
     if (g.relu_in || g.add) return false;
-    // PP_M16 (default): the 256x256 kernel runs on v_mfma_f32_16x16x32_f16, like the 128x128 latency-regime kernel of gemm.hip.  The
-    // 64-byte-row kernels (N % 256 != 0 or K % 64 != 0) still accumulate in the 32x32x16 order, so they are left out: those shapes go to
-    // gemm.hip at every batch size and a GEMM's result never depends on the batch-size-driven kernel choice.
-    if (moge_tune_get("PP_M16", 1) && ((g.N % 256) || (g.K & 63) || (g.epi == EPI_QKV && (g.D % 256)))) return false;
-    if (g.ln_mr) {          // LN-fold consumer: QKV / GELU flavours of the 256x256 kernel
-        if ((g.N % 256) || (g.K & 63) || !g.ln_c || !g.bias) return false;
-        if (!(g.epi == EPI_QKV ? (g.D % 256) == 0 : (g.epi == EPI_STORE && g.act == ACT_GELU && !g.uv.wu))) return false;
-    }
-    if (g.x16 && (g.epi != EPI_RESID || !g.ln_part || (g.N & 31))) return false;
-    if (g.K < 64 || (g.K & 31) || (g.N & 127) || g.M < 256) return false;
+    if ((g.N % 256) || (g.K & 63) || g.K < 64 || g.M < 256) return false;
     if ((g.lda & 7) || (g.ldw & 7)) return false;
+    if (g.ln_mr) {          // LN-fold consumer: QKV / GELU flavours
+        if (!g.ln_c || !g.bias) return false;
+        if (!(g.epi == EPI_QKV || (g.epi == EPI_STORE && g.act == ACT_GELU && !g.uv.wu))) return false;
+    }
+    if (g.x16 && (g.epi != EPI_RESID || !g.ln_part)) return false;
     switch (g.epi) {
     case EPI_STORE: return (g.ldc & 7) == 0 && (!g.uv.wu || g.bias);
     case EPI_RESID: return g.bias && g.gamma && (g.ldc & 3) == 0;
-    case EPI_QKV: return g.v_rowmajor && g.D % 128 == 0 && g.Ntok >= 128 && g.N == 3 * g.D && g.bias;
+    case EPI_QKV: return g.v_rowmajor && g.D % 256 == 0 && g.Ntok >= 128 && g.N == 3 * g.D && g.bias;
     case EPI_CONVT: return g.Cout % 64 == 0 && g.pixW >= 8 && !g.uv.wu;
     default: return false;
     }
@@ -1320,32 +611,42 @@ static int epilogue_kind(const GemmArgs& g) {
     return EPK_STORE;
 }
 
+// PP_KERN: 0 = gemm_pp128m16_kernel (8 waves, ping-pong groups), 1 = gemm_pp4w16_kernel (4 waves, 128 x 128 per wave), -1 = by shape (default)
 template <int EPK>
-static int launch_pp_any(const GemmArgs& g, bool wide, hipStream_t st) {
-    if (moge_tune_get("PP_NARROW", 0)) return launch_pp_cfg<4, 2, 2, EPK, 3>(g, st);       // 256x128 tiles, two workgroups per CU
-    if (wide && (g.K & 63) == 0 && moge_tune_get("PP_ROW128", 1)) return launch_pp128<EPK>(g, st);
-    return wide ? launch_pp_cfg<2, 4, 4, EPK>(g, st) : launch_pp_cfg<4, 2, 2, EPK>(g, st);
+static int launch_pp_any(const GemmArgs& g, hipStream_t st) {
+#ifdef MOGE_EXPERIMENTS
+    switch (moge_tune_get("PP_EXP", 0)) {              // tools/kbench A-B only
+    case 1: return launch_pp128_cfg<EPK, 1>(g, st);
+    case 2: return launch_pp128_cfg<EPK, 2>(g, st);
+    case 3: return launch_pp128_cfg<EPK, 0>(g, st);
+    case 4: return launch_pp4w32<EPK>(g, st);
+    case 5: return launch_pp_cfg<2, 4, 4, EPK>(g, st);
+    case 6: return launch_pp_cfg<4, 2, 2, EPK, 3>(g, st);
+    default: break;
+    }
+#endif
+    int kern = moge_tune_get("PP_KERN", -1);
+    if (kern < 0) kern = 0;
+    return kern == 1 ? launch_pp4w16<EPK>(g, st) : launch_pp128m16<EPK>(g, st);
 }
 
 int launch_gemm_pp(const GemmArgs& g0, hipStream_t st) {
     GemmArgs g = g0;
     g.dbg = moge_tune_get("PP_DBG", 0);
-    g.stagger = moge_tune_get("PP_STAGGER", 0);
+    g.stagger = 0;
     {
         const int nt = moge_tune_get("NT_STORE", 0);        // bit 0: GELU (MLP hidden), bit 1: QKV, bit 2: plain stores
         g.nt_store = (g.epi == EPI_QKV) ? (nt >> 1) & 1 : (g.act == ACT_GELU ? nt & 1 : (nt >> 2) & 1);
     }
-    const bool wide = (g.N % 256) == 0 && !(g.epi == EPI_QKV && (g.D % 256) != 0);
     switch (epilogue_kind(g)) {
-    case EPK_RESID: return launch_pp_any<EPK_RESID>(g, wide, st);
-    case EPK_QKV: return launch_pp_any<EPK_QKV>(g, wide, st);
-    case EPK_CONVT: return launch_pp_any<EPK_CONVT>(g, wide, st);
-    case EPK_UV: return launch_pp_any<EPK_UV>(g, wide, st);
-    case EPK_GELU: return launch_pp_any<EPK_GELU>(g, wide, st);
-    case EPK_GELU_LN:       // LN-fold consumers: the 256x256 kernels only (gemm_pp_eligible)
-        return moge_tune_get("PP_M16", 1) ? launch_pp128m16<EPK_GELU_LN>(g, st) : launch_pp128_cfg<EPK_GELU_LN, 1>(g, st);
-    case EPK_QKV_LN: return moge_tune_get("PP_M16", 1) ? launch_pp128m16<EPK_QKV_LN>(g, st) : launch_pp128_cfg<EPK_QKV_LN, 1>(g, st);
-    case EPK_RELU: return launch_pp_any<EPK_RELU>(g, wide, st);
-    default: return launch_pp_any<EPK_STORE>(g, wide, st);
+    case EPK_RESID: return launch_pp_any<EPK_RESID>(g, st);
+    case EPK_QKV: return launch_pp_any<EPK_QKV>(g, st);
+    case EPK_CONVT: return launch_pp_any<EPK_CONVT>(g, st);
+    case EPK_UV: return launch_pp_any<EPK_UV>(g, st);
+    case EPK_GELU: return launch_pp_any<EPK_GELU>(g, st);
+    case EPK_GELU_LN: return launch_pp_any<EPK_GELU_LN>(g, st);
+    case EPK_QKV_LN: return launch_pp_any<EPK_QKV_LN>(g, st);
+    case EPK_RELU: return launch_pp_any<EPK_RELU>(g, st);
+    default: return launch_pp_any<EPK_STORE>(g, st);
     }
 }

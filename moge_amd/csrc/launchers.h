@@ -8,7 +8,7 @@ template <typename T> int launch_attention(const void* q, const void* k, const v
 int launch_attention_pp(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st);
 
 template <typename TIn, typename TOut>
-int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out, const float* mean,
+int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out, int round16, const float* mean,
                       const float* std_, hipStream_t st);
 template <typename T> int launch_zero_cols(void* a, long rowsN, int ldk, int kfrom, hipStream_t st);
 // LN fold (fp16 path): fp16 copy + (mean, rstd) of the first block's input; partial sums -> (mean, rstd); weight folding at pack time

@@ -582,10 +582,11 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     // ---- K0: resize + normalise + patchify (modules.py:121-122, patch_embed.py:75) ------------------------------
     const float* mean = h->img_mean; const float* sd = h->img_std;
     {
-        ProfScope ps(h, st, MOGE_KC_PRE, 0, (double)B * 3 * pl.H * pl.W * (img_dtype ? 2 : 4) + (double)BP * KPATCH_PAD * sizeof(T));
+        ProfScope ps(h, st, MOGE_KC_PRE, 0, (double)B * 3 * pl.H * pl.W * (img_dtype == 1 ? 2 : 4) + (double)BP * KPATCH_PAD * sizeof(T));
         LCHK(launch_zero_cols<T>(patches, BP, KPATCH_PAD, KPATCH, st));
-        if (img_dtype == 0) LCHK((launch_preprocess<float, T>(image, patches, B, pl.H, pl.W, rows, cols, KPATCH_PAD, 0, mean, sd, st)));
-        else LCHK((launch_preprocess<f16, T>(image, patches, B, pl.H, pl.W, rows, cols, KPATCH_PAD, 0, mean, sd, st)));
+        // img_dtype 3 = fp32 values to be rounded to fp16 on load (the model-dtype cast of a .half() model, v2.py:229)
+        if (img_dtype == 0 || img_dtype == 3) LCHK((launch_preprocess<float, T>(image, patches, B, pl.H, pl.W, rows, cols, KPATCH_PAD, 0, img_dtype == 3, mean, sd, st)));
+        else LCHK((launch_preprocess<f16, T>(image, patches, B, pl.H, pl.W, rows, cols, KPATCH_PAD, 0, 0, mean, sd, st)));
     }
     const float* pos;
     CHK(get_pos(h, rows, cols, st, &pos));
@@ -944,7 +945,7 @@ static int forward_dispatch(moge_handle* h, const void* image, int img_dtype, co
     CHK(get_pos(h, pl.rows, pl.cols, st, &pos));   // fill the position-embedding cache before forking
     HIPCHK(hipEventRecord(h->ev_fork, st));
     const size_t px = (size_t)pl.H * pl.W;
-    const size_t img_elem = img_dtype ? 2 : 4;
+    const size_t img_elem = img_dtype == 1 ? 2 : 4;
     for (int i = 0; i < 2; i++) {
         const size_t b0 = i == 0 ? 0 : (size_t)Bs[0];
         HIPCHK(hipStreamWaitEvent(h->split_st[i], h->ev_fork, 0));
@@ -968,7 +969,8 @@ static int forward_dispatch(moge_handle* h, const void* image, int img_dtype, co
 // scripts/infer.py:98); the rest of the path then sees an ordinary fp32 / fp16 image.
 static int ingest_image(moge_handle* h, const void*& image, int& img_dtype, int B, int H, int W, hipStream_t st) {
     if (img_dtype != 2) {
-        if (img_dtype != 0 && img_dtype != 1) return fail(MOGE_ERR_INVALID, "img_dtype must be 0 (fp32 CHW), 1 (fp16 CHW) or 2 (uint8 HWC)");
+        if (img_dtype != 0 && img_dtype != 1 && img_dtype != 3)
+            return fail(MOGE_ERR_INVALID, "img_dtype must be 0 (fp32 CHW), 1 (fp16 CHW), 2 (uint8 HWC) or 3 (fp32 CHW, rounded to fp16 on load)");
         return 0;
     }
     const bool half = h->prec == MOGE_FP16;

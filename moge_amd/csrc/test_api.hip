@@ -40,6 +40,63 @@ static int t_gemm(const float* A, const float* W, const float* bias, float* C, i
 }
 
 template <typename T>
+static int t_gemm_ex(const moge_test_gemm_args& a, hipStream_t st) {
+    const int M = a.M, N = a.N, K = a.K;
+    if (K % TT<T>::CH) return MOGE_ERR_INVALID;
+    DevBuf ab, wb, ob, x16, qb, kb, vb;
+    TCHK(ab.alloc((size_t)M * K * sizeof(T))); TCHK(wb.alloc((size_t)N * K * sizeof(T)));
+    TL(to_t<T>(a.A, ab.p, (long)M * K, st));
+    TL(to_t<T>(a.W, wb.p, (long)N * K, st));
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.a = ab.p; g.lda = K; g.w = wb.p; g.ldw = K; g.M = M; g.N = N; g.K = K;
+    g.bias = a.bias; g.act = a.act; g.ln_mr = a.ln_mr; g.ln_c = a.ln_c;
+    g.pixW = a.pixW; g.pixH = a.pixH;
+    const size_t mn = (size_t)M * N;
+    switch (a.kind) {
+    case MOGE_TG_STORE:
+        TCHK(ob.alloc(mn * sizeof(T)));
+        g.epi = EPI_STORE; g.out = ob.p; g.ldc = N;
+        if (a.wu) {
+            g.uv.wu = a.wu; g.uv.wv = a.wv; g.uv.u0 = a.u0; g.uv.u1 = a.u1; g.uv.v0 = a.v0; g.uv.v1 = a.v1;
+            g.uv.ustep = a.pixW > 1 ? (a.u1 - a.u0) / (float)(a.pixW - 1) : 0.f;
+            g.uv.vstep = a.pixH > 1 ? (a.v1 - a.v0) / (float)(a.pixH - 1) : 0.f;
+        }
+        break;
+    case MOGE_TG_RESID:
+        g.epi = EPI_RESID; g.xres = a.xres; g.ldc = N; g.gamma = a.gamma;
+        if (a.x16_out) {
+            if (!std::is_same<T, f16>::value || !a.ln_part_out) return MOGE_ERR_INVALID;
+            TCHK(x16.alloc(mn * sizeof(f16)));
+            g.x16 = x16.p; g.ln_part = a.ln_part_out;
+        }
+        break;
+    case MOGE_TG_QKV: {
+        const int D = a.nh * 64;
+        if (N != 3 * D || M % a.Ntok) return MOGE_ERR_INVALID;
+        const size_t n = (size_t)M * D;
+        TCHK(qb.alloc(n * sizeof(T))); TCHK(kb.alloc(n * sizeof(T))); TCHK(vb.alloc(n * sizeof(T)));
+        g.epi = EPI_QKV; g.q = qb.p; g.k = kb.p; g.vT = vb.p; g.v_rowmajor = 1;
+        g.nh = a.nh; g.D = D; g.Ntok = a.Ntok; g.Npad = (a.Ntok + 63) / 64 * 64; g.qscale = a.qscale;
+        break;
+    }
+    case MOGE_TG_CONVT:
+        TCHK(ob.alloc(mn * sizeof(T)));
+        g.epi = EPI_CONVT; g.out = ob.p; g.Cout = a.Cout;
+        break;
+    default: return MOGE_ERR_INVALID;
+    }
+    TL(launch_gemm<T>(g, AMODE_LINEAR, st));
+    if (a.kind == MOGE_TG_STORE || a.kind == MOGE_TG_CONVT) TL(from_t<T>(ob.p, a.out, (long)mn, st));
+    if (a.kind == MOGE_TG_RESID && a.x16_out) TL((launch_convert<f16, float>(x16.p, a.x16_out, (long)mn, st)));
+    if (a.kind == MOGE_TG_QKV) {
+        const long n = (long)M * a.nh * 64;
+        TL(from_t<T>(qb.p, a.q_out, n, st)); TL(from_t<T>(kb.p, a.k_out, n, st)); TL(from_t<T>(vb.p, a.v_out, n, st));
+    }
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+template <typename T>
 static int t_attention(const float* q, const float* k, const float* v, float* o, int B, int nh, int N, hipStream_t st) {
     const int Npad = (N + 63) / 64 * 64;
     const size_t n = (size_t)B * nh * N * 64;
@@ -125,6 +182,12 @@ int moge_test_gemm(int precision, const float* A, const float* W, const float* b
     return precision == MOGE_FP16 ? t_gemm<f16>(A, W, bias, C, M, N, K, act, st) : t_gemm<float>(A, W, bias, C, M, N, K, act, st);
 }
 
+int moge_test_gemm_ex(const moge_test_gemm_args* args, void* stream) {
+    if (!args) return MOGE_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    return args->precision == MOGE_FP16 ? t_gemm_ex<f16>(*args, st) : t_gemm_ex<float>(*args, st);
+}
+
 int moge_test_layernorm(int precision, const float* x, const float* w, const float* b, float* y, int rows, int D, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (precision == MOGE_FP16) {
@@ -159,7 +222,7 @@ int moge_test_convt2x2(int precision, const float* x, const float* w, const floa
 int moge_test_preprocess(const float* image, float* out, int B, int H, int W, int rows, int cols, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
-    TL((launch_preprocess<float, float>(image, out, B, H, W, rows, cols, 0, 1, mean, sd, st)));
+    TL((launch_preprocess<float, float>(image, out, B, H, W, rows, cols, 0, 1, 0, mean, sd, st)));
     TCHK(hipStreamSynchronize(st));
     return 0;
 }

@@ -341,9 +341,14 @@ class MoGeModel:
         image = image.to(device=self._device)
         if image.dtype not in (torch.float16, torch.float32):
             image = image.float()
-        if self._dtype == torch.float16 and image.dtype != torch.float16:
-            image = image.half()                      # the reference casts the image to the model dtype (v2.py:229)
+        # a .half() model casts the image to fp16 (v2.py:229): an fp32 image is handed over as it is with img_dtype 3 and rounded
+        # to fp16 inside preprocess_kernel - bit-identical to `image.half()`, without a torch op on the hot path
         return image.contiguous()
+
+    def _img_dtype(self, image: torch.Tensor) -> int:
+        if image.dtype == torch.float16:
+            return 1
+        return 3 if self._dtype == torch.float16 else 0
 
     def _precision(self, use_fp16: bool) -> int:
         return L.FP16 if (self._dtype == torch.float16 or use_fp16) else L.FP32
@@ -369,7 +374,7 @@ class MoGeModel:
                 res["mask"] = torch.empty((B, H, W), dtype=torch.float32, device=dev); o.mask_prob = res["mask"].data_ptr()
             if self._bits & L.HEAD_SCALE:
                 res["metric_scale"] = torch.empty((B,), dtype=torch.float32, device=dev); o.metric_scale = res["metric_scale"].data_ptr()
-            L.check(L.lib.moge_forward(self._handle, image.data_ptr(), 1 if image.dtype == torch.float16 else 0, B, H, W, rows, cols,
+            L.check(L.lib.moge_forward(self._handle, image.data_ptr(), self._img_dtype(image), B, H, W, rows, cols,
                                        C.byref(o), L.stream_ptr(dev)))
         if self._dtype == torch.float16:
             res = {k: v.half() for k, v in res.items()}
@@ -391,7 +396,7 @@ class MoGeModel:
             image = image.unsqueeze(0)
         image = self._prep_image(image)
         B, _, H, W = image.shape
-        return self._infer_device(image, 1 if image.dtype == torch.float16 else 0, B, H, W, omit_batch_dim, num_tokens, resolution_level,
+        return self._infer_device(image, self._img_dtype(image), B, H, W, omit_batch_dim, num_tokens, resolution_level,
                                   force_projection, apply_mask, fov_x, use_fp16)
 
     @torch.inference_mode()

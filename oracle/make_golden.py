@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from . import moge_oracle as O
+from . import metrics as MX
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 REFERENCE_ROOT = "/root/reference"
@@ -83,6 +84,8 @@ def make_input(case: dict) -> torch.Tensor:
     g = torch.Generator().manual_seed(case["input_seed"])
     shape = case["shape"]
     x = torch.rand(shape, generator=g)
+    if case.get("input") == "rand":                 # exactly what bench.py / SURVEY 8(d) feed: torch.rand(..., generator=manual_seed(s))
+        return x.contiguous()
     # add low-frequency structure: mix with a blurred copy
     xb = torch.nn.functional.avg_pool2d(x.reshape(-1, 3, *shape[-2:]), 5, 1, 2).reshape(shape)
     return (0.5 * x + 0.5 * xb).clamp(0, 1).contiguous()
@@ -103,7 +106,20 @@ CASES = [
          kwargs=dict(use_fp16=False, resolution_level=0)),
     dict(name="vits_house518", config="moge-2-vits-normal", seed=0, sane=True, input="house518", shape=[3, 518, 518],
          kwargs=dict(use_fp16=False), stride=7),
+    # BASELINE.json configs[1..4] at their own sizes: the image is torch.rand(seed) exactly as the bench draws it; default
+    # resolution_level 9 -> num_tokens 3600 (v2.py:236-238); fixtures keep every 7th pixel.  B = 1: at B > 1 the CPU reference's own fp32 result depends on how ATen splits the batch
+    # over threads (1e-5), which flips mask pixels that sit on the 0.5 threshold - the oracle could not be bit-compared with it.
+    dict(name="vitb_normal_518_t3600", config="moge-2-vitb-normal", seed=0, sane=True, input="rand", input_seed=0, shape=[1, 3, 518, 518],
+         kwargs=dict(use_fp16=False), stride=7),
+    dict(name="vitl_518_t3600", config="moge-2-vitl", seed=0, sane=True, input="rand", input_seed=0, shape=[1, 3, 518, 518],
+         kwargs=dict(use_fp16=False), stride=7),
+    dict(name="vitl_normal_518x1036", config="moge-2-vitl-normal", seed=0, sane=True, input="rand", input_seed=0, shape=[1, 3, 518, 1036],
+         kwargs=dict(use_fp16=False), stride=7),
+    dict(name="vitl_normal_1036x518", config="moge-2-vitl-normal", seed=0, sane=True, input="rand", input_seed=1, shape=[1, 3, 1036, 518],
+         kwargs=dict(use_fp16=False), stride=7),
 ]
+# the cases whose reference run takes more than a few seconds on 8 cores (the CPU suite replays the oracle on the fast ones only)
+SLOW_CASES = ("vits_house518", "vitb_normal_518_t3600", "vitl_518_t3600", "vitl_normal_518x1036", "vitl_normal_1036x518")
 
 
 def run_reference(case: dict):
@@ -123,7 +139,13 @@ def run_reference(case: dict):
     x = make_input(case)
     out = model.infer(x, **case["kwargs"])
     fwd = model.forward(x if x.dim() == 4 else x[None], num_tokens=_tokens(cfg, case))
-    return cfg, sd, x, out, fwd
+    # The reference's OWN fp16 path on the same input: fp32 weights + use_fp16=True = torch.autocast(float16) (v2.py:241; what
+    # scripts/infer.py --fp16 / baselines/moge.py run when the model is not .half()).  It runs on CPU unmodified.  The other form,
+    # model.half() (scripts/infer.py:84), does not: ATen has no Half kernel for the antialiased resize on CPU
+    # ("compute_index_ranges_weights" not implemented for 'Half', modules.py:121), so it cannot be a fixture source here.
+    kw16 = dict(case["kwargs"]); kw16["use_fp16"] = True
+    out16 = model.infer(x, **kw16)
+    return cfg, sd, x, out, fwd, out16
 
 
 def _tokens(cfg, case):
@@ -137,7 +159,8 @@ def _tokens(cfg, case):
 def maxdiff(a: torch.Tensor, b: torch.Tensor) -> float:
     a, b = a.double(), b.double()
     fin = torch.isfinite(a) & torch.isfinite(b)
-    assert bool((torch.isfinite(a) == torch.isfinite(b)).all())
+    if not bool((torch.isfinite(a) == torch.isfinite(b)).all()):
+        print(f"  !! non-finite pattern differs on {int((torch.isfinite(a) != torch.isfinite(b)).sum())} entries", flush=True)
     return float((a[fin] - b[fin]).abs().max()) if fin.any() else 0.0
 
 
@@ -158,7 +181,7 @@ def main():
     for case in CASES:
         if args.only and case["name"] != args.only:
             continue
-        cfg, sd, x, ref, ref_fwd = run_reference(case)
+        cfg, sd, x, ref, ref_fwd, ref16 = run_reference(case)
         kw = {k: v for k, v in case["kwargs"].items() if k != "use_fp16"}
         tr = {}
         ora = O.infer(cfg, sd, x, trace=tr, **kw)
@@ -173,6 +196,9 @@ def main():
         for k in ref_fwd:
             line.append(f"fwd.{k}:{maxdiff(ref_fwd[k], tr['forward'][k]):.2e}")
         line.append(f"focal={tr['focal'].tolist()} shift={tr['shift'].tolist()}")
+        # drift of the reference's own fp16 (autocast) path against its fp32 path, in the per-pixel metric the parity tests use
+        drift16 = {k: (dict(flips=MX.mask_flips(ref16[k], ref[k])) if ref[k].dtype == torch.bool else MX.summarize(k, ref16[k], ref[k])) for k in ref}
+        line.append("ref-fp16 drift: " + " ".join(f"{k}:{(v.get('p999', v.get('flips'))):.2e}" for k, v in drift16.items()))
         print("  ".join(line), flush=True)
         if args.check_only:
             continue
@@ -183,6 +209,11 @@ def main():
             if k != "intrinsics" and st > 1:
                 a = a[..., ::st, ::st, :] if (a.ndim >= 3 and a.shape[-1] == 3 and k in ("points", "normal")) else a[..., ::st, ::st]
             blob["infer." + k] = a
+        for k, v in ref16.items():          # the reference's fp16 (autocast) outputs, fp16 storage is enough for them
+            a = v.numpy()
+            if k != "intrinsics" and st > 1:
+                a = a[..., ::st, ::st, :] if (a.ndim >= 3 and a.shape[-1] == 3 and k in ("points", "normal")) else a[..., ::st, ::st]
+            blob["infer16." + k] = a
         for k, v in ref_fwd.items():
             a = v.detach().numpy()
             if st > 1 and k != "metric_scale":
@@ -191,7 +222,8 @@ def main():
         meta = dict(case=case, weights_sha256=weights_digest(sd), torch=torch.__version__, scipy=scipy.__version__,
                     numpy=np.__version__, threads=torch.get_num_threads(),
                     input_sha256=hashlib.sha256(x.numpy().tobytes()).hexdigest(),
-                    focal=tr["focal"].tolist(), shift=tr["shift"].tolist())
+                    focal=tr["focal"].tolist(), shift=tr["shift"].tolist(), drift16=drift16,
+                    drift16_source="reference infer(use_fp16=True): fp32 weights under torch.autocast(cpu, float16), vs its own use_fp16=False output, full resolution")
         blob["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
         np.savez_compressed(os.path.join(GOLDEN_DIR, case["name"] + ".npz"), **blob)
 

@@ -26,6 +26,55 @@ def gemm(prec, A, W, bias=None, act=0):
     return C
 
 
+TG_STORE, TG_RESID, TG_QKV, TG_CONVT = 0, 1, 2, 3
+
+
+def gemm_ex(kind, A, W, bias, prec=1, act=0, ln_mr=None, ln_c=None, uv=None, pix=None, Cout=0, xres=None, gamma=None, want_x16=False,
+            nh=0, Ntok=0, qscale=1.0):
+    """One GEMM through a fused epilogue (moge_test_gemm_ex).  All tensors fp32 on the GPU.  Returns a dict of outputs."""
+    import ctypes as C
+    A, W = _f(A), _f(W)
+    M, K = A.shape
+    N = W.shape[0]
+    a = L.TestGemmArgs()
+    keep = [A, W]
+
+    def dev(t):
+        if t is None:
+            return None
+        t = _f(t)
+        keep.append(t)
+        return t.data_ptr()
+
+    a.precision, a.kind, a.act, a.M, a.N, a.K = prec, kind, act, M, N, K
+    a.A, a.W, a.bias = A.data_ptr(), W.data_ptr(), dev(bias)
+    a.ln_mr, a.ln_c = dev(ln_mr), dev(ln_c)
+    if pix is not None:
+        a.pixW, a.pixH = pix
+    if uv is not None:
+        wu, wv, u0, u1, v0, v1 = uv
+        a.wu, a.wv, a.u0, a.u1, a.v0, a.v1 = dev(wu), dev(wv), u0, u1, v0, v1
+    out = {}
+    if kind in (TG_STORE, TG_CONVT):
+        out["out"] = torch.empty((M, N), device="cuda", dtype=torch.float32)
+        a.out, a.Cout = out["out"].data_ptr(), Cout
+    elif kind == TG_RESID:
+        out["xres"] = _f(xres).clone()
+        a.xres, a.gamma = out["xres"].data_ptr(), dev(gamma)
+        if want_x16:
+            out["x16"] = torch.empty((M, N), device="cuda", dtype=torch.float32)
+            out["ln_part"] = torch.empty((M, N // 32, 2), device="cuda", dtype=torch.float32)
+            a.x16_out, a.ln_part_out = out["x16"].data_ptr(), out["ln_part"].data_ptr()
+    elif kind == TG_QKV:
+        B = M // Ntok
+        for k in ("q", "k", "v"):
+            out[k] = torch.empty((B, nh, Ntok, 64), device="cuda", dtype=torch.float32)
+        a.q_out, a.k_out, a.v_out = out["q"].data_ptr(), out["k"].data_ptr(), out["v"].data_ptr()
+        a.nh, a.Ntok, a.qscale = nh, Ntok, qscale
+    L.check(L.lib.moge_test_gemm_ex(C.byref(a), st()))
+    return out
+
+
 def layernorm(prec, x, w, b):
     x, w, b = _f(x), _f(w), _f(b)
     y = torch.empty_like(x)

@@ -1,21 +1,21 @@
-"""GPU: the parity tests proper.  The HIP path (through the Python mirror -> C ABI) against the CPU oracle on the same
-seeded inputs, against the committed golden fixtures of the REAL reference, and - at the BASELINE sizes - through
-size-independent properties.
+"""GPU: the parity tests proper.  The HIP path (through the Python mirror -> C ABI) against the committed golden fixtures of the REAL
+reference (tests/golden/*.npz, written by oracle/make_golden.py from /root/reference), against the CPU oracle on the same seeded inputs,
+and - at the BASELINE sizes - through size-independent properties.
 
-Tolerances (north_star): FP32 mode: points / depth / normal / intrinsics within 1e-3 relative, validity mask bit-exact.
-FP16 mode is judged against the fp32 oracle with the band the reference's own fp16 path shows vs its fp32 path
-(~1.5e-3 abs on O(1) values for ViT-S) - 3e-2 relative here, mask mismatches <= 0.5 %."""
+Gates (north_star; tests/golden_util.py, metric = oracle/metrics.py: per pixel, relative to that pixel's own norm):
+  FP32 mode  points / depth / normal / intrinsics: EVERY pixel within 1e-3; validity mask bit-exact; same +inf pattern.
+  FP16 mode  judged against the reference's fp32 output with the band the reference's OWN fp16 path (infer(use_fp16=True), run on the
+             same case when the fixture was made) shows against its fp32 path: p99.9 of the per-pixel error <= 2 x the reference's,
+             mask flips <= 2 x the reference's.  Every fixture carries those numbers (meta.drift16)."""
 import os
 
 import numpy as np
 import pytest
 import torch
 
-from tests.golden_util import CASE_BY_NAME, load_case, rel_err, subsample
+from tests.golden_util import CASE_BY_NAME, FP32_TOL, SLOW_CASES, check_fp16, check_fp32, fp16_band, load_case, rel_err, subsample
 
 pytestmark = pytest.mark.gpu
-
-FP32_TOL = 1e-3
 
 
 @pytest.fixture(scope="module")
@@ -33,6 +33,8 @@ def get_model(MoGeModel, cfg_name, seed, sane, tmp_path_factory):
     from oracle import moge_oracle as O
     key = (cfg_name, seed, sane)
     if key not in _models:
+        if len(_models) >= 3:                      # vitl / vitb models hold ~2 GB of device memory each: keep a few, not all
+            _models.pop(next(iter(_models)))
         cfg = O.named_configs()[cfg_name]
         sd = O.synth_state_dict(cfg, seed, sane)
         path = os.path.join(str(tmp_path_factory.mktemp("ckpt")), "model.pt")
@@ -41,25 +43,17 @@ def get_model(MoGeModel, cfg_name, seed, sane, tmp_path_factory):
     return _models[key]
 
 
-def compare(out, ref, tol, mask_frac=0.0, ill=False):
-    assert set(out.keys()) == set(ref.keys())
-    for k in ref:
-        a = out[k].cpu().numpy() if torch.is_tensor(out[k]) else out[k]
-        b = ref[k].cpu().numpy() if torch.is_tensor(ref[k]) else ref[k]
-        if b.dtype == np.bool_:
-            bad = int((a != b).sum())
-            assert bad <= mask_frac * b.size, f"mask: {bad}/{b.size} pixels differ"
-        elif mask_frac > 0 or ill:
-            fin = np.isfinite(a) & np.isfinite(b)       # fp16 mode: a few mask flips move inf entries
-            assert fin.mean() > 0.99 * np.isfinite(b).mean()
-            e = np.abs(a[fin] - b[fin]) / np.maximum(np.abs(b[fin]), 1.0)
-            assert np.quantile(e, 0.999) <= tol, (k, float(np.quantile(e, 0.999)))
-        else:
-            assert rel_err(a, b) <= tol, (k, rel_err(a, b))
+def golden_infer(gold, prefix="infer."):
+    return {k[len(prefix):]: v for k, v in gold.items() if k.startswith(prefix)}
+
+
+def sub(out, st):
+    return {k: subsample(k, v.cpu().numpy(), st) for k, v in out.items()}
 
 
 @pytest.mark.parametrize("name", [n for n in CASE_BY_NAME])
 def test_fp32_mode_matches_reference_golden_and_oracle(MoGeModel, name, tmp_path_factory):
+    """Every fixture, incl. the BASELINE-size ones (moge-2-vitl 518x518 T=3600, moge-2-vitb-normal, the 518x1036 / 1036x518 grids 42x85 / 85x42)."""
     from oracle import moge_oracle as O
     case, cfg, sd, x, gold, meta = load_case(name)
     model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory)
@@ -68,42 +62,89 @@ def test_fp32_mode_matches_reference_golden_and_oracle(MoGeModel, name, tmp_path
     ill = not case["sane"]
     st = case.get("stride", 1)
     # (1) committed golden vectors of the real reference
-    g = {k[6:]: v for k, v in gold.items() if k.startswith("infer.")}
-    o = {k: subsample(k, v.cpu().numpy(), st) for k, v in out.items()}
-    compare(o, g, 5e-2 if ill else FP32_TOL, ill=ill)
-    # (2) the oracle, live, full resolution
-    if name != "vits_house518":
+    seen = check_fp32(sub(out, st), golden_infer(gold), ill=ill)
+    print(f"[parity fp32] {name}: " + " ".join(f"{k}={v:.1e}" for k, v in seen.items()))
+    # (2) the oracle, live, full resolution (bit-identical to the reference on these cases; the big ones take the GPU box's CPU too long)
+    if name not in SLOW_CASES:
         ref = O.infer(cfg, sd, x, **{k: v for k, v in kw.items() if k != "use_fp16"})
-        compare(out, ref, 5e-2 if ill else FP32_TOL, ill=ill)
+        check_fp32(out, ref, ill=ill)
 
 
-@pytest.mark.parametrize("name", ["tiny_b2_up", "tiny_b1_down_3d", "tiny_fov_nomask_noproj"])
+SANE = [n for n, c in CASE_BY_NAME.items() if c["sane"]]
+BIG = [n for n in SANE if n in SLOW_CASES and n != "vits_house518"]
+
+
+@pytest.mark.parametrize("name", SANE)
 def test_fp16_mode_within_reference_fp16_band(MoGeModel, name, tmp_path_factory):
+    """fp16 mode, both forms the reference has (.half() weights; fp32 weights + use_fp16=True), against the reference's fp32 golden inside
+    2x the reference's own fp16 drift on that case."""
     case, cfg, sd, x, gold, meta = load_case(name)
     model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory)
     kw = dict(case["kwargs"]); kw["use_fp16"] = True
-    out = model.float().infer(x, **kw)             # fp32 weights + use_fp16 (autocast analogue)
-    out_h = model.half().infer(x, **kw)            # .half() weights
-    model.float()
-    g = {k[6:]: v for k, v in gold.items() if k.startswith("infer.")}
-    for o in (out, out_h):
-        compare({k: v.cpu().numpy() for k, v in o.items()}, g, 3e-2, mask_frac=5e-3)
+    st = case.get("stride", 1)
+    band = fp16_band(meta)
+    g = golden_infer(gold)
+    try:
+        out = model.float().infer(x, **kw)             # fp32 weights + use_fp16 (autocast analogue)
+        out_h = model.half().infer(x, **kw)            # .half() weights
+    finally:
+        model.float()
+    for tag, o in (("autocast", out), ("half", out_h)):
+        seen = check_fp16(sub(o, st), g, band)
+        print(f"[parity fp16 {tag}] {name}: " + " ".join(f"{k}={v:.1e}/{band.get(k, 0):.1e}" for k, v in seen.items()))
+    # the reference's own fp16 outputs are inside the same band by construction; ours must not be further from them than 2 bands
+    g16 = golden_infer(gold, "infer16.")
+    check_fp16(sub(out_h, st), g16, {k: 2 * v for k, v in band.items()})
 
 
-def test_fp16_mode_vits_real_image_vs_reference_golden(MoGeModel, tmp_path_factory):
-    """ViT-S decoder dims (256/128/64/32) on the 518x518 example image: the only golden case whose shapes reach every fp16
-    throughput kernel (gemm_pp 128/256-wide tiles, attention_pp, conv_pp 64/128-wide with 1..4 Cin chunks, pixel-shuffle
-    resampler).  Judged against the REAL reference's fp32 output with the fp16 band."""
-    case, cfg, sd, x, gold, meta = load_case("vits_house518")
+@pytest.mark.parametrize("name", BIG)
+def test_fp16_throughput_kernels_in_the_model_match_reference_golden(MoGeModel, name, tmp_path_factory):
+    """The BASELINE-size fixtures are single images, which the production dispatch sends to the latency-regime GEMM kernels.  Here the SAME
+    forward is pushed through the throughput kernels the batch-32 bench runs - gemm_pp128m16_kernel (PP_MIN_TILES = 0) for qkv / proj / fc1 /
+    fc2 / out-proj / conv-transpose GEMMs, then again with the image replicated to a batch that reaches them under the production dispatch - and
+    must (a) stay inside the reference-fp16 band of the fixture and (b) reproduce the single-image result bit for bit."""
+    from moge_amd import _lib as L
+    case, cfg, sd, x, gold, meta = load_case(name)
     model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory)
     kw = dict(case["kwargs"]); kw["use_fp16"] = True
     st = case.get("stride", 1)
-    g = {k[6:]: v for k, v in gold.items() if k.startswith("infer.")}
+    band, g = fp16_band(meta), golden_infer(gold)
     try:
-        out_h = model.half().infer(x, **kw)
+        model.half()
+        base = model.infer(x, **kw)
+        L.tune("PP_MIN_TILES", 0)
+        forced = model.infer(x, **kw)
+        L.tune("PP_MIN_TILES", 128)
+        xb = x.expand(9, *x.shape[1:]).contiguous()        # 9 x 3601 rows = 127 row tiles x >= 3 column tiles: ping-pong regime, two half-batch streams
+        batch = model.infer(xb, **kw)
+    finally:
+        L.tune("PP_MIN_TILES", 128)
+        model.float()
+    check_fp16(sub(forced, st), g, band)
+    for k in base:
+        for other, what in ((forced[k], "forced ping-pong"), (batch[k][:1], "batch 9, item 0"), (batch[k][8:], "batch 9, item 8")):
+            a, b = other, base[k]
+            if a.dtype == torch.bool:
+                assert torch.equal(a, b), (k, what)
+            else:
+                fin = torch.isfinite(b)
+                assert torch.equal(fin, torch.isfinite(a)) and torch.equal(a[fin], b[fin]), f"{k}: {what} differs from the single-image result"
+
+
+def test_fp32_image_into_half_model_equals_prehalved_image(MoGeModel, tmp_path_factory):
+    """v2.py:229 `image.to(dtype=self.dtype)`: an fp32 image given to a .half() model is rounded to fp16 inside preprocess_kernel (img_dtype 3);
+    the result must equal feeding the explicitly pre-rounded fp16 tensor (img_dtype 1) bit for bit."""
+    model, cfg, sd = get_model(MoGeModel, "tiny-vits-normal", 0, True, tmp_path_factory)
+    x = torch.rand(2, 3, 84, 112, generator=torch.Generator().manual_seed(21))
+    try:
+        model.half()
+        a = model.infer(x, num_tokens=108)
+        b = model.infer(x.half(), num_tokens=108)
     finally:
         model.float()
-    compare({k: subsample(k, v.cpu().numpy(), st) for k, v in out_h.items()}, g, 3e-2, mask_frac=5e-3)
+    for k in a:
+        fin = torch.isfinite(b[k]) if b[k].dtype != torch.bool else torch.ones_like(b[k])
+        assert torch.equal(a[k][fin], b[k][fin]), k
 
 
 def test_stage_taps_match_oracle(MoGeModel, tmp_path_factory):
@@ -263,14 +304,14 @@ def test_odd_shapes_and_token_grids_match_the_oracle_fp32(MoGeModel, tmp_path_fa
     out = model.infer(x, num_tokens=tokens, use_fp16=False)
     ref = O.infer(cfg, sd, x, num_tokens=tokens)
     assert out["mask"].shape == (2, H, W) and out["points"].shape == (2, H, W, 3)
-    compare(out, ref, FP32_TOL)
+    check_fp32(out, ref)
 
 
 @pytest.mark.parametrize("kind", ["black", "white", "flat_gray"])
 def test_fp16_mode_on_constant_images_stays_in_band(MoGeModel, tmp_path_factory, kind):
     """Degenerate inputs for the folded LayerNorm (fp16 path: row statistics from partial sums, raw residual in fp16): a constant image gives
-    every patch the same embedding, so the token rows differ by the position embedding only.  Outputs must stay finite and within the fp16 band
-    of the fp32 oracle, like any other image."""
+    every patch the same embedding, so the token rows differ by the position embedding only.  Outputs must stay finite and within (twice) the fp16 band
+    the reference shows on an ordinary image with the same model."""
     from oracle import moge_oracle as O
     model, cfg, sd = get_model(MoGeModel, "tiny-vits-normal", 0, True, tmp_path_factory)
     val = {"black": 0.0, "white": 1.0, "flat_gray": 0.5}[kind]
@@ -284,4 +325,5 @@ def test_fp16_mode_on_constant_images_stays_in_band(MoGeModel, tmp_path_factory,
     for k in ("points", "depth", "intrinsics"):
         a = out[k].float().cpu().numpy()
         assert np.isfinite(a).all(), k
-    compare({k: out[k] for k in ref}, ref, 3e-2, mask_frac=0.02)
+    band = fp16_band(load_case("tiny_b2_up")[5])            # same model: the reference's fp16 drift measured on an ordinary image
+    check_fp16({k: out[k] for k in ref}, ref, {k: 2 * v for k, v in band.items()})

@@ -6,12 +6,15 @@ import torch
 
 from oracle import moge_oracle as O
 from oracle.make_golden import weights_digest
+from oracle import metrics as MX
 from tests.golden_util import CASE_BY_NAME, load_case, rel_err, subsample
 
-FAST = [n for n in CASE_BY_NAME if n != "vits_house518"]
+# the two 518x1036 / 1036x518 vitl-normal cases take ~25 s each on 8 cores: they are replayed by `python -m oracle.make_golden --check-only`
+# (oracle == reference bit for bit there) and kept out of the default CPU suite
+CPU_CASES = [n for n in CASE_BY_NAME if n not in ("vitl_normal_518x1036", "vitl_normal_1036x518")]
 
 
-@pytest.mark.parametrize("name", FAST + ["vits_house518"])
+@pytest.mark.parametrize("name", CPU_CASES)
 def test_oracle_matches_reference_golden(name):
     torch.manual_seed(0)
     case, cfg, sd, x, gold, meta = load_case(name)
@@ -29,8 +32,12 @@ def test_oracle_matches_reference_golden(name):
             assert (a == g).all(), f"{k}: {int((a != g).sum())} mask pixels differ"
         else:
             # fp32 CPU kernels are not bit-reproducible across thread splits (1e-5 seen); the ill-posed case amplifies
-            tol = 2e-2 if ill else 1e-4
-            assert rel_err(a, g) <= tol, (k, rel_err(a, g))
+            e, nmis, _ = MX.pixel_errors(k, a, g)
+            assert nmis == 0, (k, nmis)
+            if ill:
+                assert float(np.quantile(e, 0.999)) <= 2e-2, (k, float(np.quantile(e, 0.999)))
+            else:
+                assert float(e.max()) <= 1e-4, (k, float(e.max()))
     for k, v in tr["forward"].items():
         g = gold["forward." + k]
         tol = 1e-3 if ill else 1e-4
@@ -54,3 +61,14 @@ def test_token_grid_matches_survey():
     assert O.token_grid(518, 518, 1369) == (37, 37)
     assert O.token_grid(518, 1036, 3600) == (42, 85)
     assert O.token_grid(1036, 518, 3600) == (85, 42)
+
+
+def test_fixtures_carry_reference_fp16_outputs_and_drift():
+    """Every fixture holds the reference's own fp16 (autocast) outputs and the drift statistics the fp16 gate is derived from."""
+    for name in CASE_BY_NAME:
+        case, cfg, sd, x, gold, meta = load_case(name)
+        assert {k[8:] for k in gold if k.startswith("infer16.")} == {k[6:] for k in gold if k.startswith("infer.")}, name
+        d = meta["drift16"]
+        assert set(d) == {k[6:] for k in gold if k.startswith("infer.")}
+        if case["sane"]:
+            assert 1e-4 < d["points"]["p999"] < 1e-2 and d["mask"]["flips"] < 2e-3, (name, d)

@@ -149,18 +149,17 @@ static int bench_gemm(const char* filter, int iters) {
         {"b4.proj", 4 * Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"b4.fc2", 4 * Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
     };
-    struct Variant { const char* name; int pp, glds, dbg, row128, stagger; int a3 = 1; int w4 = 0; };
-    std::vector<Variant> variants = {{"glds2-m16", 0, 2, 0, 0}, {"pp64", 1, 2, 0, 0}, {"pp128-a3", 1, 2, 0, 1}, {"pp128-m16", 1, 2, 0, 1, 0, 1, 3}};
-    if (getenv("KB_A3")) variants = {{"pp128-2buf", 1, 2, 0, 1, 0, 0}, {"pp128-a3", 1, 2, 0, 1, 0, 1}, {"pp128-a3c", 1, 2, 0, 1, 0, 2}};
-    if (getenv("KB_4W")) variants = {{"pp128-a3", 1, 2, 0, 1, 0, 1, 0}, {"pp4w", 1, 2, 0, 1, 0, 1, 1}, {"pp4w-16", 1, 2, 0, 1, 0, 1, 2}, {"pp128-m16", 1, 2, 0, 1, 0, 1, 3}};
-    if (getenv("KB_NARROW")) variants = {{"pp128", 1, 2, 0, 1, 0}, {"pp64-2wg", 1, 2, 0, 1, 100}};
-    if (getenv("KB_STAGGER")) variants = {{"pp128", 1, 2, 0, 1, 0}, {"pp128-stg2", 1, 2, 0, 1, 2}, {"pp128-stg4", 1, 2, 0, 1, 4}, {"pp128-stg8", 1, 2, 0, 1, 8}};
-    if (getenv("KB_ABLATE")) {
-        variants = {{"pp128", 1, 2, 0, 1}, {"pp128-noact", 1, 2, 16, 1}, {"pp128-noepi", 1, 2, 32, 1}, {"pp128-nodma", 1, 2, 1, 1}, {"pp128-nolds", 1, 2, 2, 1}, {"pp128-nomfma", 1, 2, 4, 1},
-                    {"pp128-nobar", 1, 2, 8, 1}, {"pp128-mfmaonly", 1, 2, 11, 1}, {"pp128-A0", 1, 2, 64, 1}, {"pp128-W0", 1, 2, 128, 1}, {"pp128-A0W0", 1, 2, 192, 1}};
-        if (getenv("KB_ABLATE")[0] == '2') variants = {{"pp128", 1, 2, 0, 1}, {"pp128-A0", 1, 2, 64, 1}, {"pp128-W0", 1, 2, 128, 1}, {"pp128-A0W0", 1, 2, 192, 1}, {"pp128-nodma", 1, 2, 1, 1}};
-        if (getenv("KB_ABLATE")[0] == '3') variants = {{"pp128-2buf", 1, 2, 0, 1, 0, 0}, {"pp128-2buf-A0W0", 1, 2, 192, 1, 0, 0}, {"pp128-2buf-nodma", 1, 2, 1, 1, 0, 0}, {"pp128-2buf-mfmaonly", 1, 2, 11, 1, 0, 0}, {"pp128-a3", 1, 2, 0, 1, 0, 1}};
-    }
+    // kern: PP_KERN (0 = gemm_pp128m16_kernel, 1 = gemm_pp4w16_kernel);  exp: PP_EXP (library built with --experiments only: 1/2/3 = gemm_pp128
+    // 32x32x16 form with A3 = 1/2/0, 4 = gemm_pp4w 32x32x16, 5 = 64-byte-row 256x256, 6 = 64-byte-row 256x128 two workgroups per CU)
+    struct Variant { const char* name; int pp, glds, dbg, kern, exp; };
+    auto apply = [](const Variant& v) {
+        moge_tune_set("GEMM_PP", v.pp); moge_tune_set("PP_MIN_TILES", 0); moge_tune_set("GLDS_VARIANT", v.glds); moge_tune_set("PP_DBG", v.dbg);
+        moge_tune_set("PP_KERN", v.kern); moge_tune_set("PP_EXP", v.exp);
+    };
+    std::vector<Variant> variants = {{"glds2-m16", 0, 2, 0, 0, 0}, {"pp128-m16", 1, 2, 0, 0, 0}, {"pp4w-16", 1, 2, 0, 1, 0}};
+    if (getenv("KB_EXP")) variants = {{"pp128-m16", 1, 2, 0, 0, 0}, {"pp4w-16", 1, 2, 0, 1, 0}, {"x:pp128-a3", 1, 2, 0, 0, 1}, {"x:pp128-a3c", 1, 2, 0, 0, 2}, {"x:pp128-2buf", 1, 2, 0, 0, 3},
+                                      {"x:pp4w-32", 1, 2, 0, 0, 4}, {"x:pp64", 1, 2, 0, 0, 5}, {"x:pp64-2wg", 1, 2, 0, 0, 6}};
+    if (getenv("KB_PP")) variants = {{"pp128-m16", 1, 2, 0, 0, 0}, {"pp4w-16", 1, 2, 0, 1, 0}};
     int fails = 0;
     for (const Shape& s : shapes) {
         if (filter && !strstr(s.name, filter)) continue;
@@ -207,15 +206,7 @@ static int bench_gemm(const char* filter, int iters) {
         ref_gemm<<<dim3((unsigned)((N + 255) / 256), (unsigned)rows.size()), 256, 0, st>>>(A, (int)K, W, (int)K, bias, drows, (int)rows.size(), (int)N, (int)K, ref);
         CK(hipStreamSynchronize(st));
         for (const Variant& v : variants) {
-            moge_tune_set("GEMM_PP", v.pp);
-            moge_tune_set("GLDS_VARIANT", v.glds);
-            moge_tune_set("PP_DBG", v.dbg);
-            moge_tune_set("PP_ROW128", v.row128);
-            moge_tune_set("PP_STAGGER", v.stagger == 100 ? 0 : v.stagger);
-            moge_tune_set("PP_NARROW", v.stagger == 100 ? 1 : 0);
-            moge_tune_set("PP_A3", v.a3);
-            moge_tune_set("PP_4W", v.w4);
-            moge_tune_set("PP_M16", v.w4 == 3 ? 1 : 0);
+            apply(v);
             // correctness: one launch on fresh buffers
             CK(hipMemsetAsync(out, 0, out_elems * 2, st));
             if (x) CK(hipMemcpyAsync(x, x0, M * N * 4, hipMemcpyDeviceToDevice, st));
@@ -227,7 +218,7 @@ static int bench_gemm(const char* filter, int iters) {
             float hmax; int hbad;
             CK(hipMemcpyAsync(&hmax, dmax, 4, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hbad, dbad, 4, hipMemcpyDeviceToHost, st));
             CK(hipStreamSynchronize(st));
-            if (getenv("KB_TS") && v.pp && v.row128) {
+            if (getenv("KB_TS") && v.pp && v.exp >= 1 && v.exp <= 3) {
                 unsigned long long* dts; CK(hipMalloc(&dts, 64 * 8)); CK(hipMemsetAsync(dts, 0, 64 * 8, st));
                 GemmArgs g2 = g; g2.dbg_ts = dts;
                 launch_gemm<f16>(g2, AMODE_LINEAR, st);
@@ -252,9 +243,7 @@ static int bench_gemm(const char* filter, int iters) {
             for (int r = 0; r < rounds; r++)
                 for (size_t vi = 0; vi < variants.size(); vi++) {
                     const Variant& v = variants[vi];
-                    moge_tune_set("GEMM_PP", v.pp); moge_tune_set("GLDS_VARIANT", v.glds); moge_tune_set("PP_DBG", v.dbg); moge_tune_set("PP_ROW128", v.row128);
-                    moge_tune_set("PP_STAGGER", v.stagger == 100 ? 0 : v.stagger); moge_tune_set("PP_NARROW", v.stagger == 100 ? 1 : 0);
-                    moge_tune_set("PP_A3", v.a3); moge_tune_set("PP_4W", v.w4); moge_tune_set("PP_M16", v.w4 == 3 ? 1 : 0);
+                    apply(v);
                     const double ms = time_launches(g, iters, st);
                     sum[vi] += ms; mn[vi] = ms < mn[vi] ? ms : mn[vi];
                 }
