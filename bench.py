@@ -6,19 +6,26 @@ A "step" is ONE infer() pass of the hot path over one batch of synthetic images 
 Workload (BASELINE.json metric: images/sec, moge-2-vitl 518x518 fp16): configs[2] = moge-2-vitl (no normal head),
 batch 32 per GPU, torch.rand 3x518x518, default num_tokens 3600 (60x60 token grid, N=3601), fp16 weights
 (model.half()), full infer() including focal/shift recovery and masking; outputs stay on the device.
-For N>1 the driver launches one process per GPU (torch.distributed / RCCL): rank 0 builds the synthetic checkpoint,
-the fp32 master weight blob is broadcast once over xGMI, then every rank runs independent inference on its own
-shard (weak scaling: per-GPU batch fixed; no steady-state collective - SURVEY.md 8(e)).
+For N>1 there is one process per GPU (torch.distributed / RCCL): rank 0 builds the synthetic checkpoint, the fp32 master
+weight blob is broadcast once over xGMI, then every rank runs independent inference on its own shard (weak scaling:
+per-GPU batch fixed; no steady-state collective - SURVEY.md 8(e)).  `python bench.py --gpus N` launches itself: when it is
+not already running under torch.distributed.run (WORLD_SIZE unset) it re-executes as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...`.
+The workload is the SAME at every N (moge-2-vitl, the config BASELINE.json's metric names, 32 images per GPU) so that the per-N values
+form one weak-scaling curve; `--config moge-2-vitl-normal` is BASELINE configs[3], `--shape mixed` configs[4].
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline        dominant kernel class (the MFMA GEMMs of the ViT linears): algorithmic FLOPs / HIP-event time on the launch stream over the
-                  same K steps run single-stream right after the timed region; `traffic` = fabric bytes per launch from the committed
-                  rocprofv3 PMC passes (moge_amd/pmc_traffic.json, default workload only)
+  roofline        the dominant kernel, gemm_pp128m16_kernel (every launch of it and nothing else: profiler class gemm_pp): algorithmic FLOPs /
+                  HIP-event time on the launch stream over the same K steps run single-stream right after the timed region; `traffic` =
+                  fabric bytes per launch from the committed rocprofv3 PMC passes (moge_amd/pmc_traffic.json, default workload only)
+  rccl            N>1: ranks RCCL saw (all-reduce of ones), bytes and seconds of the one-time weight broadcast
   kernel_classes  per-class ms/step, TFLOP/s, GB/s of that profiled pass;  whole_path: end-to-end MFMA fraction
   pcie_inclusive  images/s of the caller-side pipeline (host uint8 in, all maps back to pinned host memory) - N=1 only, never `value`
   load_seconds    from_pretrained(.pt) vs from_blob(packed master blob) to a ready model
-  cpu_baseline    the CPU oracle (oracle/moge_oracle.py, a restatement pinned to the reference) on ONE image of the
-                  same workload on this box's host cores (rank 0, N=1 only)
+  cpu_baseline    the reference itself (kind "reference": /root/reference imported unmodified, build container only) or, where it does not
+                  exist (the GPU box), the CPU oracle (kind "port": oracle/moge_oracle.py, bit-identical to the reference on the committed
+                  fixtures) on single images of the same workload on this box's host cores: thread count chosen by a short calibration,
+                  median of 3 after warm-up (rank 0, N=1 only)
 """
 import argparse
 import json
@@ -39,6 +46,75 @@ BATCH_PER_GPU = 32
 IMG = 518
 
 
+def self_launch_command(argv, gpus, port=None):
+    """The command `python bench.py --gpus N` turns into when it is not yet running under torch.distributed.run."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(O, cfg, sd, x1, kw, config_name, num_tokens):
+    """Reference CPU path beside the GPU number: the unmodified reference when it can be imported, else the oracle.
+    Thread count = the fastest of a short calibration (more threads than ~32 are SLOWER for this model in ATen); 1 warm-up (the
+    calibration) + median of 3."""
+    import statistics
+    kind, run = "port", None
+    if os.path.isdir("/root/reference/moge"):
+        try:
+            from oracle.make_golden import install_stubs
+            install_stubs()
+            from moge.model import import_model_class_by_version as ref_import
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "model.pt")
+                O.save_checkpoint(path, cfg, sd)
+                ref_model = ref_import("v2").from_pretrained(path).eval()
+            kind, run = "reference", (lambda x, **k: ref_model.infer(x, use_fp16=False, **k))
+        except Exception as e:            # noqa: BLE001 - fall back to the port, say why
+            print(f"[bench] reference not importable ({e}); cpu_baseline uses the oracle", file=sys.stderr)
+    if run is None:
+        run = lambda x, **k: O.infer(cfg, sd, x, **k)      # noqa: E731
+    ncpu = os.cpu_count() or 1
+    cands = sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu})
+    calib = {}
+    kcal = dict(kw); kcal["num_tokens"] = min(1369, num_tokens)
+    prev = torch.get_num_threads()
+    for t in cands:
+        torch.set_num_threads(t)
+        t1 = time.perf_counter()
+        run(x1, **kcal)
+        calib[t] = time.perf_counter() - t1
+    best = min(calib, key=calib.get)
+    torch.set_num_threads(best)
+    times = []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        run(x1, **kw)
+        times.append(time.perf_counter() - t1)
+    torch.set_num_threads(prev)
+    med = statistics.median(times)
+    what = "the unmodified reference MoGeModel.infer(use_fp16=False) (stubs for the un-installed cv2 / utils3d only)" if kind == "reference" \
+        else "oracle.infer (torch CPU fp32 + scalar lmdif; /root/reference does not exist on this box)"
+    return {"value": round(1.0 / med, 4), "unit": "images/s", "cores": best, "kind": kind, "host_cpus": ncpu, "cpu_model": cpu_model_name(),
+            "seconds_per_image": [round(t, 2) for t in times],
+            "sample": f"3 single images of the same workload ({config_name}, 518x518, num_tokens {num_tokens}, fp32) through {what}; median "
+                      f"{med:.1f} s; thread count {best} = fastest of a calibration at num_tokens {kcal['num_tokens']} over "
+                      + ", ".join(f"{t}: {calib[t]:.1f} s" for t in cands) + " (also the warm-up)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,14 +128,32 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pipeline leg and the blob load-time comparison")
     ap.add_argument("--no-profile", action="store_true", help="disable the per-kernel HIP-event profiler")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="run only the cpu_baseline leg (no GPU needed) and print it")
+    ap.add_argument("--print-launch", action="store_true", help="print the torch.distributed.run command --gpus N would re-execute as, and exit")
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        # no GPU needed: the CPU leg alone (in the build container this times the unmodified reference: kind "reference")
+        from oracle import moge_oracle as O
+        cfg = O.named_configs()[args.config]
+        sd = O.synth_state_dict(cfg, 0, True)
+        x1 = torch.rand(1, 3, IMG, IMG, generator=torch.Generator().manual_seed(1000))
+        nt = args.num_tokens or int(cfg["num_tokens_range"][1])
+        print(json.dumps({"cpu_baseline": cpu_baseline(O, cfg, sd, x1, {} if args.num_tokens is None else {"num_tokens": args.num_tokens}, args.config, nt)}))
+        return
+    if args.print_launch:
+        print(json.dumps(self_launch_command([a for a in sys.argv[1:] if a != "--print-launch"], args.gpus)))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher yet: become `python -m torch.distributed.run ... bench.py <same arguments>` (one rank per GPU over RCCL)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execvpe(sys.executable, self_launch_command(sys.argv[1:], args.gpus), env)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -84,8 +178,18 @@ def main():
     else:
         model = MoGeModel(**cfg)
     model.to(dev).eval()
+    rccl = None
     if world > 1:
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        tb = time.perf_counter()
         broadcast_weights(model, src=0)                  # one-time RCCL broadcast of the master blob
+        dist.barrier()
+        tb = time.perf_counter() - tb
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                            # how many ranks RCCL actually joined
+        rccl = {"rccl_ranks": int(ones.item()), "backend": dist.get_backend(), "weight_broadcast_bytes": int(model.master_blob().numel()),
+                "weight_broadcast_seconds": round(tb, 4)}
     model.half()
 
     B = args.batch
@@ -165,10 +269,13 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world} (independent shards, one-time RCCL weight broadcast)"},
             "p50_latency_ms_batch1": round(lat[len(lat) // 2], 3),
         }
+        if rccl is not None:
+            res["rccl"] = rccl
         if prof is not None:
-            gm = prof["gemm"]
+            gm = prof["gemm_pp"] if prof["gemm_pp"]["launches"] else prof["gemm"]
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
-            res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp128m16_kernel (ViT qkv/proj/fc1/fc2 + out-proj ping-pong MFMA GEMMs, v_mfma_f32_16x16x32_f16)",
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp128m16_kernel: all of its launches and only those (ViT qkv / proj / fc1 / fc2 + summed out-projection, "
+                                                              "v_mfma_f32_16x16x32_f16)" if prof["gemm_pp"]["launches"] else "gemm_glds_kernel / gemm_kernel (latency-regime GEMMs; no ping-pong launch in this workload)",
                                "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4),
                                "traffic": None, "avg_launch_ms": round(gm["ms"] / max(gm["launches"], 1), 4), "launches": gm["launches"],
                                "algorithmic_bytes_per_launch": round(gm["bytes"] / max(gm["launches"], 1))}
@@ -226,14 +333,7 @@ def main():
             res["load_seconds"] = {"checkpoint_pt": round(t_pt, 3), "master_blob": round(t_bl, 3),
                                    "note": "from_pretrained(.pt) vs from_blob(packed fp32 master blob) to a ready fp32 model on the device, page cache warm"}
         if world == 1 and not args.no_cpu_baseline:
-            # bounded sample: ONE image of the same workload through the CPU oracle (fp32), all host threads
-            xc = x[:1].float().cpu()
-            t1 = time.perf_counter()
-            O.infer(cfg, sd, xc, **kw)
-            dt = time.perf_counter() - t1
-            res["cpu_baseline"] = {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-                                   "sample": f"1 image of the same workload ({args.config}, 518x518, num_tokens {num_tokens}) through oracle.infer "
-                                             f"(torch CPU fp32 + scalar lmdif), {dt:.1f} s"}
+            res["cpu_baseline"] = cpu_baseline(O, cfg, sd, x[:1].float().cpu(), kw, args.config, num_tokens)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MOGE_ABI_VERSION 1
+#define MOGE_ABI_VERSION 2
 #define MOGE_MAX_TAPS 8
 #define MOGE_LEVELS 5
 
@@ -93,8 +93,10 @@ typedef struct moge_outputs {
 typedef struct moge_handle moge_handle;
 
 /* Kernel classes for the built-in HIP-event profiler (bench.py roofline). */
+/* MOGE_KC_GEMM_PP: launches of the ViT / out-projection linear layers that ran on the ping-pong throughput kernel (gemm_pp128m16_kernel) -
+ * the roofline object of bench.py; MOGE_KC_GEMM: the same layers on the latency-regime kernels + the patch-embed GEMM. */
 enum { MOGE_KC_GEMM = 0, MOGE_KC_ATTN = 1, MOGE_KC_CONV = 2, MOGE_KC_NORM = 3, MOGE_KC_PRE = 4, MOGE_KC_POST = 5,
-       MOGE_KC_RECOVER = 6, MOGE_KC_COUNT = 7 };
+       MOGE_KC_RECOVER = 6, MOGE_KC_GEMM_PP = 7, MOGE_KC_COUNT = 8 };
 typedef struct moge_profile {
     double ms[MOGE_KC_COUNT];        /* summed kernel time per class (HIP events on the launch stream) */
     double flops[MOGE_KC_COUNT];     /* algorithmic FLOPs (2*MAC) launched per class */

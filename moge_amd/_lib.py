@@ -17,7 +17,8 @@ HEAD_POINTS, HEAD_NORMAL, HEAD_MASK, HEAD_SCALE = 1, 2, 4, 8
 FORCE_PROJECTION, APPLY_MASK = 1, 2
 REMAP = {"linear": 0, "sinh": 1, "exp": 2, "sinh_exp": 3}
 ERR_NONFINITE = -5
-KC_NAMES = ["gemm", "attn", "conv", "norm", "pre", "post", "recover"]
+KC_NAMES = ["gemm", "attn", "conv", "norm", "pre", "post", "recover", "gemm_pp"]
+ABI_VERSION = 2
 
 
 class MogeConfig(C.Structure):
@@ -38,7 +39,7 @@ class Outputs(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("ms", C.c_double * 7), ("flops", C.c_double * 7), ("bytes", C.c_double * 7), ("launches", C.c_int64 * 7)]
+    _fields_ = [("ms", C.c_double * 8), ("flops", C.c_double * 8), ("bytes", C.c_double * 8), ("launches", C.c_int64 * 8)]
 
 
 class TestGemmArgs(C.Structure):
@@ -95,7 +96,7 @@ def _load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so does not export what the header declares
         fn.restype = res
         fn.argtypes = args
-    if lib.moge_abi_version() != 1:
+    if lib.moge_abi_version() != ABI_VERSION:
         raise ImportError("libmoge_hip.so ABI version mismatch")
     return lib
 

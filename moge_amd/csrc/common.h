@@ -139,6 +139,11 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
 __device__ __forceinline__ float resid_term(float gamma, float acc, float bias) { return fmaf(gamma, acc, gamma * bias); }   // gamma*(acc+bias)
 __device__ __forceinline__ float uv_term_add(float v, float wu, float u, float wv, float vv) { return fmaf(wu, u, fmaf(wv, vv, v)); }
 
+// q pre-scale of the QKV epilogues: the product is made opaque so that no kernel fuses it with the following fp16 conversion into one
+// v_fma_mixlo_f16 (single rounding) while another emits v_mul_f32 + v_cvt (double rounding): 3e-5 of the q entries differed by one fp16 ulp
+// between gemm.hip and gemm_pp.hip before this
+__device__ __forceinline__ float q_scaled(float v, float s) { float r = v * s; asm volatile("" : "+v"(r)); return r; }
+
 // LN fold (GemmArgs::ln_mr): one output element of the consumer GEMM, and the (sum, sum of squares) of 4 consecutive residual columns
 __device__ __forceinline__ float ln_fold_term(float acc, float mean, float rstd, float c, float b) { return fmaf(rstd, fmaf(-mean, c, acc), b); }
 __device__ __forceinline__ void ln_quad_sums(const f32x4& x, float& s1, float& s2) {
@@ -235,6 +240,7 @@ inline int set_dyn_lds(int bytes) {
 // host-side launchers (gemm.hip, gemm_pp.hip)
 template <typename T> int launch_gemm(const GemmArgs& g, int amode, hipStream_t st);
 bool gemm_pp_eligible(const GemmArgs& g);
+bool gemm_runs_pp(const GemmArgs& g);       // launch_gemm<f16>(g, AMODE_LINEAR) will take the ping-pong throughput kernel (profiler class)
 int launch_gemm_pp(const GemmArgs& g, hipStream_t st);
 bool conv_pp_eligible(const GemmArgs& g);
 int launch_conv_pp(const GemmArgs& g, hipStream_t st);

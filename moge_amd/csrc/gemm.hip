@@ -89,7 +89,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float
         const int b = m / g.Ntok, tok = m - b * g.Ntok;
         const size_t bh = (size_t)b * g.nh + hd;
         if (which == 0) {
-            store4(reinterpret_cast<T*>(g.q) + (bh * g.Ntok + tok) * 64 + d, v[0] * g.qscale, v[1] * g.qscale, v[2] * g.qscale, v[3] * g.qscale);
+            store4(reinterpret_cast<T*>(g.q) + (bh * g.Ntok + tok) * 64 + d, q_scaled(v[0], g.qscale), q_scaled(v[1], g.qscale), q_scaled(v[2], g.qscale), q_scaled(v[3], g.qscale));
         } else if (which == 1) {
             store4(reinterpret_cast<T*>(g.k) + (bh * g.Ntok + tok) * 64 + d, v[0], v[1], v[2], v[3]);
         } else if (g.v_rowmajor) {
@@ -589,6 +589,14 @@ static int launch_by_n(const GemmArgs& g, hipStream_t st) {
     return launch_cfg<T, 4, 1, 1, 1, AMODE>(g, st);                   // 128 x 32
 }
 
+// latency regime (batch 1): fewer than half a wave of 256x256 tiles leaves most CUs idle; the 128x128 / 64x128 kernels below have 4-8x the
+// workgroups (measured at M = 3601: proj 24 vs 33 us, fc2 56 vs 90 us)
+bool gemm_runs_pp(const GemmArgs& g) {
+    if (!moge_tune_get("GEMM_PP", 1) || !gemm_pp_eligible(g)) return false;
+    const long tiles = ((long)(g.M + 255) / 256) * ((g.N + 255) / 256);
+    return tiles >= moge_tune_get("PP_MIN_TILES", 128);
+}
+
 template <typename T>
 int launch_gemm(const GemmArgs& g, int amode, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return -1;
@@ -598,13 +606,7 @@ int launch_gemm(const GemmArgs& g, int amode, hipStream_t st) {
     switch (amode) {
     case AMODE_LINEAR:
         if constexpr (std::is_same<T, f16>::value) {
-            if (moge_tune_get("GEMM_PP", 1) && gemm_pp_eligible(g)) {
-                // latency regime (batch 1): fewer than half a wave of 256x256 tiles leaves most CUs idle; the 128x128 kernel
-                // below has 4x the workgroups (measured at M = 3601: proj 24 vs 33 us, fc2 56 vs 90 us)
-                const long tiles = ((long)(g.M + 255) / 256) * ((g.N + 255) / 256);
-                const bool small = tiles < moge_tune_get("PP_MIN_TILES", 128) && g.N > 64 && (g.K % (8 * TT<T>::CH)) == 0;
-                if (!small) return launch_gemm_pp(g, st);
-            }
+            if (gemm_runs_pp(g)) return launch_gemm_pp(g, st);
         }
         if (g.N > 64 && !g.relu_in && (g.K % (8 * TT<T>::CH)) == 0 && !g_disable_glds) {
             // latency regime: when 128x128 tiles do not even give every CU two workgroups, halve the tile rows (64x128, 48 KiB LDS: up to three

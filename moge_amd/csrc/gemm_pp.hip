@@ -137,7 +137,7 @@ __device__ __forceinline__ f16x4 pp_quad_f16(const f32x4& a, const f32x4& b, flo
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         v[e] = FOLD ? ln_fold_term(a[e], mean, rstd, lc[e], b[e]) : a[e] + b[e];
-        if constexpr (EPK == EPK_QKV) v[e] *= scale;
+        if constexpr (EPK == EPK_QKV) v[e] = q_scaled(v[e], scale);
         if constexpr (EPK == EPK_UV) v[e] = uv_term_add(v[e], wu[e], u, wv[e], vv);
         if constexpr (EPK == EPK_RELU) v[e] = fmaxf(v[e], 0.f);
     }

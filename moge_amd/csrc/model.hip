@@ -471,6 +471,7 @@ static int run_gemm(moge_handle* h, const GemmArgs& g, int amode, int cls, hipSt
     const double k = kalgo > 0 ? kalgo : (double)g.K;
     const double flops = 2.0 * g.M * (double)g.N * k;
     const double bytes = ((double)g.M * k + (double)g.N * k + (double)g.M * g.N) * sizeof(T);
+    if (cls == MOGE_KC_GEMM && amode == AMODE_LINEAR && std::is_same<T, f16>::value && gemm_runs_pp(g)) cls = MOGE_KC_GEMM_PP;
     ProfScope ps(h, st, cls, flops, bytes);
     LCHK(launch_gemm<T>(g, amode, st));
     return 0;
@@ -546,9 +547,24 @@ static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* 
     return 0;
 }
 
+// Position embedding of a token grid: computed once per grid and kept in a small LRU (a CLI / evaluation run sees a new grid for every
+// aspect ratio: 15 MB per entry for ViT-L at 3600 tokens must not accumulate).  Most recently used entry sits at the back.
+static const size_t POS_CACHE_MAX = 8;
 static int get_pos(moge_handle* h, int rows, int cols, hipStream_t st, const float** out) {
-    for (auto& e : h->pos_cache)
-        if (e.rows == rows && e.cols == cols) { *out = e.ptr; return 0; }
+    for (size_t i = 0; i < h->pos_cache.size(); i++)
+        if (h->pos_cache[i].rows == rows && h->pos_cache[i].cols == cols) {
+            const moge_handle::PosEntry e = h->pos_cache[i];
+            h->pos_cache.erase(h->pos_cache.begin() + i);
+            h->pos_cache.push_back(e);
+            *out = e.ptr;
+            return 0;
+        }
+    if (h->pos_cache.size() >= POS_CACHE_MAX) {
+        // the evicted buffer may still be read by kernels in flight on this or the split streams: drain the device before freeing it
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipFree(h->pos_cache.front().ptr));
+        h->pos_cache.erase(h->pos_cache.begin());
+    }
     float* p;
     HIPCHK(hipMalloc(&p, (size_t)(1 + rows * cols) * h->cfg.embed_dim * sizeof(float)));
     LCHK(launch_posembed(M(h, "encoder.backbone.pos_embed"), p, h->cfg.embed_dim, rows, cols, st));

@@ -456,7 +456,9 @@ class MoGeModel:
                 fov = torch.as_tensor(fov_x, dtype=torch.float32, device=dev)
                 if fov.ndim == 0:
                     fov = fov[None].expand(B)
-                fov = fov.contiguous()
+                fov = fov.reshape(-1).contiguous()
+                if fov.numel() != B:        # the reference indexes fov per image (IndexError there); the kernel would read past the buffer
+                    raise ValueError(f"fov_x has {fov.numel()} elements for a batch of {B} images")
                 fov_ptr = fov.data_ptr()
             flags = (L.FORCE_PROJECTION if force_projection else 0) | (L.APPLY_MASK if apply_mask else 0)
             L.check(L.lib.moge_infer(self._handle, image.data_ptr(), img_dtype, B, H, W, rows, cols,
@@ -481,4 +483,4 @@ class MoGeModel:
     def profile_read(self, reset: bool = True) -> Dict[str, Dict[str, float]]:
         p = L.Profile()
         L.check(L.lib.moge_profile_read(self._handle, C.byref(p), 1 if reset else 0))
-        return {L.KC_NAMES[i]: dict(ms=p.ms[i], flops=p.flops[i], bytes=p.bytes[i], launches=p.launches[i]) for i in range(7)}
+        return {L.KC_NAMES[i]: dict(ms=p.ms[i], flops=p.flops[i], bytes=p.bytes[i], launches=p.launches[i]) for i in range(len(L.KC_NAMES))}

@@ -16,10 +16,19 @@ def broadcast_weights(model, src: int = 0, group=None) -> None:
     """Broadcast the master weight blob of `model` (a moge_amd MoGeModel already placed on this rank's GPU) from
     rank `src`.  Non-source ranks need no checkpoint on disk: their blob is allocated from the config alone."""
     blob = model.master_blob()                 # zero-copy uint8 view of the device buffer
-    dist.broadcast(blob, src=src, group=group)
+    if blob.is_cuda and dist.get_backend(group) != "nccl":
+        # a transport without device-memory support (gloo: the 2-ranks-on-one-GPU test, or a node without RCCL): stage through the host.
+        # Production is backend "nccl" (= RCCL on ROCm): the broadcast below reads / writes the device blob directly over xGMI.
+        host = blob.cpu() if dist.get_rank(group) == src else torch.empty(blob.shape, dtype=blob.dtype)
+        dist.broadcast(host, src=src, group=group)
+        if dist.get_rank(group) != src:
+            blob.copy_(host)
+    else:
+        dist.broadcast(blob, src=src, group=group)
     if dist.get_rank(group) != src:
         model.master_received()
-    torch.cuda.synchronize(model.device)
+    if blob.is_cuda:
+        torch.cuda.synchronize(model.device)
 
 
 def shard_batch(n_items: int, world: int, rank: int) -> range:

@@ -51,17 +51,18 @@ class InferPipeline:
         self.pin_in[s][:n].copy_(src)                                   # host memcpy into the pinned slot
         with torch.cuda.stream(self.s_h2d):
             self.s_h2d.wait_event(self.e_comp[s])                       # the previous user of this device slot has been consumed
-            self.dev_in[s].copy_(self.pin_in[s], non_blocking=True)
+            self.dev_in[s][:n].copy_(self.pin_in[s][:n], non_blocking=True)
             self.e_h2d[s].record(self.s_h2d)
         with torch.cuda.stream(self.s_comp):
             self.s_comp.wait_event(self.e_h2d[s])
-            out = self.model.infer_uint8(self.dev_in[s], **self.kw)
+            # only the n submitted images: a short last batch must not run (or raise the sticky non-finite status for) stale slot contents
+            out = self.model.infer_uint8(self.dev_in[s][:n], **self.kw)
             self.e_comp[s].record(self.s_comp)
         with torch.cuda.stream(self.s_d2h):
             self.s_d2h.wait_event(self.e_comp[s])
             for k in self.keys:
                 out[k].record_stream(self.s_d2h)
-                self.pin_out[s][k].copy_(out[k], non_blocking=True)
+                self.pin_out[s][k][:n].copy_(out[k], non_blocking=True)
             self.e_d2h[s].record(self.s_d2h)
 
     def _collect(self, s: int, n: int, copy: bool) -> Dict[str, np.ndarray]:

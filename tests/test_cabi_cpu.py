@@ -16,14 +16,14 @@ def test_library_exports_match_header():
     assert declared == sorted(L.EXPORTS)
     for name in declared:
         assert hasattr(L.lib, name), f"libmoge_hip.so does not export {name}"
-    assert L.lib.moge_abi_version() == 1
+    assert L.lib.moge_abi_version() == L.ABI_VERSION == 2
 
 
 def test_config_struct_layout():
     from moge_amd import _lib as L
     assert ctypes.sizeof(L.MogeConfig) == 4 * (4 + 8 + 5 + 5 + 5 + 3)
     assert ctypes.sizeof(L.Outputs) == 9 * ctypes.sizeof(ctypes.c_void_p)
-    assert ctypes.sizeof(L.Profile) == 7 * 8 * 4
+    assert ctypes.sizeof(L.Profile) == 8 * 8 * 4
 
 
 def test_model_mirror_host_logic():
