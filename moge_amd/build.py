@@ -74,9 +74,12 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
     return LIB
 
 
-def build_tools(verbose: bool = True) -> str:
-    """tools/kbench: stand-alone kernel bench/checker linked against the in-tree library (GPU box utility)."""
-    lib = build(verbose=verbose)
+def build_tools(verbose: bool = True, experiments: bool = None) -> str:
+    """tools/kbench: stand-alone kernel bench/checker linked against the in-tree library (GPU box utility).  experiments=None keeps the
+    flavour the library was last built in."""
+    if experiments is None:
+        experiments = os.path.exists(os.path.join(LIBDIR, "obj", ".experiments"))
+    lib = build(verbose=verbose, experiments=experiments)
     root = os.path.dirname(HERE)
     src = os.path.join(root, "tools", "kbench.hip")
     out = os.path.join(root, "tools", "kbench")
@@ -93,4 +96,4 @@ def build_tools(verbose: bool = True) -> str:
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv))
     if "--tools" in sys.argv:
-        print(build_tools())
+        print(build_tools(experiments="--experiments" in sys.argv))

@@ -63,7 +63,17 @@ constexpr float AP_PSUM_LIMIT = 16384.f;
 // (((row >> 3) & 1) << 2)) - both reads conflict-free for these lane patterns.  Softmax state is per (lane, query block); the four lanes
 // of a query combine their partial sums / maxima with two shuffles where the exact path needs them.
 // ------------------------------------------------------------------------------------------------------------------------
-template <int ABL>      // ABL (tools/kbench only): 1 = the hot loop's exp2 replaced by one multiply (what the transcendental costs)
+// VAR (bit field; the product instantiates ONE value, AP_VAR_DEFAULT; the others exist in -DMOGE_EXPERIMENTS builds for tools/kbench):
+//   1  ablation: the hot loop's exp2 replaced by one multiply (what the transcendental costs; wrong results)
+//   2  ablation: no overflow guard at all (what the guard's serialisation costs; wrong on spiked keys)
+//   4  K Q^T issue order: all eight (key block, query block) chains take their first K-step, then all eight their second - no MFMA is issued
+//      right behind the one it depends on
+//   8  overflow guard on the RAW scores (max over the lane's 32 values of s - m, <= 15 -> every P <= 2^15 fits fp16) instead of on the row
+//      sums: the decision is known right after the K Q^T chain, so the exponentials are free to interleave with the P V MFMAs (with the
+//      sum-based guard the branch sits between the last exponential and the first P V MFMA and serialises the two)
+constexpr int AP_VAR_DEFAULT = 0;
+constexpr float AP_SCORE_LIMIT = 15.f;
+template <int VAR>
 __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
                                                            f16* __restrict__ out, int Ntok, int nh) {
     constexpr int NW = 4, NPW = 4;
@@ -252,6 +262,24 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
         bool hit = false;
         for (; t < ntiles - 1; t++) {                // ---- hot loop: S^T - m = K Q^T + (-m);  P = exp2(.) ----
             tile_head(t);
+            if constexpr (VAR & 4) {
+                u32x4 kf[4][2];
+#pragma unroll
+                for (int kb = 0; kb < 4; kb++) {
+                    const int koff = (32 * (kb >> 1) + 4 * (kb & 1)) * 128;
+                    kf[kb][0] = *reinterpret_cast<const u32x4*>(ka[0] + koff);
+                    kf[kb][1] = *reinterpret_cast<const u32x4*>(ka[1] + koff);
+                }
+#pragma unroll
+                for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+                    for (int qb = 0; qb < 2; qb++)
+                        sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[kb][0]), __builtin_bit_cast(f16x8, qf[qb][0]), negs[qb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+                    for (int qb = 0; qb < 2; qb++) mma16<f16>(sc[kb][qb], kf[kb][1], qf[qb][1]);
+            } else {
 #pragma unroll
             for (int kb = 0; kb < 4; kb++) {
                 const int koff = (32 * (kb >> 1) + 4 * (kb & 1)) * 128;
@@ -262,7 +290,19 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
                     mma16<f16>(sc[kb][qb], kf1, qf[qb][1]);
                 }
             }
+            }
             bool trig = false;
+            if constexpr ((VAR & 8) != 0) {            // guard on the raw scores, decided before any exponential
+                float mx = sc[0][0][0];
+#pragma unroll
+                for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+                    for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) mx = fmaxf(mx, sc[kb][qb][r]);
+                trig = !(mx <= AP_SCORE_LIMIT);
+                if (__builtin_expect(__any(trig), 0)) { hit = true; break; }
+            }
 #pragma unroll
             for (int qb = 0; qb < 2; qb++) {
                 float ps0 = 0.f, ps1 = 0.f;
@@ -270,13 +310,15 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
                 for (int kb = 0; kb < 4; kb++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        sc[kb][qb][r] = ABL == 1 ? sc[kb][qb][r] * 1e-3f : __builtin_amdgcn_exp2f(sc[kb][qb][r]);
+                        sc[kb][qb][r] = (VAR & 1) ? sc[kb][qb][r] * 1e-3f : __builtin_amdgcn_exp2f(sc[kb][qb][r]);
                         if (kb & 1) ps1 += sc[kb][qb][r]; else ps0 += sc[kb][qb][r];
                     }
                 psum[qb] = ps0 + ps1;
                 trig |= !(psum[qb] < AP_PSUM_LIMIT);
             }
-            if (__builtin_expect(__any(trig), 0)) { hit = true; break; }
+            if constexpr ((VAR & (2 | 8)) == 0) {
+                if (__builtin_expect(__any(trig), 0)) { hit = true; break; }
+            }
             pv();
         }
         if (!hit) break;
@@ -308,17 +350,25 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
 
 static int launch_attn_pp16(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
     constexpr int smem = 3 * AP_STAGE;
-    if (int rc = set_dyn_lds<attn_pp16_kernel<0>>(smem)) return rc;
     dim3 grid((Ntok + 127) / 128, B * nh);
+#define AP_LAUNCH_VAR(V) do { if (int rc = set_dyn_lds<attn_pp16_kernel<V>>(smem)) return rc; \
+        hipLaunchKernelGGL(attn_pp16_kernel<V>, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh); \
+        return (int)hipGetLastError(); } while (0)
 #ifdef MOGE_EXPERIMENTS
-    if (moge_tune_get("ATTN_ABL", 0) == 1) {           // ablation: the hot loop's exp2 replaced by one multiply (wrong results; timing only)
-        if (int rc = set_dyn_lds<attn_pp16_kernel<1>>(smem)) return rc;
-        hipLaunchKernelGGL(attn_pp16_kernel<1>, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
-        return (int)hipGetLastError();
+    switch (moge_tune_get("ATTN_VAR", AP_VAR_DEFAULT)) {       // tools/kbench A-B only
+    case 0: AP_LAUNCH_VAR(0);
+    case 1: AP_LAUNCH_VAR(1);
+    case 2: AP_LAUNCH_VAR(2);
+    case 4: AP_LAUNCH_VAR(4);
+    case 6: AP_LAUNCH_VAR(6);
+    case 8: AP_LAUNCH_VAR(8);
+    case 12: AP_LAUNCH_VAR(12);
+    default: return -1;
     }
+#else
+    AP_LAUNCH_VAR(AP_VAR_DEFAULT);
 #endif
-    hipLaunchKernelGGL(attn_pp16_kernel<0>, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
-    return (int)hipGetLastError();
+#undef AP_LAUNCH_VAR
 }
 
 #ifdef MOGE_EXPERIMENTS

@@ -390,6 +390,20 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     }
     f16* const outp = reinterpret_cast<f16*>(g.out);
     const f16* const addp = reinterpret_cast<const f16*>(g.add);
+    // residual add (x + conv(x), modules.py:66): ALL rows of the skip input are loaded before the first store - vmcnt counts stores too and
+    // retires in order, so a {load row; add; store row} loop would wait for the previous row's store before every add
+    f16x8 addv[WROWS / 8];
+    if constexpr (!CONVT) {
+        if (addp) {
+#pragma unroll
+            for (int it = 0; it < WROWS / 8; it++) {
+                const int mp = wm * WROWS + it * 8 + rr;
+                int y = y0 + (mp >> LOG_TW), x = x0 + (mp & (TW - 1));
+                y = y < H ? y : H - 1; x = x < W ? x : W - 1;
+                addv[it] = *reinterpret_cast<const f16x8*>(addp + (((size_t)b * H + y) * W + x) * g.ldadd + nw + cc * 8);
+            }
+        }
+    }
 #pragma unroll
     for (int it = 0; it < WROWS / 8; it++) {
         const int row = it * 8 + rr;
@@ -406,9 +420,8 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
             } else {
                 const size_t idx = (((size_t)b * H + y) * W + x) * g.ldc + nw + cc * 8;
                 if (addp) {
-                    const f16x8 a = *reinterpret_cast<const f16x8*>(addp + (((size_t)b * H + y) * W + x) * g.ldadd + nw + cc * 8);
                     f16x8 h = __builtin_bit_cast(f16x8, v);
-                    h += a;                                  // fp16 + fp16, as the reference's .half() path does (x + conv(x))
+                    h += addv[it];                           // fp16 + fp16, as the reference's .half() path does (x + conv(x))
                     v = __builtin_bit_cast(u32x4, h);
                 }
                 *reinterpret_cast<u32x4*>(outp + idx) = v;

@@ -37,41 +37,70 @@ template <int EPK> struct EpkBase { static constexpr int K = EPK == EPK_GELU_LN 
                                     static constexpr bool FOLD = EPK == EPK_GELU_LN || EPK == EPK_QKV_LN; };
 
 // ---- stage 2: LDS staging region (row-major, 128 B per row, 16-byte chunks XOR-swizzled by row & 7) -> global memory ----
+// The read-modify-write of the fp32 residual is split into three straight-line stages so that NO load is ever waited for behind a store:
+// on gfx950 vmcnt counts stores as well as loads and retires in issue order, so a loop of {wait for row i's load; add; store row i}
+// makes every iteration wait for the previous iteration's STORES to be acknowledged (measured: ~1 us per row group, 18 us of a 43 us
+// K = 1024 tile).  Here: (1) all row loads of a pass are issued, (2) all adds are done (waits see loads only), (3) all stores are issued
+// back to back; the caller issues the NEXT pass's loads before this pass's stores.
+// Addressing: raw buffer instructions over a descriptor of exactly M rows (wave-uniform, built from kernel arguments) + ONE 32-bit byte
+// offset per lane - no 64-bit per-lane address lives across the stages (with them the kernel spilled, and every scratch reload waited
+// vmcnt(0) = for all stores in flight); rows >= M are out of range of the descriptor: their loads return 0 and their stores are dropped.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+struct ResidBufs {
+    __amdgpu_buffer_rsrc_t x, x16, part;
+    unsigned ldc4, ldc2, npart8;        // row pitches in bytes: fp32 residual, fp16 copy, (sum, sum of squares) pairs
+};
+__device__ __forceinline__ ResidBufs pp_resid_bufs(const GemmArgs& g) {
+    ResidBufs r;
+    r.ldc4 = (unsigned)g.ldc * 4u; r.ldc2 = (unsigned)g.ldc * 2u; r.npart8 = (unsigned)(g.N >> 5) * 8u;
+    r.x = __builtin_amdgcn_make_buffer_rsrc(g.xres, 0, (int)((unsigned)g.M * r.ldc4), 0x00020000);
+    r.x16 = __builtin_amdgcn_make_buffer_rsrc(g.x16, 0, g.x16 ? (int)((unsigned)g.M * r.ldc2) : 0, 0x00020000);
+    r.part = __builtin_amdgcn_make_buffer_rsrc(g.ln_part, 0, g.ln_part ? (int)((unsigned)g.M * r.npart8) : 0, 0x00020000);
+    return r;
+}
 template <int WROWS>
-__device__ __forceinline__ void pp_resid_rows(const GemmArgs& g, const char* R, int lane, int mw, int ncol) {
-    // read-modify-write of 32 fp32 columns in full 128-byte row segments; all loads of a pass are issued before the first add
+__device__ __forceinline__ void pp_resid_load(const ResidBufs& rb, int lane, int mw, int ncol, f32x4 (&xv)[WROWS / 8]) {
     const int rr = lane >> 3, cc = lane & 7;
-    const int M = g.M;
-    float* const xres = g.xres;
-    const long ldc = g.ldc;
-    f32x4 xv[WROWS / 8];
+    const unsigned off0 = (unsigned)(mw + rr) * rb.ldc4 + (unsigned)(ncol + cc * 4) * 4u;
 #pragma unroll
-    for (int it = 0; it < WROWS / 8; it++) {
-        const int m = mw + it * 8 + rr;
-        const int mc = m < M ? m : M - 1;
-        xv[it] = *reinterpret_cast<const f32x4*>(xres + (size_t)mc * ldc + ncol + cc * 4);
-    }
+    for (int it = 0; it < WROWS / 8; it++)
+        xv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb.x, (int)(off0 + (unsigned)it * 8u * rb.ldc4), 0, 0));
+}
+template <int WROWS>
+__device__ __forceinline__ void pp_resid_add(const char* R, int lane, f32x4 (&xv)[WROWS / 8]) {
+    const int rr = lane >> 3, cc = lane & 7;
 #pragma unroll
     for (int it = 0; it < WROWS / 8; it++) {
         const int row = it * 8 + rr;
-        const int m = mw + row;
         const f32x4 v = *reinterpret_cast<const f32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
-        const f32x4 xnew = xv[it] + v;
-        if (m < M) *reinterpret_cast<f32x4*>(xres + (size_t)m * ldc + ncol + cc * 4) = xnew;
-        if (g.x16) {          // LN fold producer: fp16 copy + (sum, sum of squares) of this row's 32-column group (8 lanes, butterfly 1-2-4)
-            {   // lane pairs (cc, cc ^ 1) share one 16-byte store of 8 columns
-                const f16x4 h4 = {(f16)xnew[0], (f16)xnew[1], (f16)xnew[2], (f16)xnew[3]};
-                const f32x2 mine = __builtin_bit_cast(f32x2, h4);
-                f32x2 other;
-                other[0] = __shfl_xor(mine[0], 1); other[1] = __shfl_xor(mine[1], 1);
-                if (m < M && !(cc & 1))
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<f16*>(g.x16) + (size_t)m * ldc + ncol + cc * 4) = f32x4{mine[0], mine[1], other[0], other[1]};
-            }
+        xv[it] = xv[it] + v;
+    }
+}
+template <int WROWS>
+__device__ __forceinline__ void pp_resid_store(const ResidBufs& rb, bool fold, int lane, int mw, int ncol, const f32x4 (&xv)[WROWS / 8]) {
+    const int rr = lane >> 3, cc = lane & 7;
+    const unsigned off0 = (unsigned)(mw + rr) * rb.ldc4 + (unsigned)(ncol + cc * 4) * 4u;
+#pragma unroll
+    for (int it = 0; it < WROWS / 8; it++)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xv[it]), rb.x, (int)(off0 + (unsigned)it * 8u * rb.ldc4), 0, 0);
+    if (fold) {               // LN fold producer: fp16 copy + (sum, sum of squares) of each row's 32-column group (8 lanes, butterfly 1-2-4)
+        // lane pairs (cc, cc ^ 1) share one 16-byte store of 8 columns: odd lanes point past the end of the descriptor (store dropped)
+        const unsigned h0 = (cc & 1) ? 0xffffff00u : (unsigned)(mw + rr) * rb.ldc2 + (unsigned)(ncol + cc * 4) * 2u;
+        const unsigned p0 = cc ? 0xffffff00u : (unsigned)(mw + rr) * rb.npart8 + (unsigned)(ncol >> 5) * 8u;
+#pragma unroll
+        for (int it = 0; it < WROWS / 8; it++) {
+            const f32x4 xnew = xv[it];
+            const f16x4 h4 = {(f16)xnew[0], (f16)xnew[1], (f16)xnew[2], (f16)xnew[3]};
+            const u32x2 mine = __builtin_bit_cast(u32x2, h4);
+            u32x4 pk;
+            pk[0] = mine[0]; pk[1] = mine[1];
+            pk[2] = (unsigned)__shfl_xor((int)mine[0], 1); pk[3] = (unsigned)__shfl_xor((int)mine[1], 1);
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rb.x16, (int)((cc & 1) ? h0 : h0 + (unsigned)it * 8u * rb.ldc2), 0, 0);
             float s1, s2;
             ln_quad_sums(xnew, s1, s2);
 #pragma unroll
             for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-            if (cc == 0 && m < M) *reinterpret_cast<f32x2*>(g.ln_part + ((size_t)m * (g.N >> 5) + (ncol >> 5)) * 2) = f32x2{s1, s2};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{s1, s2}), rb.part, (int)(cc ? p0 : p0 + (unsigned)it * 8u * rb.npart8), 0, 0);
         }
     }
 }
@@ -163,24 +192,39 @@ __device__ __forceinline__ void pp_epilogue16(const GemmArgs& g, f32x4 (&acc)[8]
     const int M = g.M;
 
     if constexpr (EPK == EPK_RESID) {
+        // two passes of 32 fp32 columns (128 B per staging row); pass 1's row loads are in flight before pass 0's stores are issued.
+        // gamma (acc + bias) is applied IN PLACE to all accumulators first: a bias / gamma load issued after the first stores would sit
+        // behind them in the in-order vmcnt queue
+        auto stage = [&](int J) {
 #pragma unroll
-        for (int J = 0; J < 2; J++) {                       // 32 fp32 columns = 128 B per staging row
-#pragma unroll
-            for (int jh = 0; jh < 2; jh++) {
-                const int n = nw + J * 32 + jh * 16 + 4 * g4;
-                const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
+            for (int jh = 0; jh < 2; jh++)
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const int row = i * 16 + l15;
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = resid_term(gm[e], acc[i][j0 + J * 2 + jh][e], b[e]);
-                    *reinterpret_cast<f32x4*>(R + row * 128 + (((jh * 4 + g4) ^ (row & 7)) << 4)) = v;
+                    *reinterpret_cast<f32x4*>(R + row * 128 + (((jh * 4 + g4) ^ (row & 7)) << 4)) = acc[i][j0 + J * 2 + jh];
                 }
-            }
-            pp_resid_rows<WROWS>(g, R, lane, mw, nw + J * 32);
+        };
+        const ResidBufs rb = pp_resid_bufs(g);
+        const bool fold = g.x16 != nullptr;
+        f32x4 x0[WROWS / 8], x1[WROWS / 8];
+        pp_resid_load<WROWS>(rb, lane, mw, nw, x0);
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int n = nw + jj * 16 + 4 * g4;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[i][j0 + jj][e] = resid_term(gm[e], acc[i][j0 + jj][e], b[e]);
         }
+        stage(0);
+        pp_resid_add<WROWS>(R, lane, x0);
+        pp_resid_load<WROWS>(rb, lane, mw, nw + 32, x1);
+        pp_resid_store<WROWS>(rb, fold, lane, mw, nw, x0);
+        stage(1);
+        pp_resid_add<WROWS>(R, lane, x1);
+        pp_resid_store<WROWS>(rb, fold, lane, mw, nw + 32, x1);
     } else {
         float scale = 1.f;
         if constexpr (EPK == EPK_QKV) scale = nw < g.D ? g.qscale : 1.f;
@@ -589,6 +633,7 @@ bool gemm_pp_eligible(const GemmArgs& g) {
         if (!(g.epi == EPI_QKV || (g.epi == EPI_STORE && g.act == ACT_GELU && !g.uv.wu))) return false;
     }
     if (g.x16 && (g.epi != EPI_RESID || !g.ln_part)) return false;
+    if (g.epi == EPI_RESID && (size_t)g.M * (size_t)g.ldc * 4 >= 0xffffff00ull) return false;       // 32-bit buffer offsets in the RESID epilogue
     switch (g.epi) {
     case EPI_STORE: return (g.ldc & 7) == 0 && (!g.uv.wu || g.bias);
     case EPI_RESID: return g.bias && g.gamma && (g.ldc & 3) == 0;

@@ -73,8 +73,9 @@ struct moge_handle {
     size_t u8_stage_bytes = 0;
     // batch-split execution: two internal streams run the two halves of a batch concurrently (tails of one half's kernels
     // and its HBM-bound kernels overlap the other half's MFMA kernels); joined on the caller's stream before post-processing
-    hipStream_t split_st[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    static constexpr int MAX_SPLIT = 4;
+    hipStream_t split_st[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
     float img_mean[3] = {0.485f, 0.456f, 0.406f}, img_std[3] = {0.229f, 0.224f, 0.225f};   // refreshed from the checkpoint buffers
     // profiler
     bool prof_on = false;
@@ -840,7 +841,7 @@ void moge_destroy(moge_handle* h) {
     if (h->u8_stage) hipFree(h->u8_stage);
     for (auto& e : h->pos_cache) hipFree(e.ptr);
     if (h->d_status) hipFree(h->d_status);
-    for (int i = 0; i < 2; i++) { if (h->split_st[i]) hipStreamDestroy(h->split_st[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
+    for (int i = 0; i < moge_handle::MAX_SPLIT; i++) { if (h->split_st[i]) hipStreamDestroy(h->split_st[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     for (auto& r : h->prof_pending) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (auto e : h->ev_pool) hipEventDestroy(e);
@@ -921,38 +922,50 @@ static int check_call(moge_handle* h, const void* image, int B, int H, int W, in
     return 0;
 }
 
-static bool use_split(moge_handle* h, int B) { return B >= 8 && !h->prof_on && moge_tune_get("BATCH_SPLIT", 1) != 0; }
+// number of sub-batches a batch of B runs as (each on its own internal stream): BATCH_SPLIT = 0/1 off, n >= 2 -> n parts (default 2) when
+// every part keeps at least 4 images
+static int split_parts(moge_handle* h, int B) {
+    if (h->prof_on) return 1;
+    int n = moge_tune_get("BATCH_SPLIT", 2);
+    if (n > moge_handle::MAX_SPLIT) n = moge_handle::MAX_SPLIT;
+    while (n > 1 && B / n < 4) n--;
+    return n < 2 ? 1 : n;
+}
 // workspace bytes a forward over plan pl needs (callers size the arena BEFORE taking pointers into it)
 static size_t forward_ws_bytes(moge_handle* h, const Plan& pl) {
-    if (!use_split(h, pl.B)) return pl.total;
+    const int n = split_parts(h, pl.B);
+    if (n == 1) return pl.total;
     size_t off = pl.post_end;
-    off += make_plan(h->cfg, h->prec, pl.B / 2, pl.H, pl.W, pl.rows, pl.cols).total;
-    off += make_plan(h->cfg, h->prec, pl.B - pl.B / 2, pl.H, pl.W, pl.rows, pl.cols).total;
+    for (int i = 0; i < n; i++) {
+        const int b0 = (int)((long)pl.B * i / n), b1 = (int)((long)pl.B * (i + 1) / n);
+        off += make_plan(h->cfg, h->prec, b1 - b0, pl.H, pl.W, pl.rows, pl.cols).total;
+    }
     return off > pl.total ? off : pl.total;
 }
 
 static int forward_dispatch(moge_handle* h, const void* image, int img_dtype, const Plan& pl, float* pts, float* nrm, float* mp, float* metric, hipStream_t st) {
     if (!h->pk_ready[h->prec]) CHK(moge_set_precision(h, h->prec, st));
     const int B = pl.B;
-    const bool split = use_split(h, B);
-    if (!split) {
+    const int n = split_parts(h, B);
+    if (n == 1) {
         CHK(ensure_ws(h, pl.total));
         if (h->prec == MOGE_FP16) return forward_impl<f16>(h, image, img_dtype, pl, pts, nrm, mp, metric, st);
         return forward_impl<float>(h, image, img_dtype, pl, pts, nrm, mp, metric, st);
     }
-    // ---- two half batches on two internal streams ----------------------------------------------------------------------
-    if (!h->split_st[0]) {
-        for (int i = 0; i < 2; i++) {
+    // ---- n sub-batches on n internal streams ---------------------------------------------------------------------------
+    for (int i = 0; i < n; i++)
+        if (!h->split_st[i]) {
             HIPCHK(hipStreamCreateWithFlags(&h->split_st[i], hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
         }
-        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    }
-    const int Bs[2] = {B / 2, B - B / 2};
-    Plan sub[2];
+    if (!h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    Plan sub[moge_handle::MAX_SPLIT];
+    int b0s[moge_handle::MAX_SPLIT + 1];
     size_t off = pl.post_end;                      // keep the caller-visible post buffers (mask prob, focal, ...) of the full plan
-    for (int i = 0; i < 2; i++) {
-        sub[i] = make_plan(h->cfg, h->prec, Bs[i], pl.H, pl.W, pl.rows, pl.cols);
+    for (int i = 0; i < n; i++) {
+        b0s[i] = (int)((long)B * i / n);
+        const int b1 = (int)((long)B * (i + 1) / n);
+        sub[i] = make_plan(h->cfg, h->prec, b1 - b0s[i], pl.H, pl.W, pl.rows, pl.cols);
         sub[i].base = off;
         off += sub[i].total;
     }
@@ -962,8 +975,8 @@ static int forward_dispatch(moge_handle* h, const void* image, int img_dtype, co
     HIPCHK(hipEventRecord(h->ev_fork, st));
     const size_t px = (size_t)pl.H * pl.W;
     const size_t img_elem = img_dtype == 1 ? 2 : 4;
-    for (int i = 0; i < 2; i++) {
-        const size_t b0 = i == 0 ? 0 : (size_t)Bs[0];
+    for (int i = 0; i < n; i++) {
+        const size_t b0 = (size_t)b0s[i];
         HIPCHK(hipStreamWaitEvent(h->split_st[i], h->ev_fork, 0));
         const void* img_i = (const char*)image + b0 * 3 * px * img_elem;
         float* pts_i = pts ? pts + b0 * px * 3 : nullptr;
@@ -976,7 +989,7 @@ static int forward_dispatch(moge_handle* h, const void* image, int img_dtype, co
         if (rc) return rc;
         HIPCHK(hipEventRecord(h->ev_join[i], h->split_st[i]));
     }
-    for (int i = 0; i < 2; i++) HIPCHK(hipStreamWaitEvent(st, h->ev_join[i], 0));
+    for (int i = 0; i < n; i++) HIPCHK(hipStreamWaitEvent(st, h->ev_join[i], 0));
     h->last.valid = false;                          // debug taps address one contiguous batch: not available in split mode
     return 0;
 }

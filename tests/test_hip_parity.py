@@ -222,7 +222,7 @@ def test_batch_split_streams_are_bit_identical(MoGeModel, tmp_path_factory):
                 model.half()
             L.tune("BATCH_SPLIT", 0)
             ref = model.infer(x, num_tokens=108)
-            L.tune("BATCH_SPLIT", 1)
+            L.tune("BATCH_SPLIT", 2)
             out = model.infer(x, num_tokens=108)
             for k in ref:
                 a, b = out[k], ref[k]
@@ -232,7 +232,7 @@ def test_batch_split_streams_are_bit_identical(MoGeModel, tmp_path_factory):
                     fin = torch.isfinite(b)
                     assert torch.equal(fin, torch.isfinite(a)) and torch.equal(a[fin], b[fin]), f"{k}: split != single stream"
     finally:
-        L.tune("BATCH_SPLIT", 1)
+        L.tune("BATCH_SPLIT", 2)
         model.float()
 
 

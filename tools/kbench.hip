@@ -352,13 +352,14 @@ static int bench_attn(int iters) {
         CK(hipMemcpyAsync(dbh, sbh.data(), ns * 4, hipMemcpyHostToDevice, st)); CK(hipMemcpyAsync(dq, sq.data(), ns * 4, hipMemcpyHostToDevice, st));
         ref_attn<<<ns, 256, 0, st>>>(q, k, v, dbh, dq, c.Ntok, ref);
         CK(hipStreamSynchronize(st));
-        struct Var { const char* name; int kind, nw, qt, m16, abl; };
-        const Var vars[] = {{"old(vT)", 0, 0, 1, 0, 0}, {"pp nw4", 1, 4, 1, 0, 0}, {"pp16", 1, 4, 1, 1, 0}, {"pp16-noexp", 1, 4, 1, 1, 1}};
+        // exp: ATTN_EXP (32x32x16 kernels), var: ATTN_VAR bits of attn_pp16_kernel - both need a library built with --experiments
+        struct Var { const char* name; int kind, exp, var; };
+        std::vector<Var> vars = {{"pp16", 1, 0, 0}};
+        if (getenv("KB_EXP")) vars = {{"old(vT)", 0, 0, 0}, {"x:pp32 nw4", 1, 1, 0}, {"pp16", 1, 0, 0}, {"x:noexp", 1, 0, 1}, {"x:noguard", 1, 0, 2}, {"x:ks-outer", 1, 0, 4},
+                                      {"x:ks+noguard", 1, 0, 6}, {"x:maxguard", 1, 0, 8}, {"x:ks+maxguard", 1, 0, 12}};
         for (const Var& va : vars) {
-            moge_tune_set("ATTN_NW", va.nw);
-            moge_tune_set("ATTN_QT", va.qt);
-            moge_tune_set("ATTN_M16", va.m16);
-            moge_tune_set("ATTN_ABL", va.abl);
+            moge_tune_set("ATTN_EXP", va.exp);
+            moge_tune_set("ATTN_VAR", va.var);
             auto run = [&]() { return va.kind == 0 ? launch_attention<f16>(q, k, vT, out, c.B, c.nh, c.Ntok, Npad, st) : launch_attention_pp(q, k, v, out, c.B, c.nh, c.Ntok, st); };
             CK(hipMemsetAsync(out, 0, n * 2, st));
             int rc = run();
