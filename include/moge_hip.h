@@ -127,6 +127,11 @@ int moge_master_ready(moge_handle* h);
  * kernel-layout weight set for that precision on first use (both sets may stay resident). */
 int moge_set_precision(moge_handle* h, int precision, void* stream);
 
+/* replaces the `MoGeModel.onnx_compatible_mode` setter (v2.py:67-74, docs/onnx.md): the forward the reference exports to ONNX - the 14x
+ * image resize without antialiasing (modules.py:121) and the position embedding resampled by output size instead of the scale-factor
+ * kludge, never bypassed (vision_transformer.py:192,202-210).  Affects forward and infer of this handle until switched off. */
+int moge_set_onnx_compatible_mode(moge_handle* h, int on);
+
 /* bytes of device workspace a call with these shapes needs (grown lazily by forward/infer). */
 int moge_workspace_bytes(moge_handle* h, int B, int H, int W, int token_rows, int token_cols, size_t* bytes);
 

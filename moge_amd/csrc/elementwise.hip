@@ -22,7 +22,9 @@ __device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1
 
 template <typename TIn, typename TOut>
 __global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict__ out, int B, int H, int W, int rows, int cols,
-                                  int ldk, int nchw_out, int round16, float m0, float m1, float m2, float s0, float s1, float s2) {
+                                  int ldk, int nchw_out, int round16, int aa, float m0, float m1, float m2, float s0, float s1, float s2) {
+    // aa == 0: onnx_compatible_mode (modules.py:121 antialias=False): ATen upsample_bilinear2d, align_corners=False - two taps per axis at
+    // src = scale * (dst + 0.5) - 0.5 clamped at 0, i1 = min(i0 + 1, in - 1), whatever the scale
     // round16: fp32 input whose values are first rounded to fp16 - the reference's `image.to(dtype=self.dtype)` for a .half() model
     // (v2.py:229) - done here on load instead of as a separate cast pass over the image
     // one thread per output PIXEL: the filter ranges and weight sums depend on (oy, ox) only and serve the three channels
@@ -35,6 +37,26 @@ __global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict_
         long t = idx / OW;
         const int oy = t % OH;
         const int b = t / OH;
+        if (!aa) {
+            float sy = scale_y * ((float)oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+            float sx = scale_x * ((float)ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+            const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+            const int py = oy / 14, iy = oy - py * 14, px = ox / 14, ix = ox - px * 14;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const TIn* pl = img + ((size_t)b * 3 + c) * H * W;
+                float v00 = (float)pl[(size_t)y0 * W + x0], v01 = (float)pl[(size_t)y0 * W + x1], v10 = (float)pl[(size_t)y1 * W + x0], v11 = (float)pl[(size_t)y1 * W + x1];
+                if (round16) { v00 = (float)(f16)v00; v01 = (float)(f16)v01; v10 = (float)(f16)v10; v11 = (float)(f16)v11; }
+                const float r = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+                const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+                const float v = (r - mean) / sd;
+                if (nchw_out) out[(((size_t)b * 3 + c) * OH + oy) * OW + ox] = (TOut)v;
+                else out[((size_t)b * rows * cols + (size_t)py * cols + px) * ldk + c * 196 + iy * 14 + ix] = (TOut)v;
+            }
+            continue;
+        }
         int ylo, yn, xlo, xn; float yc, yis, ysup, xc, xis, xsup;
         aa_range(oy, scale_y, H, ylo, yn, yc, yis, ysup);
         aa_range(ox, scale_x, W, xlo, xn, xc, xis, xsup);
@@ -69,19 +91,19 @@ __global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict_
 }
 
 template <typename TIn, typename TOut>
-int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out, int round16,
+int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out, int round16, int aa,
                       const float* mean, const float* std_, hipStream_t st) {
     const long total = (long)B * rows * 14 * cols * 14;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL((preprocess_kernel<TIn, TOut>), dim3(blocks), dim3(256), 0, st, (const TIn*)img, (TOut*)out, B, H, W, rows, cols,
-                       ldk, nchw_out, round16, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2]);
+                       ldk, nchw_out, round16, aa, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2]);
     return (int)hipGetLastError();
 }
-template int launch_preprocess<float, f16>(const void*, void*, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
-template int launch_preprocess<float, float>(const void*, void*, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
-template int launch_preprocess<f16, f16>(const void*, void*, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
-template int launch_preprocess<f16, float>(const void*, void*, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+template int launch_preprocess<float, f16>(const void*, void*, int, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+template int launch_preprocess<float, float>(const void*, void*, int, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+template int launch_preprocess<f16, f16>(const void*, void*, int, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+template int launch_preprocess<f16, float>(const void*, void*, int, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
 
 // Caller-side ingest (scripts/infer.py:98: `torch.tensor(image / 255, dtype=torch.float32).permute(2, 0, 1)`, then v2.py:229 casts to the model
 // dtype): uint8 (B,H,W,3) -> T (B,3,H,W).  numpy divides in float64 and the tensor constructor rounds to float32 once: same here.
@@ -175,10 +197,13 @@ __global__ void posembed_kernel(const float* __restrict__ pos, float* __restrict
         out[idx] = acc;
     }
 }
-int launch_posembed(const float* pos, float* out, int D, int rows, int cols, hipStream_t st) {
+// size_mode (onnx_compatible_mode, vision_transformer.py:192,202-210): never bypassed, resampled by OUTPUT SIZE: src scale = 37 / n in float
+// (ATen area_pixel_compute_scale without a scale factor) instead of 1 / ((n + 0.1) / 37)
+int launch_posembed(const float* pos, float* out, int D, int rows, int cols, int size_mode, hipStream_t st) {
     const int M = 37;
-    const int bypass = (rows == M && cols == M) ? 1 : 0;
-    const float ry = (float)(1.0 / ((double)(rows + 0.1) / M)), rx = (float)(1.0 / ((double)(cols + 0.1) / M));
+    const int bypass = (!size_mode && rows == M && cols == M) ? 1 : 0;
+    float ry = (float)(1.0 / ((double)(rows + 0.1) / M)), rx = (float)(1.0 / ((double)(cols + 0.1) / M));
+    if (size_mode) { ry = (float)M / (float)rows; rx = (float)M / (float)cols; }
     const long total = (long)(1 + rows * cols) * D;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;

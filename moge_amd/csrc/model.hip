@@ -65,7 +65,8 @@ struct moge_handle {
     char* ws = nullptr;
     size_t ws_bytes = 0;
     // position-embedding cache
-    struct PosEntry { int rows, cols; float* ptr; };
+    struct PosEntry { int rows, cols, mode; float* ptr; };
+    int onnx_mode = 0;          // onnx_compatible_mode (v2.py:67-74): plain bilinear 14x resize, size-based pos-embed resampling
     std::vector<PosEntry> pos_cache;
     int* d_status = nullptr;
     // staging for uint8 HWC input (img_dtype 2): converted to the model dtype, CHW, before the forward
@@ -553,7 +554,7 @@ static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* 
 static const size_t POS_CACHE_MAX = 8;
 static int get_pos(moge_handle* h, int rows, int cols, hipStream_t st, const float** out) {
     for (size_t i = 0; i < h->pos_cache.size(); i++)
-        if (h->pos_cache[i].rows == rows && h->pos_cache[i].cols == cols) {
+        if (h->pos_cache[i].rows == rows && h->pos_cache[i].cols == cols && h->pos_cache[i].mode == h->onnx_mode) {
             const moge_handle::PosEntry e = h->pos_cache[i];
             h->pos_cache.erase(h->pos_cache.begin() + i);
             h->pos_cache.push_back(e);
@@ -568,8 +569,8 @@ static int get_pos(moge_handle* h, int rows, int cols, hipStream_t st, const flo
     }
     float* p;
     HIPCHK(hipMalloc(&p, (size_t)(1 + rows * cols) * h->cfg.embed_dim * sizeof(float)));
-    LCHK(launch_posembed(M(h, "encoder.backbone.pos_embed"), p, h->cfg.embed_dim, rows, cols, st));
-    h->pos_cache.push_back({rows, cols, p});
+    LCHK(launch_posembed(M(h, "encoder.backbone.pos_embed"), p, h->cfg.embed_dim, rows, cols, h->onnx_mode, st));
+    h->pos_cache.push_back({rows, cols, h->onnx_mode, p});
     *out = p;
     return 0;
 }
@@ -602,8 +603,8 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
         ProfScope ps(h, st, MOGE_KC_PRE, 0, (double)B * 3 * pl.H * pl.W * (img_dtype == 1 ? 2 : 4) + (double)BP * KPATCH_PAD * sizeof(T));
         LCHK(launch_zero_cols<T>(patches, BP, KPATCH_PAD, KPATCH, st));
         // img_dtype 3 = fp32 values to be rounded to fp16 on load (the model-dtype cast of a .half() model, v2.py:229)
-        if (img_dtype == 0 || img_dtype == 3) LCHK((launch_preprocess<float, T>(image, patches, B, pl.H, pl.W, rows, cols, KPATCH_PAD, 0, img_dtype == 3, mean, sd, st)));
-        else LCHK((launch_preprocess<f16, T>(image, patches, B, pl.H, pl.W, rows, cols, KPATCH_PAD, 0, 0, mean, sd, st)));
+        if (img_dtype == 0 || img_dtype == 3) LCHK((launch_preprocess<float, T>(image, patches, B, pl.H, pl.W, rows, cols, KPATCH_PAD, 0, img_dtype == 3, !h->onnx_mode, mean, sd, st)));
+        else LCHK((launch_preprocess<f16, T>(image, patches, B, pl.H, pl.W, rows, cols, KPATCH_PAD, 0, 0, !h->onnx_mode, mean, sd, st)));
     }
     const float* pos;
     CHK(get_pos(h, rows, cols, st, &pos));
@@ -904,6 +905,12 @@ int moge_set_precision(moge_handle* h, int precision, void* stream) {
     CHK(build_aux(h, st));
     if (precision == MOGE_FP16) CHK(pack_weights<f16>(h, st)); else CHK(pack_weights<float>(h, st));
     h->prec = precision;
+    return 0;
+}
+
+int moge_set_onnx_compatible_mode(moge_handle* h, int on) {
+    if (!h) return fail(MOGE_ERR_INVALID, "null handle");
+    h->onnx_mode = on ? 1 : 0;
     return 0;
 }
 

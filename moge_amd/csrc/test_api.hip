@@ -222,14 +222,14 @@ int moge_test_convt2x2(int precision, const float* x, const float* w, const floa
 int moge_test_preprocess(const float* image, float* out, int B, int H, int W, int rows, int cols, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
-    TL((launch_preprocess<float, float>(image, out, B, H, W, rows, cols, 0, 1, 0, mean, sd, st)));
+    TL((launch_preprocess<float, float>(image, out, B, H, W, rows, cols, 0, 1, 0, 1, mean, sd, st)));
     TCHK(hipStreamSynchronize(st));
     return 0;
 }
 
 int moge_test_posembed(const float* pos, float* out, int D, int rows, int cols, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    TL(launch_posembed(pos, out, D, rows, cols, st));
+    TL(launch_posembed(pos, out, D, rows, cols, 0, st));
     TCHK(hipStreamSynchronize(st));
     return 0;
 }

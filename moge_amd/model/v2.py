@@ -130,9 +130,11 @@ class MoGeModel:
 
     @onnx_compatible_mode.setter
     def onnx_compatible_mode(self, value: bool):
-        if value:
-            raise NotImplementedError("onnx_compatible_mode is not implemented by the HIP path")
-        self._onnx_compatible_mode = False
+        """v2.py:67-74: the forward the reference exports to ONNX (no antialiasing in the 14x resize, size-based position-embedding
+        resampling).  Applied to the HIP handle now, or when the handle is created."""
+        self._onnx_compatible_mode = bool(value)
+        if self._handle is not None:
+            L.check(L.lib.moge_set_onnx_compatible_mode(self._handle, 1 if self._onnx_compatible_mode else 0))
 
     def eval(self) -> "MoGeModel":
         self.training = False
@@ -212,6 +214,8 @@ class MoGeModel:
         L.check(L.lib.moge_create(C.byref(self._cfg), self._device.index, C.byref(h)))
         self._handle = h
         self._state_ready = False
+        if self._onnx_compatible_mode:
+            L.check(L.lib.moge_set_onnx_compatible_mode(self._handle, 1))
         if self._state is not None:
             self._upload()
         elif self._blob_path is not None:

@@ -3,9 +3,10 @@
 Same flags where the step exists here (`--input/-i`, `--output/-o`, `--pretrained`, `--fov_x`, `--resize`, `--resolution_level`,
 `--num_tokens`, `--threshold`, `--maps`, `--ply`, `--fp16`, `--device`); images of equal size are batched (`--batch`) and run through
 `moge_amd.pipeline.InferPipeline` (uint8 upload, transfers overlapped with compute).  Differences, all forced by what this image ships:
-decode / resize use PIL instead of cv2 (BOX filter for `--resize`, the closest PIL has to INTER_AREA); float maps are written as
-`.npy` instead of `.exr`; `--glb` / `--show` (trimesh) are not provided; the point cloud's vertices are the pixels of
-`mask & ~depth_map_edge(depth, rtol=threshold)` (the vertex set `utils3d.np.build_mesh_from_map` produces at scripts/infer.py:128-145).
+decode / resize use PIL instead of cv2 (BOX filter for `--resize`, the closest PIL has to INTER_AREA); `depth.exr` / `points.exr` are
+written by moge_amd.io.save_exr (uncompressed float32 OpenEXR, same channels as cv2 writes); `mesh.glb` by moge_amd.io.save_glb (glTF 2.0
+binary written directly - trimesh is not installed; same material parameters as moge/utils/io.py:18-42); `--show` (trimesh viewer) is not
+provided.  Mesh and point cloud are built from `mask & ~depth_map_edge(depth, rtol=threshold)` exactly as scripts/infer.py:127-149 does.
 """
 from __future__ import annotations
 
@@ -30,14 +31,15 @@ import numpy as np
 @click.option("--num_tokens", type=int, default=None, help="Number of ViT tokens, [1200, 2500] suggested.")
 @click.option("--threshold", type=float, default=0.04, help="Relative depth-edge threshold for the point cloud, default 0.04.")
 @click.option("--maps", "save_maps_", is_flag=True, help="Save depth / points / mask / normal maps and fov.json.")
+@click.option("--glb", "save_glb_", is_flag=True, help="Save a textured mesh (.glb).")
 @click.option("--ply", "save_ply_", is_flag=True, help="Save a coloured point cloud (.ply).")
 @click.option("--batch", "batch", type=int, default=8, help="Images of equal size per infer() call.")
 def main(input_path, fov_x_, output_path, pretrained_model_name_or_path, device_name, use_fp16, resize_to, resolution_level, num_tokens,
-         threshold, save_maps_, save_ply_, batch):
+         threshold, save_maps_, save_glb_, save_ply_, batch):
     import torch
     from PIL import Image
 
-    from moge_amd.io import masked_point_cloud, save_ply
+    from moge_amd.io import build_mesh_from_map, colorize_depth, colorize_normal, save_exr, save_glb, save_ply, uv_map
     from moge_amd.model import import_model_class_by_version
     from moge_amd.pipeline import InferPipeline
 
@@ -52,8 +54,8 @@ def main(input_path, fov_x_, output_path, pretrained_model_name_or_path, device_
     model = import_model_class_by_version("v2").from_pretrained(pretrained_model_name_or_path).to(torch.device(device_name)).eval()
     if use_fp16:
         model.half()
-    if not (save_maps_ or save_ply_):
-        save_maps_ = save_ply_ = True
+    if not (save_maps_ or save_glb_ or save_ply_):
+        save_maps_ = save_glb_ = save_ply_ = True
 
     def load(path):
         im = Image.open(path).convert("RGB")
@@ -86,7 +88,7 @@ def main(input_path, fov_x_, output_path, pretrained_model_name_or_path, device_
         for ch, out in zip(chunks, pipe.run(gen())):
             imgs = loaded.pop(0)
             cleaned = None
-            if save_ply_:
+            if save_ply_ or save_glb_:
                 cleaned = model.depth_edge_mask(torch.from_numpy(out["depth"]), torch.from_numpy(out["mask"]) if "mask" in out else None,
                                                 rtol=threshold).cpu().numpy()
             for j, p in enumerate(ch):
@@ -94,19 +96,27 @@ def main(input_path, fov_x_, output_path, pretrained_model_name_or_path, device_
                 save_path.mkdir(exist_ok=True, parents=True)
                 if save_maps_:
                     Image.fromarray(imgs[j]).save(save_path / "image.jpg")
-                    np.save(save_path / "depth.npy", out["depth"][j])
-                    np.save(save_path / "points.npy", out["points"][j])
+                    Image.fromarray(colorize_depth(out["depth"][j])).save(save_path / "depth_vis.png")
+                    save_exr(save_path / "depth.exr", out["depth"][j])
+                    save_exr(save_path / "points.exr", out["points"][j])
                     if "mask" in out:
                         Image.fromarray((out["mask"][j] * 255).astype(np.uint8)).save(save_path / "mask.png")
                     if "normal" in out:
-                        Image.fromarray(((out["normal"][j] * [0.5, -0.5, -0.5] + 0.5).clip(0, 1) * 255).astype(np.uint8)).save(save_path / "normal.png")
+                        Image.fromarray(colorize_normal(out["normal"][j])).save(save_path / "normal.png")
                     K = out["intrinsics"][j]
                     with open(save_path / "fov.json", "w") as f:           # normalised intrinsics: fov = 2 atan(0.5 / f)
                         json.dump({"fov_x": round(math.degrees(2 * math.atan(0.5 / float(K[0, 0]))), 2),
                                    "fov_y": round(math.degrees(2 * math.atan(0.5 / float(K[1, 1]))), 2)}, f)
-                if save_ply_:
-                    v, c, n = masked_point_cloud(out["points"][j], cleaned[j], imgs[j], out["normal"][j] if "normal" in out else None)
-                    save_ply(save_path / "pointcloud.ply", v, None, c, n)
+                if save_glb_ or save_ply_:
+                    maps = [out["points"][j], imgs[j].astype(np.float32) / 255, uv_map(h, w)] + ([out["normal"][j]] if "normal" in out else [])
+                    faces, vertices, vertex_colors, vertex_uvs, *rest = build_mesh_from_map(*maps, mask=cleaned[j], tri=True)
+                    # OpenGL conventions for the export (scripts/infer.py:146-151): x right, y up, z backward; (0, 0) = left-bottom of the texture
+                    vertices, vertex_uvs = vertices * [1, -1, -1], vertex_uvs * [1, -1] + [0, 1]
+                    vertex_normals = rest[0] * [1, -1, -1] if rest else None
+                    if save_glb_:
+                        save_glb(save_path / "mesh.glb", vertices, faces, vertex_uvs, imgs[j], vertex_normals)
+                    if save_ply_:
+                        save_ply(save_path / "pointcloud.ply", vertices, np.zeros((0, 3), dtype=np.int32), vertex_colors, vertex_normals)
 
 
 if __name__ == "__main__":

@@ -104,6 +104,12 @@ CASES = [
          kwargs=dict(num_tokens=1369, use_fp16=False)),
     dict(name="tiny_default_tokens_wide", config="tiny-vits-normal", seed=2, sane=True, input_seed=6, shape=[1, 3, 74, 148],
          kwargs=dict(use_fp16=False, resolution_level=0)),
+    # onnx_compatible_mode = True (docs/onnx.md; v2.py:67-74): no antialiasing in the 14x resize, position embedding resampled by size -
+    # on a down-sampling input (where AA matters) and on the native 37x37 grid (where the default mode bypasses the resampling)
+    dict(name="tiny_onnx_mode_down", config="tiny-vits-normal", seed=0, sane=True, input_seed=7, shape=[2, 3, 140, 150], onnx=True,
+         kwargs=dict(num_tokens=56, use_fp16=False)),
+    dict(name="tiny_onnx_mode_native37", config="tiny-vits-normal", seed=0, sane=True, input_seed=8, shape=[1, 3, 80, 80], onnx=True,
+         kwargs=dict(num_tokens=1369, use_fp16=False)),
     dict(name="vits_house518", config="moge-2-vits-normal", seed=0, sane=True, input="house518", shape=[3, 518, 518],
          kwargs=dict(use_fp16=False), stride=7),
     # BASELINE.json configs[1..4] at their own sizes: the image is torch.rand(seed) exactly as the bench draws it; default
@@ -137,6 +143,8 @@ def run_reference(case: dict):
     for k, v in model.state_dict().items():
         assert tuple(v.shape) == tuple(sd[k].shape), (k, v.shape, sd[k].shape)
     x = make_input(case)
+    if case.get("onnx"):
+        model.onnx_compatible_mode = True
     out = model.infer(x, **case["kwargs"])
     fwd = model.forward(x if x.dim() == 4 else x[None], num_tokens=_tokens(cfg, case))
     # The reference's OWN fp16 path on the same input: fp32 weights + use_fp16=True = torch.autocast(float16) (v2.py:241; what
@@ -184,7 +192,7 @@ def main():
         cfg, sd, x, ref, ref_fwd, ref16 = run_reference(case)
         kw = {k: v for k, v in case["kwargs"].items() if k != "use_fp16"}
         tr = {}
-        ora = O.infer(cfg, sd, x, trace=tr, **kw)
+        ora = O.infer(cfg, sd, x, trace=tr, onnx_compatible_mode=bool(case.get("onnx")), **kw)
         line = [case["name"]]
         assert set(ora.keys()) == set(ref.keys()), (ora.keys(), ref.keys())
         for k in ref:

@@ -276,17 +276,21 @@ def _depth_to_points(depth: torch.Tensor, K: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 # encoder
 # --------------------------------------------------------------------------------------------
-def pos_embed_for_grid(pos_embed: torch.Tensor, h0: int, w0: int) -> torch.Tensor:
+def pos_embed_for_grid(pos_embed: torch.Tensor, h0: int, w0: int, onnx_compatible_mode: bool = False) -> torch.Tensor:
     """(1, 1+h0*w0, D) position embedding for an h0 x w0 grid (vision_transformer.py:187-221): bicubic with the
-    scale_factor=(n+0.1)/37 kludge, computed in fp32; returned unchanged iff the grid is the native 37x37."""
+    scale_factor=(n+0.1)/37 kludge, computed in fp32; returned unchanged iff the grid is the native 37x37.
+    onnx_compatible_mode (vision_transformer.py:192,202-210): always resampled, with size=(h0, w0) instead of the scale-factor kludge."""
     n = pos_embed.shape[1] - 1
-    if h0 * w0 == n and h0 == w0:
+    if not onnx_compatible_mode and h0 * w0 == n and h0 == w0:
         return pos_embed
     pe = pos_embed.float()
     M = int(math.sqrt(n))
     D = pe.shape[-1]
     grid = pe[:, 1:].reshape(1, M, M, D).permute(0, 3, 1, 2)
-    grid = F.interpolate(grid, scale_factor=((h0 + 0.1) / M, (w0 + 0.1) / M), mode="bicubic", antialias=False)
+    if onnx_compatible_mode:
+        grid = F.interpolate(grid, size=(h0, w0), mode="bicubic", antialias=False)
+    else:
+        grid = F.interpolate(grid, scale_factor=((h0 + 0.1) / M, (w0 + 0.1) / M), mode="bicubic", antialias=False)
     assert grid.shape[-2:] == (h0, w0)
     grid = grid.permute(0, 2, 3, 1).reshape(1, h0 * w0, D)
     return torch.cat([pe[:, :1], grid], dim=1).to(pos_embed.dtype)
@@ -308,20 +312,22 @@ def vit_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str, heads: int) 
     return x + h * sd[p + "ls2.gamma"]
 
 
-def encoder(cfg: dict, sd: Dict[str, torch.Tensor], image: torch.Tensor, h0: int, w0: int, trace: Optional[dict] = None):
-    """DINOv2Encoder.forward (modules.py:120-136) -> (features (B,c0,h0,w0), cls (B,D))."""
+def encoder(cfg: dict, sd: Dict[str, torch.Tensor], image: torch.Tensor, h0: int, w0: int, trace: Optional[dict] = None,
+            onnx_compatible_mode: bool = False):
+    """DINOv2Encoder.forward (modules.py:120-136) -> (features (B,c0,h0,w0), cls (B,D)).  onnx_compatible_mode: the resize loses its
+    antialiasing (modules.py:121) and the position embedding is resampled by output size (see pos_embed_for_grid)."""
     bb = "encoder.backbone."
     D, L, heads = VIT_SPECS[cfg["encoder"]["backbone"]]
     taps = cfg["encoder"]["intermediate_layers"]
     B = image.shape[0]
-    x = F.interpolate(image, (h0 * PATCH, w0 * PATCH), mode="bilinear", align_corners=False, antialias=True)
+    x = F.interpolate(image, (h0 * PATCH, w0 * PATCH), mode="bilinear", align_corners=False, antialias=not onnx_compatible_mode)
     x = (x - sd["encoder.image_mean"].to(x.dtype)) / sd["encoder.image_std"].to(x.dtype)
     if trace is not None:
         trace["image_14"] = x
     x = F.conv2d(x, sd[bb + "patch_embed.proj.weight"], sd[bb + "patch_embed.proj.bias"], stride=PATCH)
     x = x.flatten(2).transpose(1, 2)
     x = torch.cat([sd[bb + "cls_token"].expand(B, -1, -1), x], dim=1)
-    x = x + pos_embed_for_grid(sd[bb + "pos_embed"], h0, w0)
+    x = x + pos_embed_for_grid(sd[bb + "pos_embed"], h0, w0, onnx_compatible_mode)
     if trace is not None:
         trace["tokens0"] = x
     outs = []
@@ -398,7 +404,7 @@ def remap_points(p: torch.Tensor, mode: str) -> torch.Tensor:
 
 
 def forward(cfg: dict, sd: Dict[str, torch.Tensor], image: torch.Tensor, num_tokens: int,
-            trace: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+            trace: Optional[dict] = None, onnx_compatible_mode: bool = False) -> Dict[str, torch.Tensor]:
     """MoGeModel.forward (v2.py:138-192). image (B,3,H,W) in [0,1], dtype = compute dtype (fp32 / fp64)."""
     B, _, H, W = image.shape
     dt = image.dtype
@@ -406,7 +412,7 @@ def forward(cfg: dict, sd: Dict[str, torch.Tensor], image: torch.Tensor, num_tok
         sd = {k: v.to(dt) for k, v in sd.items()}
     aspect = W / H
     h0, w0 = token_grid(H, W, num_tokens)
-    feats, cls = encoder(cfg, sd, image, h0, w0, trace)
+    feats, cls = encoder(cfg, sd, image, h0, w0, trace, onnx_compatible_mode)
     if trace is not None:
         trace["features"] = feats
         trace["cls"] = cls
@@ -503,7 +509,7 @@ def recover_focal_shift(points: torch.Tensor, mask: Optional[torch.Tensor], foca
 @torch.inference_mode()
 def infer(cfg: dict, sd: Dict[str, torch.Tensor], image: torch.Tensor, num_tokens: Optional[int] = None,
           resolution_level: int = 9, force_projection: bool = True, apply_mask: bool = True,
-          fov_x=None, trace: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+          fov_x=None, trace: Optional[dict] = None, onnx_compatible_mode: bool = False) -> Dict[str, torch.Tensor]:
     """MoGeModel.infer (v2.py:194-303), fp32 path (use_fp16=False)."""
     squeeze = image.dim() == 3
     if squeeze:
@@ -514,7 +520,7 @@ def infer(cfg: dict, sd: Dict[str, torch.Tensor], image: torch.Tensor, num_token
     if num_tokens is None:
         lo, hi = cfg["num_tokens_range"]
         num_tokens = int(lo + (resolution_level / 9) * (hi - lo))
-    out = forward(cfg, sd, image, num_tokens, trace)
+    out = forward(cfg, sd, image, num_tokens, trace, onnx_compatible_mode)
     points, normal, mask, metric = (out.get(k) for k in ("points", "normal", "mask", "metric_scale"))
     if trace is not None:
         trace["forward"] = {k: v.clone() for k, v in out.items()}

@@ -30,6 +30,91 @@ def test_ingest_uint8_is_the_reference_callers_expression():
     assert torch.equal(t, torch.from_numpy((img.astype(np.float64) / 255.0).astype(np.float32)).permute(2, 0, 1))
 
 
+def test_exr_writer_roundtrip_and_header(tmp_path):
+    """depth.exr / points.exr (scripts/infer.py:113,115): uncompressed float32 OpenEXR; +inf (masked pixels) survives; channels Y or R,G,B = x,y,z."""
+    from moge_amd import io as IO
+    rng = np.random.default_rng(0)
+    pts = rng.standard_normal((11, 17, 3)).astype(np.float32)
+    depth = np.abs(pts[..., 2]) + 0.1
+    depth[3, 5] = np.inf
+    IO.save_exr(tmp_path / "d.exr", depth)
+    IO.save_exr(tmp_path / "p.exr", pts)
+    assert np.array_equal(IO.read_exr(tmp_path / "d.exr"), depth)
+    assert np.array_equal(IO.read_exr(tmp_path / "p.exr"), pts)
+    raw = (tmp_path / "p.exr").read_bytes()
+    assert raw[:4] == bytes([0x76, 0x2F, 0x31, 0x01]) and raw[4] == 2                      # magic 20000630, version 2
+    assert raw.index(b"B\x00") < raw.index(b"G\x00") < raw.index(b"R\x00")                # channel list sorted by name
+    assert len(raw) == raw.index(b"screenWindowWidth") + len(b"screenWindowWidth\x00float\x00") + 4 + 4 + 1 + 8 * 11 + 11 * (8 + 3 * 17 * 4)
+
+
+def test_image_mesh_and_glb_container(tmp_path):
+    """scripts/infer.py:127-151: grid mesh over the cleaned mask (one quad per fully valid 2x2 block, two triangles each, unused vertices
+    dropped) and the .glb container: header, JSON chunk, BIN chunk, accessor counts, PBR parameters of moge/utils/io.py:34-36."""
+    import json
+    import struct
+    from moge_amd import io as IO
+    H, W = 6, 8
+    rng = np.random.default_rng(1)
+    pts = rng.standard_normal((H, W, 3)).astype(np.float32)
+    img = (rng.random((H, W, 3)) * 255).astype(np.uint8)
+    nrm = rng.standard_normal((H, W, 3)).astype(np.float32)
+    mask = np.ones((H, W), dtype=bool)
+    mask[2, 3] = False                       # kills the 4 quads around it
+    mask[:, 7] = False                       # last column: kills the quads touching it, its vertices go unused
+    faces, v, c, uv, n = IO.build_mesh_from_map(pts, img.astype(np.float32) / 255, IO.uv_map(H, W), nrm, mask=mask, tri=True)
+    quads = (H - 1) * (W - 2) - 4
+    assert faces.shape == (2 * quads, 3) and faces.dtype == np.int32
+    assert v.shape[0] == c.shape[0] == uv.shape[0] == n.shape[0] == H * (W - 1) - 1 and faces.max() == v.shape[0] - 1
+    # every face's three vertices are pixels of one 2x2 block, inside the mask, and the attribute rows are the pixels' values
+    flat_idx = np.flatnonzero(np.isin(np.arange(H * W), np.flatnonzero(mask.reshape(-1))))
+    assert np.array_equal(v, pts.reshape(-1, 3)[flat_idx]) and np.array_equal(n, nrm.reshape(-1, 3)[flat_idx])
+    ys, xs = np.divmod(flat_idx[faces], W)
+    assert (np.ptp(ys, axis=1) == 1).all() and (np.ptp(xs, axis=1) == 1).all()
+    e1 = np.stack([xs[:, 1] - xs[:, 0], ys[:, 1] - ys[:, 0]], -1)
+    e2 = np.stack([xs[:, 2] - xs[:, 0], ys[:, 2] - ys[:, 0]], -1)
+    assert (np.sign(e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]) == -1).all()            # one consistent winding
+    u0 = IO.uv_map(H, W)
+    assert u0.shape == (H, W, 2) and abs(u0[0, 0, 0] - 0.5 / W) < 1e-7 and abs(u0[-1, -1, 1] - (H - 0.5) / H) < 1e-7
+    # export conventions of the caller, then the container
+    IO.save_glb(tmp_path / "m.glb", v * [1, -1, -1], faces, uv * [1, -1] + [0, 1], img, n * [1, -1, -1])
+    raw = (tmp_path / "m.glb").read_bytes()
+    magic, ver, total = struct.unpack_from("<4sII", raw, 0)
+    assert magic == b"glTF" and ver == 2 and total == len(raw)
+    jl, jt = struct.unpack_from("<I4s", raw, 12)
+    g = json.loads(raw[20:20 + jl])
+    bl, bt = struct.unpack_from("<I4s", raw, 20 + jl)
+    assert jt == b"JSON" and bt == b"BIN\x00" and 20 + jl + 8 + bl == len(raw) and g["buffers"][0]["byteLength"] == bl
+    prim = g["meshes"][0]["primitives"][0]
+    acc = g["accessors"]
+    assert acc[prim["attributes"]["POSITION"]]["count"] == v.shape[0] and acc[prim["indices"]]["count"] == faces.size
+    assert set(prim["attributes"]) == {"POSITION", "NORMAL", "TEXCOORD_0"}
+    pbr = g["materials"][0]["pbrMetallicRoughness"]
+    assert pbr["metallicFactor"] == 0.5 and pbr["roughnessFactor"] == 1.0 and pbr["baseColorTexture"]["index"] == 0
+    binc = raw[20 + jl + 8:]
+    pv = g["bufferViews"][acc[prim["attributes"]["POSITION"]]["bufferView"]]
+    pos = np.frombuffer(binc, dtype="<f4", count=3 * v.shape[0], offset=pv["byteOffset"]).reshape(-1, 3)
+    assert np.allclose(pos, v * [1, -1, -1])
+    tv = g["bufferViews"][acc[prim["attributes"]["TEXCOORD_0"]]["bufferView"]]
+    tex = np.frombuffer(binc, dtype="<f4", count=2 * v.shape[0], offset=tv["byteOffset"]).reshape(-1, 2)
+    assert np.allclose(tex, uv, atol=1e-6)                    # glTF's own v axis points down: the OpenGL flip is undone inside the file
+    iv = g["bufferViews"][g["images"][0]["bufferView"]]
+    from PIL import Image
+    import io as _io
+    assert np.array_equal(np.asarray(Image.open(_io.BytesIO(binc[iv["byteOffset"]:iv["byteOffset"] + iv["byteLength"]]))), img)
+
+
+def test_colorize_helpers():
+    from moge_amd import io as IO
+    d = np.linspace(0.5, 5.0, 200, dtype=np.float32).reshape(10, 20)
+    d[0, 0] = np.inf
+    col = IO.colorize_depth(d)
+    assert col.shape == (10, 20, 3) and col.dtype == np.uint8 and (col[0, 0] == 0).all()
+    near, far = col[0, 1].astype(int), col[-1, -1].astype(int)
+    assert near[0] > near[2] and far[2] > far[0]                 # Spectral over 1 - disparity: near = red end, far = blue end
+    n = np.zeros((2, 2, 3), dtype=np.float32); n[..., 2] = 1.0
+    assert (IO.colorize_normal(n)[0, 0] == [127, 127, 0]).all()
+
+
 def test_save_ply_layout_roundtrip(tmp_path):
     from moge_amd.io import masked_point_cloud, save_ply
     rng = np.random.default_rng(1)

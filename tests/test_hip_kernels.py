@@ -163,3 +163,27 @@ def test_recover_fallback_and_nonfinite(H):
     pts[0, :, :, 2] = 0.0                # z + 0 == 0 -> inf residuals at x0 -> scipy raises ValueError
     f, s, status = H.recover(pts, torch.ones(2, 70, 70, dtype=torch.bool))
     assert status == -5
+
+
+def test_onnx_mode_forward_matches_oracle_raw_outputs(H):
+    """docs/onnx.md: the exported graph is the raw forward() (points, normal, mask probability, metric scale) in onnx_compatible_mode."""
+    import os
+    import tempfile
+    from moge_amd.model import import_model_class_by_version
+    from oracle import moge_oracle as O
+    cfg = O.named_configs()["tiny-vits-normal"]
+    sd = O.synth_state_dict(cfg, 0, True)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "m.pt")
+        O.save_checkpoint(path, cfg, sd)
+        model = import_model_class_by_version("v2").from_pretrained(path).to("cuda").eval()
+    model.onnx_compatible_mode = True
+    assert model.onnx_compatible_mode is True
+    x = torch.rand(2, 3, 140, 150, generator=torch.Generator().manual_seed(31))
+    for tokens in (56, 1369):                                  # down-sampling grid; the native 37x37 grid (not bypassed in this mode)
+        fwd = model.forward(x, tokens)
+        ref = O.forward(cfg, sd, x, tokens, onnx_compatible_mode=True)
+        off = O.forward(cfg, sd, x, tokens)
+        for k in ref:
+            assert relmax(fwd[k], ref[k]) < 5e-4, (tokens, k, relmax(fwd[k], ref[k]))
+        assert relmax(off["points"], ref["points"]) > 1e-3, "the flag must change the result (AA off / pos-embed by size)"

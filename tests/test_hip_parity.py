@@ -58,7 +58,11 @@ def test_fp32_mode_matches_reference_golden_and_oracle(MoGeModel, name, tmp_path
     case, cfg, sd, x, gold, meta = load_case(name)
     model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory)
     kw = dict(case["kwargs"]); kw["use_fp16"] = False
-    out = model.float().infer(x, **kw)
+    model.onnx_compatible_mode = bool(case.get("onnx"))        # docs/onnx.md: fixtures "tiny_onnx_mode_*" were made with the flag set
+    try:
+        out = model.float().infer(x, **kw)
+    finally:
+        model.onnx_compatible_mode = False
     ill = not case["sane"]
     st = case.get("stride", 1)
     # (1) committed golden vectors of the real reference
@@ -66,7 +70,7 @@ def test_fp32_mode_matches_reference_golden_and_oracle(MoGeModel, name, tmp_path
     print(f"[parity fp32] {name}: " + " ".join(f"{k}={v:.1e}" for k, v in seen.items()))
     # (2) the oracle, live, full resolution (bit-identical to the reference on these cases; the big ones take the GPU box's CPU too long)
     if name not in SLOW_CASES:
-        ref = O.infer(cfg, sd, x, **{k: v for k, v in kw.items() if k != "use_fp16"})
+        ref = O.infer(cfg, sd, x, onnx_compatible_mode=bool(case.get("onnx")), **{k: v for k, v in kw.items() if k != "use_fp16"})
         check_fp32(out, ref, ill=ill)
 
 
@@ -84,11 +88,13 @@ def test_fp16_mode_within_reference_fp16_band(MoGeModel, name, tmp_path_factory)
     st = case.get("stride", 1)
     band = fp16_band(meta)
     g = golden_infer(gold)
+    model.onnx_compatible_mode = bool(case.get("onnx"))
     try:
         out = model.float().infer(x, **kw)             # fp32 weights + use_fp16 (autocast analogue)
         out_h = model.half().infer(x, **kw)            # .half() weights
     finally:
         model.float()
+        model.onnx_compatible_mode = False
     for tag, o in (("autocast", out), ("half", out_h)):
         seen = check_fp16(sub(o, st), g, band)
         print(f"[parity fp16 {tag}] {name}: " + " ".join(f"{k}={v:.1e}/{band.get(k, 0):.1e}" for k, v in seen.items()))
