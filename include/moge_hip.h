@@ -66,6 +66,22 @@ typedef struct moge_config {
     int32_t remap_output;              /* moge_remap                                v2.py:122-136                  */
 } moge_config;
 
+/* Mirrors the `model_config` of a MoGe-1 checkpoint (moge/model/v1.py:148-163).  Supported layout = the released one:
+ * group_norm residual blocks, dim_times_res_block_hidden 1, last_res_blocks 0, last_conv_size 1, head outputs [3 (points), 1 (mask)]. */
+#define MOGE_V1_MAX_UP 4
+typedef struct moge_v1_config {
+    int32_t embed_dim, depth, num_heads;      /* ViT (head_dim 64)                                                          */
+    int32_t n_taps;                           /* number of tapped blocks                                                    */
+    int32_t taps[MOGE_MAX_TAPS];              /* their indices (an int `intermediate_layers` n = the LAST n blocks)         */
+    int32_t dim_proj;                         /* Head.projects output channels                          v1.py:79-81         */
+    int32_t n_up;                             /* len(dim_upsample)                                                          */
+    int32_t dim_upsample[MOGE_V1_MAX_UP];     /* channels after each [ConvTranspose2d k2 s2, 3x3, res blocks] stage         */
+    int32_t num_res_blocks;                   /* ResidualConvBlocks per stage                           v1.py:86            */
+    int32_t last_conv_channels;               /* hidden width of the output blocks                      v1.py:105-110       */
+    int32_t remap_output;                     /* moge_remap                                             v1.py:253-267       */
+    float mask_threshold;                     /* validity = raw mask output > mask_threshold            v1.py:358           */
+} moge_v1_config;
+
 /* One state-dict entry handed to moge_load_weights: fp32, contiguous, host memory. */
 typedef struct moge_tensor_desc {
     const char* name;                  /* reference state-dict key, e.g. "encoder.backbone.blocks.0.attn.qkv.weight" */
@@ -111,6 +127,10 @@ const char* moge_last_error(void);
 int moge_create(const moge_config* cfg, int device, moge_handle** out);
 void moge_destroy(moge_handle* h);
 
+/* replaces moge.model.v1.MoGeModel.__init__ (v1.py:148-205).  The returned handle takes the same moge_load_weights / master-blob /
+ * moge_set_precision / moge_sync / profiler calls as a MoGe-2 handle (state-dict keys: "backbone.*", "head.*", "image_mean", "image_std"). */
+int moge_create_v1(const moge_v1_config* cfg, int device, moge_handle** out);
+
 /* replaces nn.Module.load_state_dict (v2.py:105): upload the fp32 master copy of every tensor the config
  * needs.  Unknown names are ignored (strict=False); a missing required tensor -> MOGE_ERR_MISSING_KEY. */
 int moge_load_weights(moge_handle* h, const moge_tensor_desc* descs, int n, void* stream);
@@ -149,6 +169,16 @@ int moge_forward(moge_handle* h, const void* image, int img_dtype, int B, int H,
  * metric scale + masking.  fov_x_deg: NULL, or device pointer to B floats (degrees). */
 int moge_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int token_rows, int token_cols,
                const float* fov_x_deg, int flags, const moge_outputs* out, void* stream);
+
+/* replace moge.model.v1.MoGeModel.forward (v1.py:269-300) and .infer (v1.py:302-391) on a handle made by moge_create_v1.  The host passes
+ * (resized_h, resized_w) = the size v1.py:272-274 computes from num_tokens (Python float arithmetic + int() truncation), the library does the
+ * bicubic antialiased resize, normalisation, bilinear antialiased resize to multiples of 14, the ViT, the head, the resize back and the
+ * remap.  forward writes points (B,H,W,3) and mask_prob (B,H,W) = the RAW mask output (no activation in MoGe-1); infer additionally writes
+ * depth, the validity mask (raw > mask_threshold; no depth > 0 term in v1), intrinsics.  normal / metric_scale do not exist in MoGe-1. */
+int moge_v1_forward(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int resized_h, int resized_w,
+                    const moge_outputs* out, void* stream);
+int moge_v1_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int resized_h, int resized_w,
+                  const float* fov_x_deg, int flags, const moge_outputs* out, void* stream);
 
 /* replaces the post-processing half of infer (v2.py:246-289) on caller-supplied forward outputs: used to
  * test the recovery path in isolation.  points/normal/mask_prob are read; all outputs written. */
@@ -219,6 +249,10 @@ int moge_test_convt2x2(int precision, const float* x, const float* w, const floa
                        int Cin, int Cout, void* stream);
 /* image (B,3,H,W) fp32 -> antialiased bilinear resize to (14*rows,14*cols), normalised, NCHW fp32 */
 int moge_test_preprocess(const float* image, float* out, int B, int H, int W, int rows, int cols, void* stream);
+/* MoGe-1 kernels: image (B,3,H,W) fp32 -> bicubic antialiased resize (OH,OW), NCHW fp32 (v1.py:275) */
+int moge_test_resize_bicubic_aa(const float* image, float* out, int B, int H, int W, int OH, int OW, void* stream);
+/* relu(GroupNorm(groups, C)(x)), eps 1e-5, NHWC x (B,H,W,C) fp32 in / out, computed in `precision` (v1.py:44-49) */
+int moge_test_groupnorm_relu(int precision, const float* x, const float* gamma, const float* beta, float* y, int B, int H, int W, int C, int groups, void* stream);
 /* pos_embed (1+37*37, D) -> (1+rows*cols, D) bicubic with the +0.1 kludge */
 int moge_test_posembed(const float* pos, float* out, int D, int rows, int cols, void* stream);
 /* focal/shift solve on (B,H,W,3) points + (B,H,W) 0/1 mask; focal_in NULL or (B,) */

@@ -28,6 +28,15 @@ class MogeConfig(C.Structure):
                 ("heads", C.c_int32), ("scale_hidden", C.c_int32), ("remap_output", C.c_int32)]
 
 
+MOGE_V1_MAX_UP = 4
+
+
+class MogeV1Config(C.Structure):
+    _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32), ("n_taps", C.c_int32),
+                ("taps", C.c_int32 * MOGE_MAX_TAPS), ("dim_proj", C.c_int32), ("n_up", C.c_int32), ("dim_upsample", C.c_int32 * MOGE_V1_MAX_UP),
+                ("num_res_blocks", C.c_int32), ("last_conv_channels", C.c_int32), ("remap_output", C.c_int32), ("mask_threshold", C.c_float)]
+
+
 class TensorDesc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
 
@@ -66,6 +75,9 @@ def _load() -> C.CDLL:
         "moge_abi_version": (C.c_int, []),
         "moge_last_error": (C.c_char_p, []),
         "moge_create": (C.c_int, [C.POINTER(MogeConfig), i32, C.POINTER(vp)]),
+        "moge_create_v1": (C.c_int, [C.POINTER(MogeV1Config), i32, C.POINTER(vp)]),
+        "moge_v1_forward": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(Outputs), vp]),
+        "moge_v1_infer": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, C.POINTER(Outputs), vp]),
         "moge_destroy": (None, [vp]),
         "moge_load_weights": (C.c_int, [vp, C.POINTER(TensorDesc), i32, vp]),
         "moge_alloc_master": (C.c_int, [vp]),
@@ -90,6 +102,8 @@ def _load() -> C.CDLL:
         "moge_test_conv3x3": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, vp]),
         "moge_test_convt2x2": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, vp]),
         "moge_test_preprocess": (C.c_int, [f32p, f32p, i32, i32, i32, i32, i32, vp]),
+        "moge_test_resize_bicubic_aa": (C.c_int, [f32p, f32p, i32, i32, i32, i32, i32, vp]),
+        "moge_test_groupnorm_relu": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, vp]),
         "moge_test_posembed": (C.c_int, [f32p, f32p, i32, i32, i32, vp]),
         "moge_test_recover": (C.c_int, [f32p, vp, f32p, i32, i32, i32, f32p, f32p, vp, vp]),
     }
@@ -103,11 +117,11 @@ def _load() -> C.CDLL:
 
 
 lib = _load()
-EXPORTS = ["moge_abi_version", "moge_last_error", "moge_create", "moge_destroy", "moge_load_weights", "moge_alloc_master",
+EXPORTS = ["moge_abi_version", "moge_last_error", "moge_create", "moge_create_v1", "moge_v1_forward", "moge_v1_infer", "moge_destroy", "moge_load_weights", "moge_alloc_master",
            "moge_master_blob", "moge_master_ready", "moge_set_precision", "moge_set_onnx_compatible_mode", "moge_workspace_bytes", "moge_forward", "moge_infer",
            "moge_postprocess", "moge_depth_edge_mask", "moge_sync", "moge_profile_enable", "moge_profile_read", "moge_debug_tap", "moge_tune_set", "moge_test_gemm",
            "moge_test_gemm_ex", "moge_test_layernorm", "moge_test_attention", "moge_test_conv3x3", "moge_test_convt2x2", "moge_test_preprocess",
-           "moge_test_posembed", "moge_test_recover"]
+           "moge_test_resize_bicubic_aa", "moge_test_groupnorm_relu", "moge_test_posembed", "moge_test_recover"]
 
 
 def check(code: int) -> None:

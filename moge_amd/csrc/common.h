@@ -215,6 +215,8 @@ struct GemmArgs {
     float* ln_part;
     const float* ln_mr;
     const float* ln_c;
+    int uv_in;             // EPI_CONVT + uv: the term is evaluated at the INPUT pixel m with wu / wv indexed by the GEMM column n (MoGe-1: the uv
+                           // channels are inputs of the ConvTranspose2d, v1.py:118-121); 0: at the output pixel, indexed by output channel (MoGe-2 resampler)
     int nt_store;          // gemm_pp: non-temporal stores for the f16 output rows (streaming activations; keeps the residual in the Infinity Cache)
     unsigned long long* dbg_ts;   // gemm_pp128: optional s_memtime stamps of one block (tools/kbench)
     int stagger;           // gemm_pp128: number of start-phase classes (0/1 = off)

@@ -501,3 +501,249 @@ int launch_pack_phase_conv(const float* w, void* dst, int Cout, int Cin, hipStre
 }
 template int launch_pack_phase_conv<f16>(const float*, void*, int, int, hipStream_t);
 template int launch_pack_phase_conv<float>(const float*, void*, int, int, hipStream_t);
+
+// ============================================================================================================================
+// MoGe-1 (moge/model/v1.py) support kernels
+// ============================================================================================================================
+// v1.py:275: F.interpolate(image, (rh, rw), mode="bicubic", align_corners=False, antialias=True) - ATen _upsample_bicubic2d_aa: cubic
+// convolution filter with a = -0.5, support 2 * max(scale, 1), weights normalised per output pixel; horizontal pass, then vertical (same
+// index / weight formulas as aa_range above with the wider support).  NCHW in (TIn) -> NCHW fp32 out.
+__device__ __forceinline__ float cubic_aa(float x) {
+    constexpr float a = -0.5f;
+    x = fabsf(x);
+    if (x < 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
+    if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * a;
+    return 0.f;
+}
+__device__ __forceinline__ void aa_range_cubic(int o, float scale, int in_size, int& lo, int& n, float& center, float& invscale) {
+    const float support = scale >= 1.f ? 2.f * scale : 2.f;
+    invscale = scale >= 1.f ? 1.f / scale : 1.f;
+    center = scale * (o + 0.5f);
+    lo = (int)(center - support + 0.5f);
+    lo = lo < 0 ? 0 : lo;
+    int hi = (int)(center + support + 0.5f);
+    hi = hi > in_size ? in_size : hi;
+    n = hi - lo;
+}
+template <typename TIn>
+__global__ void resize_bicubic_aa_kernel(const TIn* __restrict__ img, float* __restrict__ out, int B, int H, int W, int OH, int OW, int round16) {
+    const long total = (long)B * OH * OW;
+    const float scale_y = (float)H / (float)OH, scale_x = (float)W / (float)OW;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ox = idx % OW;
+        long t = idx / OW;
+        const int oy = t % OH;
+        const int b = t / OH;
+        int ylo, yn, xlo, xn; float yc, yis, xc, xis;
+        aa_range_cubic(oy, scale_y, H, ylo, yn, yc, yis);
+        aa_range_cubic(ox, scale_x, W, xlo, xn, xc, xis);
+        float wysum = 0.f, wxsum = 0.f;
+        for (int j = 0; j < yn; j++) wysum += cubic_aa((j + ylo - yc + 0.5f) * yis);
+        for (int i = 0; i < xn; i++) wxsum += cubic_aa((i + xlo - xc + 0.5f) * xis);
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int j = 0; j < yn; j++) {
+            const float wy = cubic_aa((j + ylo - yc + 0.5f) * yis) / wysum;
+            float h[3] = {0.f, 0.f, 0.f};
+            for (int i = 0; i < xn; i++) {
+                const float wx = cubic_aa((i + xlo - xc + 0.5f) * xis) / wxsum;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    float pv = (float)img[(((size_t)b * 3 + c) * H + (ylo + j)) * W + xlo + i];
+                    if (round16) pv = (float)(f16)pv;
+                    h[c] += wx * pv;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc[c] += wy * h[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) out[(((size_t)b * 3 + c) * OH + oy) * OW + ox] = round16 ? (float)(f16)acc[c] : acc[c];
+    }
+}
+template <typename TIn>
+int launch_resize_bicubic_aa(const void* img, float* out, int B, int H, int W, int OH, int OW, int round16, hipStream_t st) {
+    const long total = (long)B * OH * OW;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((resize_bicubic_aa_kernel<TIn>), dim3(blocks), dim3(256), 0, st, (const TIn*)img, out, B, H, W, OH, OW, round16);
+    return (int)hipGetLastError();
+}
+template int launch_resize_bicubic_aa<float>(const void*, float*, int, int, int, int, int, int, hipStream_t);
+template int launch_resize_bicubic_aa<f16>(const void*, float*, int, int, int, int, int, int, hipStream_t);
+
+// GroupNorm (v1.py:44,47: nn.GroupNorm(G, C), eps 1e-5) on an NHWC map, fused with the ReLU that follows it.  Three deterministic steps:
+//   gn_partial: every block reduces a fixed slab of pixels to per-group (sum, sum of squares) in fp32 -> part[b][blk][G][2]
+//   gn_finalize: one thread per (b, group) adds the slabs in order in fp64 -> (mean, rstd)
+//   gn_apply: y = relu((x - mean) * rstd * gamma[c] + beta[c])
+// C % CH == 0 and C / CH divides 256 (C in {32, 64, 128, 256} for the released models).
+constexpr int GN_PIX_PER_BLOCK = 2048;
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, float* __restrict__ part, int HW, int C, int G, int nblk) {
+    constexpr int CH = TT<T>::CH;
+    const int cpr = C / CH;                         // 16-byte chunks per pixel
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr, ppb = 256 / cpr;
+    const int cg = C / G;                           // channels per group
+    const long p0 = (long)blk * GN_PIX_PER_BLOCK;
+    const long p1 = p0 + GN_PIX_PER_BLOCK < HW ? p0 + GN_PIX_PER_BLOCK : HW;
+    float s1 = 0.f, s2 = 0.f;
+    const T* base = x + (size_t)b * HW * C + chunk * CH;
+    for (long p = p0 + prow; p < p1; p += ppb) {
+        float v[CH];
+        if constexpr (CH == 8) {
+            const f16x8 h = *reinterpret_cast<const f16x8*>(base + (size_t)p * C);
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (float)h[i];
+        } else {
+            const f32x4 h = *reinterpret_cast<const f32x4*>(base + (size_t)p * C);
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = h[i];
+        }
+#pragma unroll
+        for (int i = 0; i < CH; i++) { s1 += v[i]; s2 = fmaf(v[i], v[i], s2); }
+    }
+    __shared__ float sh1[256], sh2[256];
+    sh1[threadIdx.x] = s1; sh2[threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < G) {                          // fixed-order sum of this group's threads (a chunk never straddles groups: cg % CH == 0)
+        const int g = threadIdx.x;
+        double a1 = 0.0, a2 = 0.0;
+        for (int t = 0; t < 256; t++) {
+            const int c0 = (t % cpr) * CH;
+            if (c0 / cg == g) { a1 += sh1[t]; a2 += sh2[t]; }
+        }
+        float* o = part + (((size_t)b * nblk + blk) * G + g) * 2;
+        o[0] = (float)a1; o[1] = (float)a2;
+    }
+}
+__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ mr, int B, int G, int nblk, double count, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i - b * G;
+    double a1 = 0.0, a2 = 0.0;
+    for (int k = 0; k < nblk; k++) {
+        const float* p = part + (((size_t)b * nblk + k) * G + g) * 2;
+        a1 += p[0]; a2 += p[1];
+    }
+    const double mean = a1 / count;
+    double var = a2 / count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    mr[2 * i] = (float)mean;
+    mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_relu_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ mr,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, long HW, int C, int G, long total_chunks) {
+    constexpr int CH = TT<T>::CH;
+    const int cpr = C / CH, cg = C / G;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total_chunks; idx += (long)gridDim.x * 256) {
+        const int chunk = idx % cpr;
+        const long pix = idx / cpr;
+        const int b = pix / HW;
+        const int c0 = chunk * CH, g = c0 / cg;
+        const float mean = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
+        float v[CH];
+        if constexpr (CH == 8) {
+            const f16x8 h = *reinterpret_cast<const f16x8*>(x + idx * CH);
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (float)h[i];
+        } else {
+            const f32x4 h = *reinterpret_cast<const f32x4*>(x + idx * CH);
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = h[i];
+        }
+#pragma unroll
+        for (int i = 0; i < CH; i++) v[i] = fmaxf((v[i] - mean) * rstd * gamma[c0 + i] + beta[c0 + i], 0.f);
+        if constexpr (CH == 8) {
+            f16x8 h;
+#pragma unroll
+            for (int i = 0; i < 8; i++) h[i] = (f16)v[i];
+            *reinterpret_cast<f16x8*>(y + idx * CH) = h;
+        } else {
+            *reinterpret_cast<f32x4*>(y + idx * CH) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+// scratch: part (B * nblk * G * 2 floats) followed by mr (B * G * 2 floats); returns the float count needed when x == nullptr
+template <typename T>
+int launch_groupnorm_relu(const void* x, void* y, const float* gamma, const float* beta, float* scratch, int B, int H, int W, int C, int G, hipStream_t st) {
+    constexpr int CH = TT<T>::CH;
+    if (C % G || (C / G) % CH || C % CH || 256 % (C / CH) || G > 64) return -1;
+    const long HW = (long)H * W;
+    const int nblk = (int)((HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK);
+    float* part = scratch;
+    float* mr = scratch + (size_t)B * nblk * G * 2;
+    hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, part, (int)HW, C, G, nblk);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 63) / 64), dim3(64), 0, st, part, mr, B, G, nblk, (double)HW * (C / G), 1e-5f);
+    const long chunks = (long)B * HW * (C / CH);
+    int blocks = (int)((chunks + 255) / 256);
+    if (blocks > 32768) blocks = 32768;
+    hipLaunchKernelGGL((gn_apply_relu_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)y, mr, gamma, beta, HW, C, G, chunks);
+    return (int)hipGetLastError();
+}
+size_t groupnorm_scratch_floats(int B, int H, int W, int G) {
+    const long HW = (long)H * W;
+    const int nblk = (int)((HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK);
+    return (size_t)B * nblk * G * 2 + (size_t)B * G * 2;
+}
+template int launch_groupnorm_relu<f16>(const void*, void*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+template int launch_groupnorm_relu<float>(const void*, void*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+
+// v1.py:127-130: bilinear (align_corners=False, no antialias) resize of the NHWC feature map (B, hs, ws, C) to (B, OH, OW, .) with the view-plane
+// uv of the OUTPUT grid appended as channels C, C+1 (aspect = OW / OH) and zeros up to the padded pitch Cp (a multiple of 8: the 3x3 conv
+// that follows reads 16-byte chunks)
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bilinear_uv_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int hs, int ws, int C, int OH, int OW, int Cp,
+                                                                 float u0, float u1, float ustep, float v0, float v1, float vstep) {
+    constexpr int CH = TT<T>::CH;
+    const int cpr = Cp / CH;
+    const long total = (long)B * OH * OW * cpr;
+    const float sy_scale = (float)hs / (float)OH, sx_scale = (float)ws / (float)OW;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int chunk = idx % cpr;
+        long t = idx / cpr;
+        const int ox = t % OW; t /= OW;
+        const int oy = t % OH;
+        const int b = t / OH;
+        const int c0 = chunk * CH;
+        float v[CH];
+#pragma unroll
+        for (int i = 0; i < CH; i++) v[i] = 0.f;
+        if (c0 < C) {
+            float sy = sy_scale * (oy + 0.5f) - 0.5f, sx = sx_scale * (ox + 0.5f) - 0.5f;
+            sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx;
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < hs - 1 ? 1 : 0), x1 = x0 + (x0 < ws - 1 ? 1 : 0);
+            const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+            const T* base = x + (size_t)b * hs * ws * C + c0;
+            float a[CH], bq[CH], cq[CH], dq[CH];
+            load4(base + ((size_t)y0 * ws + x0) * C, a); load4(base + ((size_t)y0 * ws + x1) * C, bq);
+            load4(base + ((size_t)y1 * ws + x0) * C, cq); load4(base + ((size_t)y1 * ws + x1) * C, dq);
+            if constexpr (CH == 8) {
+                load4(base + ((size_t)y0 * ws + x0) * C + 4, a + 4); load4(base + ((size_t)y0 * ws + x1) * C + 4, bq + 4);
+                load4(base + ((size_t)y1 * ws + x0) * C + 4, cq + 4); load4(base + ((size_t)y1 * ws + x1) * C + 4, dq + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < CH; i++) v[i] = ly0 * (lx0 * a[i] + lx1 * bq[i]) + ly1 * (lx0 * cq[i] + lx1 * dq[i]);
+        }
+        if (c0 <= C && C < c0 + CH) {                 // the chunk that holds channels C, C + 1 (C % CH == 0: they start the chunk)
+            v[C - c0] = linspace_at(u0, u1, ustep, OW, ox);
+            v[C - c0 + 1] = linspace_at(v0, v1, vstep, OH, oy);
+        }
+        T* o = out + (((size_t)b * OH + oy) * OW + ox) * Cp + c0;
+        store4(o, v[0], v[1], v[2], v[3]);
+        if constexpr (CH == 8) store4(o + 4, v[4], v[5], v[6], v[7]);
+    }
+}
+template <typename T>
+int launch_resize_bilinear_uv(const void* x, void* out, int B, int hs, int ws, int C, int OH, int OW, int Cp, float u0, float u1, float v0, float v1, hipStream_t st) {
+    if (C % TT<T>::CH || Cp % TT<T>::CH || Cp < C + 2) return -1;
+    const long total = (long)B * OH * OW * (Cp / TT<T>::CH);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65536) blocks = 65536;
+    const float ustep = OW > 1 ? (u1 - u0) / (float)(OW - 1) : 0.f, vstep = OH > 1 ? (v1 - v0) / (float)(OH - 1) : 0.f;
+    hipLaunchKernelGGL((resize_bilinear_uv_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)out, B, hs, ws, C, OH, OW, Cp, u0, u1, ustep, v0, v1, vstep);
+    return (int)hipGetLastError();
+}
+template int launch_resize_bilinear_uv<f16>(const void*, void*, int, int, int, int, int, int, int, float, float, float, float, hipStream_t);
+template int launch_resize_bilinear_uv<float>(const void*, void*, int, int, int, int, int, int, int, float, float, float, float, hipStream_t);

@@ -107,7 +107,14 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float
         const int x = m % g.pixW;
         const int t = m / g.pixW;
         const int y = t % g.pixH, b = t / g.pixH;
-        if (g.uv.wu) {          // uv term evaluated at the HIGH-res pixel (2y+dy, 2x+dx); wu/wv indexed by output channel
+        if (g.uv.wu && g.uv_in) {          // uv channels of the ConvTranspose2d INPUT: low-res pixel (y, x), weights per column n = (dy, dx, co)
+            const float u = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, g.pixW, x);
+            const float vv = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, g.pixH, y);
+            const f32x4 wu = *reinterpret_cast<const f32x4*>(g.uv.wu + n);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(g.uv.wv + n);
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] += wu[i] * u + wv[i] * vv;
+        } else if (g.uv.wu) {          // uv term evaluated at the HIGH-res pixel (2y+dy, 2x+dx); wu/wv indexed by output channel
             const float u = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, 2 * g.pixW, 2 * x + dx);
             const float vv = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, 2 * g.pixH, 2 * y + dy);
             const f32x4 wu = *reinterpret_cast<const f32x4*>(g.uv.wu + co);

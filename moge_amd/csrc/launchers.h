@@ -31,10 +31,18 @@ template <typename T> int launch_pack_phase_conv(const float* w, void* dst, int 
 
 template <typename T>
 int launch_head_final(int kind, const void* x4, const float* w, const float* bias, const void* n4, const float* w2, float* out, int B, int Hd,
-                      int Wd, int C, int H, int W, int remap, hipStream_t st);
+                      int Wd, int C, int H, int W, int remap, hipStream_t st, int ld = 0);      // ld: channel pitch of x4 / n4 (0 = C)
 int launch_mlp_layer(const float* in, const float* W, const float* bias, float* out, int B, int K, int N, int act, hipStream_t st);
 int launch_recover(const float* points, const float* mask_prob, const uint8_t* mask_u8, const float* fov_deg, const float* focal_in, int B,
-                   int H, int W, float* focal, float* shift, float* intrinsics, int* status, hipStream_t st);
+                   int H, int W, float* focal, float* shift, float* intrinsics, int* status, hipStream_t st, float mask_thr = 0.5f);
 int launch_finalize(const float* points_in, const float* normal_in, const float* mask_prob, const float* metric, const float* shift,
                     const float* intr, int B, int H, int W, int flags, float* points_out, float* depth_out, float* normal_out,
-                    uint8_t* mask_out, hipStream_t st);
+                    uint8_t* mask_out, hipStream_t st, float mask_thr = 0.5f);
+
+// ---- MoGe-1 (moge/model/v1.py) support kernels (elementwise.hip) ----
+template <typename TIn> int launch_resize_bicubic_aa(const void* img, float* out, int B, int H, int W, int OH, int OW, int round16, hipStream_t st);
+template <typename T>
+int launch_groupnorm_relu(const void* x, void* y, const float* gamma, const float* beta, float* scratch, int B, int H, int W, int C, int G, hipStream_t st);
+size_t groupnorm_scratch_floats(int B, int H, int W, int G);
+template <typename T>
+int launch_resize_bilinear_uv(const void* x, void* out, int B, int hs, int ws, int C, int OH, int OW, int Cp, float u0, float u1, float v0, float v1, hipStream_t st);

@@ -43,7 +43,13 @@ struct TInfo { size_t off; int64_t numel; bool loaded; };
 struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; };
 
 struct moge_handle {
-    moge_config cfg;
+    moge_config cfg;            // MoGe-2 config; for a MoGe-1 handle only the ViT fields (embed_dim, depth, num_heads, n_taps, taps) and dims[0] (= dim_proj) are used
+    float mask_thr = 0.5f;      // validity threshold on the mask output (v2: sigmoid probability > 0.5, v2.py:249; v1: raw > mask_threshold, v1.py:358)
+    int version = 2;            // 1: moge.model.v1.MoGeModel (cfg1), 2: moge.model.v2.MoGeModel
+    moge_v1_config cfg1;
+    std::string bb = "encoder.backbone.";                        // state-dict prefix of the ViT
+    const char* proj_fmt = "encoder.output_projections.%d";      // 1x1 projections of the taps (v1: "head.projects.%d")
+    std::string mean_key = "encoder.image_mean", std_key = "encoder.image_std";
     int device;
     // fp32 master copy of the checkpoint (layout = f(config))
     std::map<std::string, TInfo> table;
@@ -112,10 +118,12 @@ static std::string S(const char* fmt, ...) {
     return buf;
 }
 
+static void build_tables_v2_decoder(moge_handle* h);
+static void build_tables_v1_decoder(moge_handle* h);
 static void build_tables(moge_handle* h) {
     const moge_config& c = h->cfg;
     const int D = c.embed_dim, c0 = c.dims[0];
-    const std::string bb = "encoder.backbone.";
+    const std::string bb = h->bb;
     tadd(h, bb + "cls_token", D);
     tadd(h, bb + "pos_embed", (int64_t)(1 + 37 * 37) * D);
     tadd(h, bb + "patch_embed.proj.weight", (int64_t)D * KPATCH);
@@ -143,14 +151,20 @@ static void build_tables(moge_handle* h) {
     }
     tadd(h, bb + "norm.weight", D); tadd(h, bb + "norm.bias", D);
     for (int k = 0; k < c.n_taps; k++) {
-        tadd(h, S("encoder.output_projections.%d.weight", k), (int64_t)c0 * D);
-        tadd(h, S("encoder.output_projections.%d.bias", k), c0);
+        tadd(h, S(h->proj_fmt, k) + ".weight", (int64_t)c0 * D);
+        tadd(h, S(h->proj_fmt, k) + ".bias", c0);
     }
-    tadd(h, "encoder.image_mean", 3);
-    tadd(h, "encoder.image_std", 3);
+    tadd(h, h->mean_key, 3);
+    tadd(h, h->std_key, 3);
     padd(h, "outproj.w", (int64_t)c0 * c.n_taps * D);
     aadd(h, "outproj.bias", c0);
+    if (h->version == 1) build_tables_v1_decoder(h);
+    else build_tables_v2_decoder(h);
+}
 
+static void build_tables_v2_decoder(moge_handle* h) {
+    const moge_config& c = h->cfg;
+    const int D = c.embed_dim, c0 = c.dims[0];
     auto stack = [&](const std::string& name, bool neck, const int* nres, int cout) {
         for (int l = 0; l < MOGE_LEVELS; l++) {
             const int cl = c.dims[l];
@@ -219,6 +233,7 @@ template <typename T> static T* Pm(moge_handle* h, const std::string& name) { re
 // ------------------------------------------------------------------------------------------------------------
 // packing (device side, from the fp32 master)
 // ------------------------------------------------------------------------------------------------------------
+static int build_aux_v1(moge_handle* h, hipStream_t st);
 static int build_aux(moge_handle* h, hipStream_t st) {
     if (h->aux_ready) return 0;
     const moge_config& c = h->cfg;
@@ -229,13 +244,14 @@ static int build_aux(moge_handle* h, hipStream_t st) {
     {
         std::vector<float> acc(c0, 0.f), tmp(c0);
         for (int k = 0; k < c.n_taps; k++) {
-            HIPCHK(hipMemcpyAsync(tmp.data(), M(h, S("encoder.output_projections.%d.bias", k)), c0 * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(tmp.data(), M(h, S(h->proj_fmt, k) + ".bias"), c0 * sizeof(float), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             for (int i = 0; i < c0; i++) acc[i] += tmp[i];
         }
         HIPCHK(hipMemcpyAsync(A(h, "outproj.bias"), acc.data(), c0 * sizeof(float), hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
     }
+    if (h->version == 1) { CHK(build_aux_v1(h, st)); h->aux_ready = true; return 0; }
     // neck uv columns + combined biases
     for (int l = 0; l < MOGE_LEVELS; l++) {
         const int cl = c.dims[l];
@@ -305,6 +321,7 @@ static int build_aux(moge_handle* h, hipStream_t st) {
     return 0;
 }
 
+template <typename T> static int pack_weights_v1(moge_handle* h, hipStream_t st);
 template <typename T>
 static int pack_weights(moge_handle* h, hipStream_t st) {
     const int pr = TT<T>::PREC;
@@ -313,7 +330,7 @@ static int pack_weights(moge_handle* h, hipStream_t st) {
     const int D = c.embed_dim, c0 = c.dims[0];
     if (!h->packed[pr]) HIPCHK(hipMalloc(&h->packed[pr], h->pk_elems * sizeof(T)));
     HIPCHK(hipMemsetAsync(h->packed[pr], 0, h->pk_elems * sizeof(T), st));
-    const std::string bb = "encoder.backbone.";
+    const std::string bb = h->bb;
     // patch embed [D][588] -> [D][592]
     LCHK(launch_repack<T>(M(h, bb + "patch_embed.proj.weight"), Pm<T>(h, "patch.w"), D, 1, 1, KPATCH, KPATCH, 0, 0, 1, KPATCH_PAD, 0, 0, st));
     for (int i = 0; i < c.depth; i++) {
@@ -331,8 +348,9 @@ static int pack_weights(moge_handle* h, hipStream_t st) {
     }
     // output projections: [c0][D] x n_taps -> [c0][n_taps*D]
     for (int k = 0; k < c.n_taps; k++)
-        LCHK(launch_repack<T>(M(h, S("encoder.output_projections.%d.weight", k)), Pm<T>(h, "outproj.w") + (size_t)k * D, c0, 1, 1, D, D, 0, 0, 1,
+        LCHK(launch_repack<T>(M(h, S(h->proj_fmt, k) + ".weight"), Pm<T>(h, "outproj.w") + (size_t)k * D, c0, 1, 1, D, D, 0, 0, 1,
                               (long)c.n_taps * D, 0, 0, st));
+    if (h->version == 1) { CHK(pack_weights_v1<T>(h, st)); h->pk_ready[pr] = true; return 0; }
     // neck.in0: [c0][c0+2] -> [c0][c0]
     LCHK(launch_repack<T>(M(h, "neck.input_blocks.0.weight"), Pm<T>(h, "neck.in0.w"), c0, 1, 1, c0, c0 + 2, 0, 0, 1, c0, 0, 0, st));
     auto conv3 = [&](const float* w, T* dst, int co, int ci) -> int {
@@ -575,13 +593,14 @@ static int get_pos(moge_handle* h, int rows, int cols, hipStream_t st, const flo
     return 0;
 }
 
+// ViT encoder shared by both model versions: resize + normalise + patchify of `image` (B, 3, imgH, imgW), patch embedding, the blocks, the
+// final-norm taps and their summed 1x1 projections -> pl.feat (B, rows, cols, c0) [+ pl.cls].  v2: modules.py:120-136; v1: v1.py:280-283 +
+// the `projects` of Head.forward (v1.py:108-111).
 template <typename T>
-static int forward_impl(moge_handle* h, const void* image, int img_dtype, const Plan& pl, float* o_points, float* o_normal, float* o_maskprob,
-                        float* o_metric, hipStream_t st) {
+static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, int imgW, const Plan& pl, hipStream_t st) {
     const moge_config& c = h->cfg;
     const int D = c.embed_dim, nh = c.num_heads, L = c.depth, c0 = c.dims[0];
     const int B = pl.B, rows = pl.rows, cols = pl.cols, Np = pl.Np, Ntok = pl.Ntok, Npad = pl.Npad;
-    const double aspect = (double)pl.W / (double)pl.H;
     char* ws = h->ws + pl.base;
     T* patches = (T*)(ws + pl.patches);
     float* x = (float*)(ws + pl.x);
@@ -594,17 +613,17 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     T* tapcat = (T*)(ws + pl.tapcat);
     float* cls = (float*)(ws + pl.cls);
     T* feat = (T*)(ws + pl.feat);
-    const std::string bb = "encoder.backbone.";
+    const std::string bb = h->bb;
     const long BN = (long)B * Ntok, BP = (long)B * Np;
 
     // ---- K0: resize + normalise + patchify (modules.py:121-122, patch_embed.py:75) ------------------------------
     const float* mean = h->img_mean; const float* sd = h->img_std;
     {
-        ProfScope ps(h, st, MOGE_KC_PRE, 0, (double)B * 3 * pl.H * pl.W * (img_dtype == 1 ? 2 : 4) + (double)BP * KPATCH_PAD * sizeof(T));
+        ProfScope ps(h, st, MOGE_KC_PRE, 0, (double)B * 3 * imgH * imgW * (img_dtype == 1 ? 2 : 4) + (double)BP * KPATCH_PAD * sizeof(T));
         LCHK(launch_zero_cols<T>(patches, BP, KPATCH_PAD, KPATCH, st));
         // img_dtype 3 = fp32 values to be rounded to fp16 on load (the model-dtype cast of a .half() model, v2.py:229)
-        if (img_dtype == 0 || img_dtype == 3) LCHK((launch_preprocess<float, T>(image, patches, B, pl.H, pl.W, rows, cols, KPATCH_PAD, 0, img_dtype == 3, !h->onnx_mode, mean, sd, st)));
-        else LCHK((launch_preprocess<f16, T>(image, patches, B, pl.H, pl.W, rows, cols, KPATCH_PAD, 0, 0, !h->onnx_mode, mean, sd, st)));
+        if (img_dtype == 0 || img_dtype == 3) LCHK((launch_preprocess<float, T>(image, patches, B, imgH, imgW, rows, cols, KPATCH_PAD, 0, img_dtype == 3, !h->onnx_mode, mean, sd, st)));
+        else LCHK((launch_preprocess<f16, T>(image, patches, B, imgH, imgW, rows, cols, KPATCH_PAD, 0, 0, !h->onnx_mode, mean, sd, st)));
     }
     const float* pos;
     CHK(get_pos(h, rows, cols, st, &pos));
@@ -704,6 +723,21 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
         g.epi = EPI_STORE; g.bias = A(h, "outproj.bias"); g.out = feat; g.ldc = c0;
         CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
     }
+    return 0;
+}
+
+template <typename T>
+static int forward_impl(moge_handle* h, const void* image, int img_dtype, const Plan& pl, float* o_points, float* o_normal, float* o_maskprob,
+                        float* o_metric, hipStream_t st) {
+    const moge_config& c = h->cfg;
+    const int D = c.embed_dim, c0 = c.dims[0];
+    const int B = pl.B, rows = pl.rows, cols = pl.cols, Np = pl.Np, Ntok = pl.Ntok;
+    const double aspect = (double)pl.W / (double)pl.H;
+    char* ws = h->ws + pl.base;
+    float* cls = (float*)(ws + pl.cls);
+    T* feat = (T*)(ws + pl.feat);
+    const long BN = (long)B * Ntok, BP = (long)B * Np;
+    CHK(encode<T>(h, image, img_dtype, pl.H, pl.W, pl, st));
     // ---- scale head (modules.py:184-192, v2.py:167,182) ---------------------------------------------------------
     if ((c.heads & MOGE_HEAD_SCALE) && o_metric) {
         float* m1 = (float*)(ws + pl.mlp1); float* m2 = (float*)(ws + pl.mlp2);
@@ -800,6 +834,212 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     return 0;
 }
 
+
+// ============================================================================================================================
+// MoGe-1 (moge/model/v1.py): tables, packing, plan, forward.  The ViT part is shared (build_tables / pack_weights /
+// encode above); this is the Head (v1.py:61-142) and the two-stage input resize (v1.py:271-278).
+// ============================================================================================================================
+static int v1_cpad(int c) { return (c + 2 + 7) / 8 * 8; }            // channels + (u, v), padded to 16-byte chunks in both storage types
+
+static void build_tables_v1_decoder(moge_handle* h) {
+    const moge_v1_config& c = h->cfg1;
+    for (int i = 0; i < c.n_up; i++) {
+        const int ci = i == 0 ? c.dim_proj : c.dim_upsample[i - 1], co = c.dim_upsample[i];
+        const std::string u = S("head.upsample_blocks.%d.", i);
+        tadd(h, u + "0.0.weight", (int64_t)(ci + 2) * co * 4); tadd(h, u + "0.0.bias", co);
+        tadd(h, u + "0.1.weight", (int64_t)co * co * 9); tadd(h, u + "0.1.bias", co);
+        padd(h, S("v1.up%d.wT", i), (int64_t)4 * co * ci);
+        padd(h, S("v1.up%d.w3", i), (int64_t)co * 9 * co);
+        aadd(h, S("v1.up%d.wu", i), 4 * co); aadd(h, S("v1.up%d.wv", i), 4 * co); aadd(h, S("v1.up%d.biasT", i), 4 * co);
+        for (int j = 0; j < c.num_res_blocks; j++) {
+            const std::string r = u + S("%d.layers.", 1 + j);
+            tadd(h, r + "0.weight", co); tadd(h, r + "0.bias", co);
+            tadd(h, r + "2.weight", (int64_t)co * co * 9); tadd(h, r + "2.bias", co);
+            tadd(h, r + "3.weight", co); tadd(h, r + "3.bias", co);
+            tadd(h, r + "5.weight", (int64_t)co * co * 9); tadd(h, r + "5.bias", co);
+            padd(h, S("v1.up%d.res%d.w1", i, j), (int64_t)co * 9 * co);
+            padd(h, S("v1.up%d.res%d.w2", i, j), (int64_t)co * 9 * co);
+        }
+    }
+    const int cl = c.dim_upsample[c.n_up - 1], c4 = c.last_conv_channels;
+    for (int o = 0; o < 2; o++) {
+        const std::string b = S("head.output_block.%d.", o);
+        tadd(h, b + "0.weight", (int64_t)c4 * (cl + 2) * 9); tadd(h, b + "0.bias", c4);
+        tadd(h, b + "2.weight", (int64_t)(o == 0 ? 3 : 1) * c4); tadd(h, b + "2.bias", o == 0 ? 3 : 1);
+    }
+    padd(h, "v1.out.w3", (int64_t)2 * c4 * 9 * v1_cpad(cl));
+    aadd(h, "v1.out.bias", 2 * c4);
+}
+
+static int build_aux_v1(moge_handle* h, hipStream_t st) {
+    const moge_v1_config& c = h->cfg1;
+    for (int i = 0; i < c.n_up; i++) {
+        const int ci = i == 0 ? c.dim_proj : c.dim_upsample[i - 1], co = c.dim_upsample[i];
+        const float* w = M(h, S("head.upsample_blocks.%d.0.0.weight", i));              // [ci + 2][co][2][2]; rows ci, ci + 1 = (u, v) inputs
+        LCHK(launch_repack<float>(w + (size_t)ci * co * 4, A(h, S("v1.up%d.wu", i)), 4, co, 1, 1, 1, 4, 0, 0, co, 1, 0, st));
+        LCHK(launch_repack<float>(w + (size_t)(ci + 1) * co * 4, A(h, S("v1.up%d.wv", i)), 4, co, 1, 1, 1, 4, 0, 0, co, 1, 0, st));
+        LCHK(launch_repack<float>(M(h, S("head.upsample_blocks.%d.0.0.bias", i)), A(h, S("v1.up%d.biasT", i)), 4, 1, 1, co, 0, 0, 0, 1, co, 0, 0, st));
+    }
+    const int c4 = c.last_conv_channels;
+    for (int o = 0; o < 2; o++)
+        LCHK(launch_repack<float>(M(h, S("head.output_block.%d.0.bias", o)), A(h, "v1.out.bias") + o * c4, 1, 1, 1, c4, 0, 0, 0, 1, 0, 0, 0, st));
+    return 0;
+}
+
+template <typename T>
+static int pack_weights_v1(moge_handle* h, hipStream_t st) {
+    const moge_v1_config& c = h->cfg1;
+    auto conv3 = [&](const float* w, T* dst, int co, int ci, int cip) -> int {        // torch [co][ci][3][3] -> [co][tap * cip + ci], cip >= ci zero padded
+        return launch_repack<T>(w, dst, co, 9, 1, ci, (long)ci * 9, 1, 0, 9, (long)9 * cip, cip, 0, st);
+    };
+    for (int i = 0; i < c.n_up; i++) {
+        const int ci = i == 0 ? c.dim_proj : c.dim_upsample[i - 1], co = c.dim_upsample[i];
+        const std::string u = S("head.upsample_blocks.%d.", i);
+        // ConvTranspose2d weight [ci + 2][co][2][2] -> [(dy*2+dx)*co + o][ci] (the two uv input rows go to the epilogue: build_aux_v1)
+        LCHK(launch_repack<T>(M(h, u + "0.0.weight"), Pm<T>(h, S("v1.up%d.wT", i)), 4, co, 1, ci, 1, 4, 0, (long)co * 4, (long)co * ci, ci, 0, st));
+        LCHK(conv3(M(h, u + "0.1.weight"), Pm<T>(h, S("v1.up%d.w3", i)), co, co, co));
+        for (int j = 0; j < c.num_res_blocks; j++) {
+            const std::string r = u + S("%d.layers.", 1 + j);
+            LCHK(conv3(M(h, r + "2.weight"), Pm<T>(h, S("v1.up%d.res%d.w1", i, j)), co, co, co));
+            LCHK(conv3(M(h, r + "5.weight"), Pm<T>(h, S("v1.up%d.res%d.w2", i, j)), co, co, co));
+        }
+    }
+    const int cl = c.dim_upsample[c.n_up - 1], c4 = c.last_conv_channels, cp = v1_cpad(cl);
+    for (int o = 0; o < 2; o++)
+        LCHK(conv3(M(h, S("head.output_block.%d.0.weight", o)), Pm<T>(h, "v1.out.w3") + (size_t)o * c4 * 9 * cp, c4, cl + 2, cp));
+    return 0;
+}
+
+struct PlanV1 {
+    Plan p;                       // encoder buffers + the caller-visible post buffers (same fields as MoGe-2)
+    int rh, rw;                   // resized image (v1.py:272-274)
+    size_t img1, X, T1, T2, R, Y, gn;
+};
+static PlanV1 make_plan_v1(moge_handle* h, int prec, int B, int H, int W, int rh, int rw) {
+    const moge_config& c = h->cfg;
+    const moge_v1_config& c1 = h->cfg1;
+    PlanV1 v;
+    Plan& p = v.p;
+    const size_t s = prec == MOGE_FP16 ? 2 : 4;
+    const int D = c.embed_dim;
+    const int rows = rh / 14, cols = rw / 14;
+    v.rh = rh; v.rw = rw;
+    p.B = B; p.H = H; p.W = W; p.rows = rows; p.cols = cols;
+    p.Np = rows * cols; p.Ntok = p.Np + 1; p.Npad = (p.Ntok + 63) / 64 * 64;
+    const size_t BN = (size_t)B * p.Ntok, BP = (size_t)B * p.Np, px = (size_t)B * H * W;
+    p.maskprob = take(p, px * 4);
+    p.pts_tmp = take(p, px * 12);
+    p.nrm_tmp = take(p, 16);
+    p.focal = take(p, (size_t)B * 4); p.shift = take(p, (size_t)B * 4); p.intr = take(p, (size_t)B * 36); p.metric = take(p, (size_t)B * 4);
+    p.post_end = p.total;
+    p.patches = take(p, BP * KPATCH_PAD * s);
+    p.x = take(p, BN * D * 4);
+    p.xn = take(p, BN * D * s);
+    p.ln_part = take(p, BN * (size_t)(D / 32) * 8);
+    p.ln_mr = take(p, BN * 8);
+    p.q = take(p, BN * D * s); p.k = take(p, BN * D * s);
+    p.vT = take(p, (size_t)B * D * p.Npad * s);
+    p.attn = take(p, BN * D * s);
+    p.hidden = take(p, BN * 4 * D * s);
+    p.tapcat = take(p, BP * c.n_taps * D * s);
+    p.cls = take(p, (size_t)B * D * 4);
+    p.mlp1 = p.mlp2 = 0;
+    p.feat = take(p, BP * c.dims[0] * s);
+    for (int l = 0; l < MOGE_LEVELS; l++) p.neck[l] = 0;
+    p.scratch_elems = 0;
+    size_t mx = 0, gnmax = 0;
+    for (int i = 0; i < c1.n_up; i++) {
+        const size_t e = BP * ((size_t)1 << (2 * (i + 1))) * c1.dim_upsample[i];
+        if (e > mx) mx = e;
+        const size_t gsz = groupnorm_scratch_floats(B, rows << (i + 1), cols << (i + 1), c1.dim_upsample[i] / 32 > 0 ? c1.dim_upsample[i] / 32 : 1);
+        if (gsz > gnmax) gnmax = gsz;
+    }
+    v.img1 = take(p, (size_t)B * 3 * rh * rw * 4);
+    v.X = take(p, mx * s); v.T1 = take(p, mx * s); v.T2 = take(p, mx * s);
+    const size_t rpx = (size_t)B * rh * rw;
+    v.R = take(p, rpx * v1_cpad(c1.dim_upsample[c1.n_up - 1]) * s);
+    v.Y = take(p, rpx * 2 * c1.last_conv_channels * s);
+    v.gn = take(p, gnmax * 4);
+    return v;
+}
+
+template <typename T>
+static int forward_v1_impl(moge_handle* h, const void* image, int img_dtype, const PlanV1& v, float* o_points, float* o_mask, hipStream_t st) {
+    const moge_v1_config& c = h->cfg1;
+    const Plan& pl = v.p;
+    const int B = pl.B, rh = v.rh, rw = v.rw, ph = pl.rows, pw = pl.cols;
+    char* ws = h->ws + pl.base;
+    float* img1 = (float*)(ws + v.img1);
+    // ---- v1.py:271-278: bicubic antialiased resize to (rh, rw); a .half() model keeps this image in fp16 (values rounded on load and on store);
+    // the normalisation + bilinear antialiased resize to (14 ph, 14 pw) + patchify happen in encode()'s preprocess kernel
+    {
+        ProfScope ps(h, st, MOGE_KC_PRE, 0, (double)B * 3 * ((double)pl.H * pl.W + (double)rh * rw) * 4);
+        const int round16 = (img_dtype == 1 || img_dtype == 3) ? 1 : 0;
+        if (img_dtype == 1) LCHK(launch_resize_bicubic_aa<f16>(image, img1, B, pl.H, pl.W, rh, rw, round16, st));
+        else LCHK(launch_resize_bicubic_aa<float>(image, img1, B, pl.H, pl.W, rh, rw, round16, st));
+    }
+    CHK(encode<T>(h, img1, 0, rh, rw, pl, st));
+    const double aspect = (double)rw / (double)rh;                      // Head.forward: aspect of the RESIZED image (v1.py:118)
+    T* X = (T*)(ws + v.X); T* T1 = (T*)(ws + v.T1); T* T2 = (T*)(ws + v.T2);
+    float* gns = (float*)(ws + v.gn);
+    const T* x = (const T*)(ws + pl.feat);
+    int hh = ph, ww = pw, ci = c.dim_proj;
+    for (int i = 0; i < c.n_up; i++) {
+        const int co = c.dim_upsample[i];
+        const std::string u = S("head.upsample_blocks.%d.", i);
+        {   // [x, uv] -> ConvTranspose2d(k2, s2): GEMM to 4*co columns, pixel-shuffle store; the two uv input channels are a rank-2 epilogue term
+            GemmArgs g = gemm_args();
+            g.a = x; g.lda = ci; g.w = P<T>(h, S("v1.up%d.wT", i)); g.ldw = ci;
+            g.M = B * hh * ww; g.N = 4 * co; g.K = ci;
+            g.epi = EPI_CONVT; g.bias = A(h, S("v1.up%d.biasT", i)); g.out = T1; g.Cout = co; g.pixW = ww; g.pixH = hh;
+            g.uv = uv_term(A(h, S("v1.up%d.wu", i)), A(h, S("v1.up%d.wv", i)), ww, hh, aspect);
+            g.uv_in = 1;
+            CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_CONV, st, ci + 2));
+        }
+        hh *= 2; ww *= 2;
+        CHK(conv3x3<T>(h, T1, P<T>(h, S("v1.up%d.w3", i)), M(h, u + "0.1.bias"), X, B, hh, ww, co, co, 0, ACT_NONE, nullptr, nullptr, st));
+        for (int j = 0; j < c.num_res_blocks; j++) {
+            // ResidualConvBlock (v1.py:44-58): GN(1) -> ReLU -> 3x3 -> GN(co/32) -> ReLU -> 3x3, + x
+            const std::string r = u + S("%d.layers.", 1 + j);
+            {
+                ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)B * hh * ww * co * 2 * sizeof(T));
+                LCHK(launch_groupnorm_relu<T>(X, T1, M(h, r + "0.weight"), M(h, r + "0.bias"), gns, B, hh, ww, co, 1, st));
+            }
+            CHK(conv3x3<T>(h, T1, P<T>(h, S("v1.up%d.res%d.w1", i, j)), M(h, r + "2.bias"), T2, B, hh, ww, co, co, 0, ACT_NONE, nullptr, nullptr, st));
+            {
+                ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)B * hh * ww * co * 2 * sizeof(T));
+                LCHK(launch_groupnorm_relu<T>(T2, T1, M(h, r + "3.weight"), M(h, r + "3.bias"), gns, B, hh, ww, co, co / 32 > 0 ? co / 32 : 1, st));
+            }
+            CHK(conv3x3<T>(h, T1, P<T>(h, S("v1.up%d.res%d.w2", i, j)), M(h, r + "5.bias"), X, B, hh, ww, co, co, 0, ACT_NONE, X, nullptr, st));
+        }
+        x = X; ci = co;
+    }
+    // ---- v1.py:127-136: bilinear resize to the resized image, uv concat, per-output [3x3 -> ReLU -> 1x1]; the two 3x3 convs run as one
+    // (2 * c4 output channels), the 1x1 convs + the resize back to (H, W) + the remap run in head_final (both linear: they commute)
+    const int cl = c.dim_upsample[c.n_up - 1], c4 = c.last_conv_channels, cp = v1_cpad(cl);
+    T* R = (T*)(ws + v.R); T* Y = (T*)(ws + v.Y);
+    {
+        ProfScope ps(h, st, MOGE_KC_POST, 0, (double)B * rh * rw * cp * sizeof(T));
+        const UVTerm uv = uv_term(nullptr, nullptr, rw, rh, aspect);
+        LCHK(launch_resize_bilinear_uv<T>(x, R, B, hh, ww, cl, rh, rw, cp, uv.u0, uv.u1, uv.v0, uv.v1, st));
+    }
+    CHK(conv3x3<T>(h, R, P<T>(h, "v1.out.w3"), A(h, "v1.out.bias"), Y, B, rh, rw, cp, 2 * c4, 0, ACT_RELU, nullptr, nullptr, st));
+    {
+        ProfScope ps(h, st, MOGE_KC_POST, 0, (double)B * rh * rw * 2 * c4 * sizeof(T));
+        if (o_points)
+            LCHK(launch_head_final<T>(0, Y, M(h, "head.output_block.0.2.weight"), M(h, "head.output_block.0.2.bias"), nullptr, nullptr, o_points, B, rh, rw, c4,
+                                      pl.H, pl.W, c.remap_output, st, 2 * c4));
+        if (o_mask)
+            LCHK(launch_head_final<T>(3, Y + c4, M(h, "head.output_block.1.2.weight"), M(h, "head.output_block.1.2.bias"), nullptr, nullptr, o_mask, B, rh, rw, c4,
+                                      pl.H, pl.W, 0, st, 2 * c4));
+    }
+    h->last.valid = true; h->last.prec = TT<T>::PREC; h->last.B = B; h->last.rows = ph; h->last.cols = pw;
+    h->last.bufs.clear();
+    h->last.bufs["features"] = {pl.feat, {(int64_t)B * ph * pw * c.dim_proj, 1}};
+    h->last.bufs["up_last"] = {v.X, {(int64_t)B * hh * ww * cl, 1}};
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------
@@ -821,6 +1061,44 @@ int moge_create(const moge_config* cfg, int device, moge_handle** out) {
     HIPCHK(hipSetDevice(device));
     moge_handle* h = new moge_handle();
     h->cfg = c;
+    h->device = device;
+    memset(&h->prof_acc, 0, sizeof(h->prof_acc));
+    build_tables(h);
+    hipError_t e = hipMalloc(&h->d_status, sizeof(int));
+    if (e != hipSuccess) { delete h; return fail(MOGE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    hipMemset(h->d_status, 0, sizeof(int));
+    *out = h;
+    return 0;
+}
+
+int moge_create_v1(const moge_v1_config* cfg, int device, moge_handle** out) {
+    if (!cfg || !out) return fail(MOGE_ERR_INVALID, "null argument");
+    const moge_v1_config& c = *cfg;
+    if (c.embed_dim % 128 != 0 || c.embed_dim > 1024 || c.embed_dim != c.num_heads * 64)
+        return fail(MOGE_ERR_INVALID, "unsupported ViT width %d / heads %d (need head_dim 64, width %%128==0, <=1024)", c.embed_dim, c.num_heads);
+    if (c.n_taps < 1 || c.n_taps > MOGE_MAX_TAPS) return fail(MOGE_ERR_INVALID, "bad n_taps");
+    if (c.n_up < 1 || c.n_up > MOGE_V1_MAX_UP) return fail(MOGE_ERR_INVALID, "bad number of upsample stages");
+    if (c.dim_proj % 32 != 0 || c.dim_proj <= 0) return fail(MOGE_ERR_INVALID, "dim_proj must be a positive multiple of 32");
+    for (int i = 0; i < c.n_up; i++)
+        if (c.dim_upsample[i] % 32 != 0 || c.dim_upsample[i] <= 0 || c.dim_upsample[i] > 512)
+            return fail(MOGE_ERR_INVALID, "dim_upsample entries must be multiples of 32 (GroupNorm(C / 32, C)), <= 512");
+    if (c.last_conv_channels != 32 && c.last_conv_channels != 64 && c.last_conv_channels != 16)
+        return fail(MOGE_ERR_INVALID, "last_conv_channels must be 16, 32 or 64");
+    if (c.num_res_blocks < 0 || c.num_res_blocks > 8) return fail(MOGE_ERR_INVALID, "bad num_res_blocks");
+    HIPCHK(hipSetDevice(device));
+    moge_handle* h = new moge_handle();
+    h->version = 1;
+    h->cfg1 = c;
+    h->mask_thr = c.mask_threshold;
+    h->bb = "backbone.";
+    h->proj_fmt = "head.projects.%d";
+    h->mean_key = "image_mean"; h->std_key = "image_std";
+    memset(&h->cfg, 0, sizeof(h->cfg));
+    h->cfg.embed_dim = c.embed_dim; h->cfg.depth = c.depth; h->cfg.num_heads = c.num_heads; h->cfg.n_taps = c.n_taps;
+    for (int i = 0; i < MOGE_MAX_TAPS; i++) h->cfg.taps[i] = c.taps[i];
+    h->cfg.dims[0] = c.dim_proj;
+    h->cfg.heads = MOGE_HEAD_POINTS | MOGE_HEAD_MASK;
+    h->cfg.remap_output = c.remap_output;
     h->device = device;
     memset(&h->prof_acc, 0, sizeof(h->prof_acc));
     build_tables(h);
@@ -868,8 +1146,8 @@ int moge_master_blob(moge_handle* h, void** dev_ptr, size_t* bytes) {
 
 int moge_master_ready(moge_handle* h) {
     if (!h || !h->master) return fail(MOGE_ERR_NOT_LOADED, "master blob not allocated");
-    HIPCHK(hipMemcpy(h->img_mean, M(h, "encoder.image_mean"), 3 * sizeof(float), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(h->img_std, M(h, "encoder.image_std"), 3 * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h->img_mean, M(h, h->mean_key), 3 * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h->img_std, M(h, h->std_key), 3 * sizeof(float), hipMemcpyDeviceToHost));
     h->master_ready = true;
     h->aux_ready = false; h->pk_ready[0] = h->pk_ready[1] = false;
     for (auto& e : h->pos_cache) hipFree(e.ptr);
@@ -920,8 +1198,9 @@ int moge_workspace_bytes(moge_handle* h, int B, int H, int W, int token_rows, in
     return 0;
 }
 
-static int check_call(moge_handle* h, const void* image, int B, int H, int W, int rows, int cols) {
+static int check_call(moge_handle* h, const void* image, int B, int H, int W, int rows, int cols, int version = 2) {
     if (!h || !image) return fail(MOGE_ERR_INVALID, "null argument");
+    if (h->version != version) return fail(MOGE_ERR_INVALID, "this handle is a MoGe-%d model: use the moge_%sforward / infer entry points", h->version, h->version == 1 ? "v1_" : "");
     if (!h->master_ready) return fail(MOGE_ERR_NOT_LOADED, "weights not loaded");
     if (B <= 0 || H <= 0 || W <= 0 || rows <= 0 || cols <= 0) return fail(MOGE_ERR_INVALID, "bad shape");
     if ((long)B * rows * cols * 256 > 2000000000L) return fail(MOGE_ERR_INVALID, "batch too large for 32-bit pixel indices");
@@ -1042,12 +1321,13 @@ static int post_impl(moge_handle* h, const Plan& pl, const float* pts_in, const 
     float* intr = out->intrinsics ? out->intrinsics : (float*)(h->ws + pl.intr);
     {
         ProfScope ps(h, st, MOGE_KC_RECOVER, 0, (double)B * 4096 * 16);
-        LCHK(launch_recover(pts_in, mp, nullptr, fov, nullptr, B, H, W, focal, shift, intr, h->d_status, st));
+        LCHK(launch_recover(pts_in, mp, nullptr, fov, nullptr, B, H, W, focal, shift, intr, h->d_status, st, h->mask_thr));
     }
     {
         const size_t px = (size_t)B * H * W;
         ProfScope ps(h, st, MOGE_KC_POST, 0, (double)px * (12 + 12 + 4 + 12 + 4 + 12 + 1));
-        LCHK(launch_finalize(pts_in, nrm_in, mp, metric, shift, intr, B, H, W, flags, out->points, out->depth, out->normal, out->mask, st));
+        LCHK(launch_finalize(pts_in, nrm_in, mp, metric, shift, intr, B, H, W, flags | (h->version == 1 ? 0x100 : 0), out->points, out->depth, out->normal,
+                             out->mask, st, h->mask_thr));
     }
     return 0;
 }
@@ -1068,6 +1348,39 @@ int moge_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, i
     float* metric = (c.heads & MOGE_HEAD_SCALE) ? (out->metric_scale ? out->metric_scale : (float*)(h->ws + pl.metric)) : nullptr;
     CHK(forward_dispatch(h, image, img_dtype, pl, out->points, nrm, mp, metric, st));
     return post_impl(h, pl, out->points, nrm, mp, metric, fov_x_deg, flags, out, st);
+}
+
+static int v1_check(moge_handle* h, const void* image, int B, int H, int W, int rh, int rw) {
+    CHK(check_call(h, image, B, H, W, rh / 14, rw / 14, 1));
+    if (rh < 14 || rw < 14) return fail(MOGE_ERR_INVALID, "resized image %dx%d is smaller than one 14x14 patch", rh, rw);
+    if (!h->pk_ready[h->prec]) CHK(moge_set_precision(h, h->prec, nullptr));
+    return 0;
+}
+
+int moge_v1_forward(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int resized_h, int resized_w, const moge_outputs* out, void* stream) {
+    CHK(v1_check(h, image, B, H, W, resized_h, resized_w));
+    if (!out) return fail(MOGE_ERR_INVALID, "null outputs");
+    hipStream_t st = (hipStream_t)stream;
+    CHK(ingest_image(h, image, img_dtype, B, H, W, st));
+    const PlanV1 v = make_plan_v1(h, h->prec, B, H, W, resized_h, resized_w);
+    CHK(ensure_ws(h, v.p.total));
+    if (h->prec == MOGE_FP16) return forward_v1_impl<f16>(h, image, img_dtype, v, out->points, out->mask_prob, st);
+    return forward_v1_impl<float>(h, image, img_dtype, v, out->points, out->mask_prob, st);
+}
+
+int moge_v1_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int resized_h, int resized_w, const float* fov_x_deg, int flags,
+                  const moge_outputs* out, void* stream) {
+    CHK(v1_check(h, image, B, H, W, resized_h, resized_w));
+    if (!out || !out->points || !out->depth) return fail(MOGE_ERR_INVALID, "points and depth output buffers are required");
+    hipStream_t st = (hipStream_t)stream;
+    CHK(ingest_image(h, image, img_dtype, B, H, W, st));
+    const PlanV1 v = make_plan_v1(h, h->prec, B, H, W, resized_h, resized_w);
+    CHK(ensure_ws(h, v.p.total));
+    float* mp = out->mask_prob ? out->mask_prob : (float*)(h->ws + v.p.maskprob);
+    int rc = h->prec == MOGE_FP16 ? forward_v1_impl<f16>(h, image, img_dtype, v, out->points, mp, st)
+                                  : forward_v1_impl<float>(h, image, img_dtype, v, out->points, mp, st);
+    if (rc) return rc;
+    return post_impl(h, v.p, out->points, nullptr, mp, nullptr, fov_x_deg, flags, out, st);
 }
 
 int moge_postprocess(moge_handle* h, const float* points_in, const float* normal_in, const float* mask_prob_in, const float* metric_scale_in,

@@ -12,15 +12,16 @@
 #include <type_traits>
 
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, int KIND>   // KIND 0 points, 1 normal, 2 mask
+template <typename T, int KIND>   // KIND 0 points, 1 normal, 2 mask (sigmoid), 3 raw single channel (MoGe-1 mask, v1.py:289: no activation)
 __global__ __launch_bounds__(256) void head_final_kernel(const T* __restrict__ x4, const float* __restrict__ w, const float* __restrict__ bias,
                                                          const T* __restrict__ n4, const float* __restrict__ w2,
-                                                         float* __restrict__ out, int B, int Hd, int Wd, int C, int H, int W, int remap) {
+                                                         float* __restrict__ out, int B, int Hd, int Wd, int C, int ld, int H, int W, int remap) {
+    // ld = channel pitch of x4 / n4 (>= C: x4 may point at a channel slice of a wider map)
     // optional second input n4 (same shape as x4) with its own 1x1 weights w2: the level-4 input block of the head
     // (x + in_4(neck_4), modules.py:245) pre-composed with the output conv - both are linear and commute with the bilinear
     // resize, so the 32-channel sum never has to be materialised at 16x the token resolution
     constexpr int CH = TT<T>::CH;
-    constexpr int CO = KIND == 2 ? 1 : 3;
+    constexpr int CO = (KIND == 2 || KIND == 3) ? 1 : 3;
     __shared__ float sw[2 * 3 * 64];
     for (int i = threadIdx.x; i < CO * C; i += 256) { sw[i] = w[i]; sw[CO * C + i] = n4 ? w2[i] : 0.f; }
     __syncthreads();
@@ -38,11 +39,11 @@ __global__ __launch_bounds__(256) void head_final_kernel(const T* __restrict__ x
         float ly = sy - y0, lx = sx - x0;
         ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
         const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
-        const T* base = x4 + (size_t)b * Hd * Wd * C;
-        const T* p00 = base + ((size_t)y0 * Wd + x0) * C;
-        const T* p01 = base + ((size_t)y0 * Wd + x1) * C;
-        const T* p10 = base + ((size_t)y1 * Wd + x0) * C;
-        const T* p11 = base + ((size_t)y1 * Wd + x1) * C;
+        const T* base = x4 + (size_t)b * Hd * Wd * ld;
+        const T* p00 = base + ((size_t)y0 * Wd + x0) * ld;
+        const T* p01 = base + ((size_t)y0 * Wd + x1) * ld;
+        const T* p10 = base + ((size_t)y1 * Wd + x0) * ld;
+        const T* p11 = base + ((size_t)y1 * Wd + x1) * ld;
         float o[CO];
 #pragma unroll
         for (int j = 0; j < CO; j++) o[j] = bias[j];
@@ -94,6 +95,8 @@ __global__ __launch_bounds__(256) void head_final_kernel(const T* __restrict__ x
         } else if (KIND == 1) {
             const float nrm = fmaxf(sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]), 1e-12f);
             out[idx * 3] = o[0] / nrm; out[idx * 3 + 1] = o[1] / nrm; out[idx * 3 + 2] = o[2] / nrm;
+        } else if (KIND == 3) {
+            out[idx] = o[0];
         } else {
             out[idx] = 1.f / (1.f + expf(-o[0]));
         }
@@ -104,8 +107,8 @@ __global__ __launch_bounds__(256) void head_final_kernel(const T* __restrict__ x
 template <int KIND>
 __global__ __launch_bounds__(256) void head_final32_kernel(const f16* __restrict__ x4, const float* __restrict__ w, const float* __restrict__ bias,
                                                            const f16* __restrict__ n4, const float* __restrict__ w2,
-                                                           float* __restrict__ out, int B, int Hd, int Wd, int H, int W, int remap) {
-    constexpr int C = 32, CO = KIND == 2 ? 1 : 3;
+                                                           float* __restrict__ out, int B, int Hd, int Wd, int ld, int H, int W, int remap) {
+    constexpr int C = 32, CO = (KIND == 2 || KIND == 3) ? 1 : 3;
     const int sub = threadIdx.x & 3;
     float wr[CO][8], wr2[CO][8];
 #pragma unroll
@@ -126,9 +129,9 @@ __global__ __launch_bounds__(256) void head_final32_kernel(const f16* __restrict
         float ly = sy - y0, lx = sx - x0;
         ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
         const float wt[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
-        const size_t base = (size_t)b * Hd * Wd * C + sub * 8;
-        const size_t off[4] = {base + ((size_t)y0 * Wd + x0) * C, base + ((size_t)y0 * Wd + x1) * C, base + ((size_t)y1 * Wd + x0) * C,
-                               base + ((size_t)y1 * Wd + x1) * C};
+        const size_t base = (size_t)b * Hd * Wd * ld + sub * 8;
+        const size_t off[4] = {base + ((size_t)y0 * Wd + x0) * ld, base + ((size_t)y0 * Wd + x1) * ld, base + ((size_t)y1 * Wd + x0) * ld,
+                               base + ((size_t)y1 * Wd + x1) * ld};
         u32x4 qa[4], qb[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) qa[k] = *reinterpret_cast<const u32x4*>(x4 + off[k]);
@@ -185,6 +188,8 @@ __global__ __launch_bounds__(256) void head_final32_kernel(const f16* __restrict
         } else if (KIND == 1) {
             const float nrm = fmaxf(sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]), 1e-12f);
             out[idx * 3] = o[0] / nrm; out[idx * 3 + 1] = o[1] / nrm; out[idx * 3 + 2] = o[2] / nrm;
+        } else if (KIND == 3) {
+            out[idx] = o[0];
         } else {
             out[idx] = 1.f / (1.f + expf(-o[0]));
         }
@@ -193,27 +198,28 @@ __global__ __launch_bounds__(256) void head_final32_kernel(const f16* __restrict
 
 template <typename T>
 int launch_head_final(int kind, const void* x4, const float* w, const float* bias, const void* n4, const float* w2, float* out, int B, int Hd,
-                      int Wd, int C, int H, int W, int remap, hipStream_t st) {
-    if (C > 64 || C % TT<T>::CH != 0) return -1;
+                      int Wd, int C, int H, int W, int remap, hipStream_t st, int ld) {
+    if (ld <= 0) ld = C;
+    if (C > 64 || C % TT<T>::CH != 0 || ld % TT<T>::CH != 0) return -1;
     const long total = (long)B * H * W;
     if (std::is_same<T, f16>::value && C == 32) {
         long nb = (total * 4 + 255) / 256;
         const int blocks4 = (int)(nb > 65536 ? 65536 : nb);
         const f16* xa = (const f16*)x4; const f16* xb = (const f16*)n4;
-        if (kind == 0) hipLaunchKernelGGL((head_final32_kernel<0>), dim3(blocks4), dim3(256), 0, st, xa, w, bias, xb, w2, out, B, Hd, Wd, H, W, remap);
-        else if (kind == 1) hipLaunchKernelGGL((head_final32_kernel<1>), dim3(blocks4), dim3(256), 0, st, xa, w, bias, xb, w2, out, B, Hd, Wd, H, W, remap);
-        else hipLaunchKernelGGL((head_final32_kernel<2>), dim3(blocks4), dim3(256), 0, st, xa, w, bias, xb, w2, out, B, Hd, Wd, H, W, remap);
+#define HF32(K) hipLaunchKernelGGL((head_final32_kernel<K>), dim3(blocks4), dim3(256), 0, st, xa, w, bias, xb, w2, out, B, Hd, Wd, ld, H, W, remap)
+        if (kind == 0) HF32(0); else if (kind == 1) HF32(1); else if (kind == 2) HF32(2); else HF32(3);
+#undef HF32
         return (int)hipGetLastError();
     }
     int blocks = (int)((total + 255) / 256);
     if (blocks > 32768) blocks = 32768;
-    if (kind == 0) hipLaunchKernelGGL((head_final_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const T*)x4, w, bias, (const T*)n4, w2, out, B, Hd, Wd, C, H, W, remap);
-    else if (kind == 1) hipLaunchKernelGGL((head_final_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const T*)x4, w, bias, (const T*)n4, w2, out, B, Hd, Wd, C, H, W, remap);
-    else hipLaunchKernelGGL((head_final_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const T*)x4, w, bias, (const T*)n4, w2, out, B, Hd, Wd, C, H, W, remap);
+#define HFG(K) hipLaunchKernelGGL((head_final_kernel<T, K>), dim3(blocks), dim3(256), 0, st, (const T*)x4, w, bias, (const T*)n4, w2, out, B, Hd, Wd, C, ld, H, W, remap)
+    if (kind == 0) HFG(0); else if (kind == 1) HFG(1); else if (kind == 2) HFG(2); else HFG(3);
+#undef HFG
     return (int)hipGetLastError();
 }
-template int launch_head_final<f16>(int, const void*, const float*, const float*, const void*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
-template int launch_head_final<float>(int, const void*, const float*, const float*, const void*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+template int launch_head_final<f16>(int, const void*, const float*, const float*, const void*, const float*, float*, int, int, int, int, int, int, int, hipStream_t, int);
+template int launch_head_final<float>(int, const void*, const float*, const float*, const void*, const float*, float*, int, int, int, int, int, int, int, hipStream_t, int);
 
 // ------------------------------------------------------------------------------------------------------------
 // out[b][n] = f(sum_k in[b][k]*W[n][k] + bias[n]); one wave per output, fp32.  act: 0 none, 1 relu, 2 exp
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(256) void recover_kernel(const float* __restrict__ 
                                                       const uint8_t* __restrict__ mask_u8, const float* __restrict__ fov_deg,
                                                       const float* __restrict__ focal_in, int H, int W,
                                                       float u0, float u1, float ustep, float v0, float v1, float vstep,
-                                                      float fov_c, float fx_mul, float fx_div, float fy_mul,
+                                                      float fov_c, float fx_mul, float fx_div, float fy_mul, float mask_thr,
                                                       float* __restrict__ focal_out, float* __restrict__ shift_out,
                                                       float* __restrict__ intrinsics, int* __restrict__ status) {
     __shared__ double sh[4 * 8];
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256) void recover_kernel(const float* __restrict__ 
         P.u[i] = linspace_at(u0, u1, ustep, W, sx);
         P.v[i] = linspace_at(v0, v1, vstep, H, sy);
         bool ok = true;
-        if (mask_prob) ok = mask_prob[(size_t)b * H * W + pix] > 0.5f;
+        if (mask_prob) ok = mask_prob[(size_t)b * H * W + pix] > mask_thr;
         else if (mask_u8) ok = mask_u8[(size_t)b * H * W + pix] != 0;
         if (ok) { P.valid |= 1u << i; count++; if (s < first) first = s; }
     }
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(256) void recover_kernel(const float* __restrict__ 
 }
 
 int launch_recover(const float* points, const float* mask_prob, const uint8_t* mask_u8, const float* fov_deg, const float* focal_in, int B,
-                   int H, int W, float* focal, float* shift, float* intrinsics, int* status, hipStream_t st) {
+                   int H, int W, float* focal, float* shift, float* intrinsics, int* status, hipStream_t st, float mask_thr) {
     const double a = (double)W / (double)H;
     const double sx = a / sqrt(1 + a * a), sy = 1 / sqrt(1 + a * a);
     const float u0 = (float)(-sx * (W - 1) / W), u1 = (float)(sx * (W - 1) / W);
@@ -549,7 +555,7 @@ int launch_recover(const float* points, const float* mask_prob, const uint8_t* m
     const float fov_c = (float)(a / sqrt(1 + a * a));
     const float diag = (float)sqrt(1 + a * a);
     hipLaunchKernelGGL(recover_kernel, dim3(B), dim3(256), 0, st, points, mask_prob, mask_u8, fov_deg, focal_in, H, W, u0, u1, ustep, v0, v1,
-                       vstep, fov_c, diag, (float)a, diag, focal, shift, intrinsics, status);
+                       vstep, fov_c, diag, (float)a, diag, mask_thr, focal, shift, intrinsics, status);
     return (int)hipGetLastError();
 }
 
@@ -558,8 +564,9 @@ int launch_recover(const float* points, const float* mask_prob, const uint8_t* m
 __global__ __launch_bounds__(256) void finalize_kernel(const float* points_in, const float* normal_in,
                                                        const float* __restrict__ mask_prob, const float* __restrict__ metric,
                                                        const float* __restrict__ shift, const float* __restrict__ intr,
-                                                       int B, int H, int W, int flags, float* points_out, float* __restrict__ depth_out,
+                                                       int B, int H, int W, int flags, float mask_thr, float* points_out, float* __restrict__ depth_out,
                                                        float* normal_out, uint8_t* __restrict__ mask_out) {
+    // flags bit 8 (internal, MoGe-1): the validity mask is `mask > threshold` only - v1.py:358 has no `depth > 0` term (v2.py:268 has)
     const long total = (long)B * H * W;
     const float INF = __builtin_inff();
     for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -569,7 +576,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* points_in, c
         float x = points_in[idx * 3], y = points_in[idx * 3 + 1], z = points_in[idx * 3 + 2];
         z += shift[b];
         bool m = true;
-        if (mask_prob) m = (mask_prob[idx] > 0.5f) && (z > 0.f);
+        if (mask_prob) m = (mask_prob[idx] > mask_thr) && ((flags & 0x100) || z > 0.f);
         float depth = z;
         if (flags & MOGE_FORCE_PROJECTION) {
             const float fx = intr[b * 9], fy = intr[b * 9 + 4], cx = intr[b * 9 + 2], cy = intr[b * 9 + 5];
@@ -589,11 +596,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* points_in, c
 }
 int launch_finalize(const float* points_in, const float* normal_in, const float* mask_prob, const float* metric, const float* shift,
                     const float* intr, int B, int H, int W, int flags, float* points_out, float* depth_out, float* normal_out,
-                    uint8_t* mask_out, hipStream_t st) {
+                    uint8_t* mask_out, hipStream_t st, float mask_thr) {
     const long total = (long)B * H * W;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 32768) blocks = 32768;
-    hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, st, points_in, normal_in, mask_prob, metric, shift, intr, B, H, W, flags,
+    hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, st, points_in, normal_in, mask_prob, metric, shift, intr, B, H, W, flags, mask_thr,
                        points_out, depth_out, normal_out, mask_out);
     return (int)hipGetLastError();
 }

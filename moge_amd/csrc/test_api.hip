@@ -175,6 +175,17 @@ static int t_convt(const float* x, const float* w, const float* bias, float* y, 
     return 0;
 }
 
+template <typename T>
+static int t_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int B, int H, int W, int C, int G, hipStream_t st) {
+    const size_t n = (size_t)B * H * W * C;
+    DevBuf xb, yb, sc;
+    TCHK(xb.alloc(n * sizeof(T))); TCHK(yb.alloc(n * sizeof(T))); TCHK(sc.alloc(groupnorm_scratch_floats(B, H, W, G) * sizeof(float)));
+    TL(to_t<T>(x, xb.p, (long)n, st));
+    TL(launch_groupnorm_relu<T>(xb.p, yb.p, gamma, beta, (float*)sc.p, B, H, W, C, G, st));
+    TL(from_t<T>(yb.p, y, (long)n, st));
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
 extern "C" {
 
 int moge_test_gemm(int precision, const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act, void* stream) {
@@ -225,6 +236,18 @@ int moge_test_preprocess(const float* image, float* out, int B, int H, int W, in
     TL((launch_preprocess<float, float>(image, out, B, H, W, rows, cols, 0, 1, 0, 1, mean, sd, st)));
     TCHK(hipStreamSynchronize(st));
     return 0;
+}
+
+int moge_test_resize_bicubic_aa(const float* image, float* out, int B, int H, int W, int OH, int OW, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    TL(launch_resize_bicubic_aa<float>(image, out, B, H, W, OH, OW, 0, st));
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int moge_test_groupnorm_relu(int precision, const float* x, const float* gamma, const float* beta, float* y, int B, int H, int W, int C, int groups, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    return precision == MOGE_FP16 ? t_groupnorm<f16>(x, gamma, beta, y, B, H, W, C, groups, st) : t_groupnorm<float>(x, gamma, beta, y, B, H, W, C, groups, st);
 }
 
 int moge_test_posembed(const float* pos, float* out, int D, int rows, int cols, void* stream) {

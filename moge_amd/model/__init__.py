@@ -4,8 +4,5 @@ from typing import Literal, Type
 
 
 def import_model_class_by_version(version: Literal["v1", "v2"] = "v2") -> Type:
-    if version == "v1":
-        raise NotImplementedError("moge_amd implements the MoGe-2 (v2) inference path only")
-    if version != "v2":
-        raise ValueError(f'Unsupported model version: {version}')
-    return importlib.import_module(".v2", __package__).MoGeModel
+    assert version in ("v1", "v2"), f"Unsupported model version: {version}"
+    return importlib.import_module(f".{version}", __package__).MoGeModel

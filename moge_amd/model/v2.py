@@ -211,7 +211,7 @@ class MoGeModel:
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: moge_amd needs an MI355X (there is no CPU fallback)")
         h = C.c_void_p()
-        L.check(L.lib.moge_create(C.byref(self._cfg), self._device.index, C.byref(h)))
+        L.check(self._create(h))
         self._handle = h
         self._state_ready = False
         if self._onnx_compatible_mode:
@@ -220,6 +220,9 @@ class MoGeModel:
             self._upload()
         elif self._blob_path is not None:
             self._upload_blob()
+
+    def _create(self, h) -> int:
+        return L.lib.moge_create(C.byref(self._cfg), self._device.index, C.byref(h))
 
     def _upload(self):
         names = [k.encode() for k in self._state]

@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from . import moge_oracle as O
+from . import moge_oracle_v1 as O1
 from . import metrics as MX
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -124,19 +125,37 @@ CASES = [
     dict(name="vitl_normal_1036x518", config="moge-2-vitl-normal", seed=0, sane=True, input="rand", input_seed=1, shape=[1, 3, 1036, 518],
          kwargs=dict(use_fp16=False), stride=7),
 ]
+CASES += [
+    # MoGe-1 (moge/model/v1.py): real v1 class on synthetic checkpoints
+    dict(name="v1_tiny_b2", version="v1", config="tiny-v1-vits", seed=0, sane=True, input_seed=11, shape=[2, 3, 98, 126],
+         kwargs=dict(num_tokens=120, use_fp16=False)),
+    dict(name="v1_tiny_fov_nomask_noproj_3d", version="v1", config="tiny-v1-vits", seed=0, sane=True, input_seed=12, shape=[3, 84, 112],
+         kwargs=dict(num_tokens=100, use_fp16=False, fov_x=60.0, apply_mask=False, force_projection=False)),
+    dict(name="v1_tiny_default_tokens_wide", version="v1", config="tiny-v1-vits", seed=1, sane=True, input_seed=13, shape=[1, 3, 70, 140],
+         kwargs=dict(use_fp16=False, resolution_level=3)),
+    dict(name="v1_vitl_518", version="v1", config="moge-vitl", seed=0, sane=True, input="rand", input_seed=0, shape=[1, 3, 518, 518],
+         kwargs=dict(use_fp16=False), stride=7),
+]
+
+
+def oracle_module(case: dict):
+    return O1 if case.get("version") == "v1" else O
+
+
 # the cases whose reference run takes more than a few seconds on 8 cores (the CPU suite replays the oracle on the fast ones only)
-SLOW_CASES = ("vits_house518", "vitb_normal_518_t3600", "vitl_518_t3600", "vitl_normal_518x1036", "vitl_normal_1036x518")
+SLOW_CASES = ("vits_house518", "vitb_normal_518_t3600", "vitl_518_t3600", "vitl_normal_518x1036", "vitl_normal_1036x518", "v1_vitl_518")
 
 
 def run_reference(case: dict):
     install_stubs()
     from moge.model import import_model_class_by_version
-    MoGeModel = import_model_class_by_version("v2")
-    cfg = O.named_configs()[case["config"]]
-    sd = O.synth_state_dict(cfg, case["seed"], case["sane"])
+    OM = oracle_module(case)
+    MoGeModel = import_model_class_by_version(case.get("version", "v2"))
+    cfg = OM.named_configs()[case["config"]]
+    sd = OM.synth_state_dict(cfg, case["seed"], case["sane"])
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "model.pt")
-        O.save_checkpoint(path, cfg, sd)
+        OM.save_checkpoint(path, cfg, sd)
         model = MoGeModel.from_pretrained(path).eval()
     missing = set(model.state_dict().keys()) ^ set(sd.keys())
     assert not missing, f"state-dict key mismatch vs reference: {sorted(missing)[:8]}"
@@ -192,7 +211,10 @@ def main():
         cfg, sd, x, ref, ref_fwd, ref16 = run_reference(case)
         kw = {k: v for k, v in case["kwargs"].items() if k != "use_fp16"}
         tr = {}
-        ora = O.infer(cfg, sd, x, trace=tr, onnx_compatible_mode=bool(case.get("onnx")), **kw)
+        if case.get("version") == "v1":
+            ora = O1.infer(cfg, sd, x, trace=tr, **kw)
+        else:
+            ora = O.infer(cfg, sd, x, trace=tr, onnx_compatible_mode=bool(case.get("onnx")), **kw)
         line = [case["name"]]
         assert set(ora.keys()) == set(ref.keys()), (ora.keys(), ref.keys())
         for k in ref:

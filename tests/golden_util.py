@@ -7,7 +7,7 @@ import torch
 
 from oracle import metrics as MX
 from oracle import moge_oracle as O
-from oracle.make_golden import CASES, SLOW_CASES, make_input, weights_digest
+from oracle.make_golden import CASES, SLOW_CASES, make_input, oracle_module, weights_digest
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASE_BY_NAME = {c["name"]: c for c in CASES}
@@ -18,8 +18,9 @@ def load_case(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     meta = json.loads(bytes(z["meta"]).decode())
     case = meta["case"]
-    cfg = O.named_configs()[case["config"]]
-    sd = O.synth_state_dict(cfg, case["seed"], case["sane"])
+    OM = oracle_module(case)
+    cfg = OM.named_configs()[case["config"]]
+    sd = OM.synth_state_dict(cfg, case["seed"], case["sane"])
     x = make_input(case)
     gold = {k: z[k] for k in z.files if k != "meta"}
     return case, cfg, sd, x, gold, meta

@@ -135,3 +135,19 @@ def recover(points, mask, focal=None):
     status = torch.zeros((1,), device="cuda", dtype=torch.int32)
     L.check(L.lib.moge_test_recover(_p(points), _p(m), _p(f_in), B, H, W, _p(f), _p(s), _p(status), st()))
     return f, s, int(status.item())
+
+
+def resize_bicubic_aa(img, OH, OW):
+    img = _f(img)
+    B, _, H, W = img.shape
+    y = torch.empty((B, 3, OH, OW), device="cuda", dtype=torch.float32)
+    L.check(L.lib.moge_test_resize_bicubic_aa(_p(img), _p(y), B, H, W, OH, OW, st()))
+    return y
+
+
+def groupnorm_relu(prec, x_nhwc, gamma, beta, groups):
+    x, gamma, beta = _f(x_nhwc), _f(gamma), _f(beta)
+    B, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    L.check(L.lib.moge_test_groupnorm_relu(prec, _p(x), _p(gamma), _p(beta), _p(y), B, H, W, Cc, groups, st()))
+    return y

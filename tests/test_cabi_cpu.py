@@ -34,8 +34,13 @@ def test_model_mirror_host_logic():
     assert m._grid(518, 518, 3600) == (60, 60) and m._grid(518, 1036, 3600) == (42, 85) and m._grid(1036, 518, 3600) == (85, 42)
     assert m._cfg.embed_dim == 1024 and m._cfg.depth == 24 and list(m._cfg.taps)[:4] == [5, 11, 17, 23]
     assert m.num_tokens_range == [1200, 3600] and m.dtype.is_floating_point and m.device.type == "cpu"
-    with pytest.raises(NotImplementedError):
-        import_model_class_by_version("v1")
+    M1 = import_model_class_by_version("v1")                       # MoGe-1 mirror (moge/model/v1.py): same loader, its own config keywords
+    from oracle import moge_oracle_v1 as O1
+    m1 = M1(**O1.named_configs()["moge-vitl"])
+    assert m1._cfg.n_taps == 4 and list(m1._cfg.taps)[:4] == [20, 21, 22, 23] and list(m1._cfg.dim_upsample)[:3] == [256, 128, 128]
+    assert m1._resized(518, 518, 2500) == (700, 700) and m1.num_tokens_range == [1200, 2500] and m1.mask_threshold == 0.5
+    with pytest.raises(AssertionError):
+        import_model_class_by_version("v3")
     with pytest.raises(ValueError):
         M(**{**O.named_configs()["tiny-vits-normal"], "remap_output": "bogus"})
     with pytest.raises(RuntimeError):

@@ -204,3 +204,44 @@ def test_pipeline_is_bit_identical_to_direct_calls_and_keeps_order(model):
             assert np.array_equal(g[k], ref[k][:len(b)].cpu().numpy(), equal_nan=True), k
     with pytest.raises(ValueError):
         list(pipe.run(iter([np.zeros((1, 10, 10, 3), np.uint8)])))
+
+
+@pytest.mark.gpu
+def test_cli_writes_every_output_the_reference_cli_writes(tmp_path):
+    """`python -m moge_amd.scripts.infer` (reference: moge/scripts/infer.py:18-156) on a folder with two image sizes: image.jpg, depth_vis.png,
+    depth.exr, points.exr, mask.png, normal.png, fov.json, mesh.glb, pointcloud.ply per image; the EXR depth equals infer()'s depth."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json
+    from PIL import Image
+    from click.testing import CliRunner
+    from moge_amd import io as IO
+    from moge_amd.model import import_model_class_by_version
+    from moge_amd.scripts.infer import main as cli
+    from oracle import moge_oracle as O
+    cfg = O.named_configs()["tiny-vits-normal"]
+    ckpt = str(tmp_path / "model.pt")
+    O.save_checkpoint(ckpt, cfg, O.synth_state_dict(cfg, 0, True))
+    rng = np.random.default_rng(5)
+    src = tmp_path / "in"
+    (src / "sub").mkdir(parents=True)
+    imgs = {"a.png": (84, 112), "b.png": (84, 112), "sub/c.png": (70, 98)}
+    for name, (h, w) in imgs.items():
+        Image.fromarray((rng.random((h, w, 3)) * 255).astype(np.uint8)).save(src / name)
+    out = tmp_path / "out"
+    r = CliRunner().invoke(cli, ["-i", str(src), "-o", str(out), "--pretrained", ckpt, "--num_tokens", "108", "--batch", "2"], catch_exceptions=False)
+    assert r.exit_code == 0, r.output
+    model = import_model_class_by_version("v2").from_pretrained(ckpt).to("cuda").eval()
+    for name, (h, w) in imgs.items():
+        d = out / name[:-4]
+        for f in ("image.jpg", "depth_vis.png", "depth.exr", "points.exr", "mask.png", "normal.png", "fov.json", "mesh.glb", "pointcloud.ply"):
+            assert (d / f).exists(), (name, f)
+        depth = IO.read_exr(d / "depth.exr")
+        pts = IO.read_exr(d / "points.exr")
+        assert depth.shape == (h, w) and pts.shape == (h, w, 3)
+        u8 = torch.from_numpy(np.asarray(Image.open(src / name).convert("RGB")))
+        ref = model.infer_uint8(u8, num_tokens=108, use_fp16=False)
+        assert np.array_equal(depth, ref["depth"].cpu().numpy()) and np.array_equal(pts, ref["points"].cpu().numpy())
+        fov = json.load(open(d / "fov.json"))
+        assert 1.0 < fov["fov_x"] < 179.0 and 1.0 < fov["fov_y"] < 179.0
+        assert (d / "mesh.glb").read_bytes()[:4] == b"glTF"

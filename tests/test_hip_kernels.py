@@ -187,3 +187,25 @@ def test_onnx_mode_forward_matches_oracle_raw_outputs(H):
         for k in ref:
             assert relmax(fwd[k], ref[k]) < 5e-4, (tokens, k, relmax(fwd[k], ref[k]))
         assert relmax(off["points"], ref["points"]) > 1e-3, "the flag must change the result (AA off / pos-embed by size)"
+
+
+@pytest.mark.parametrize("Hh,Ww,OH,OW", [(98, 126, 153, 197), (140, 150, 87, 93), (518, 518, 700, 700), (300, 500, 120, 640)])
+def test_resize_bicubic_antialiased(H, Hh, Ww, OH, OW):
+    """MoGe-1 input resize (v1.py:275): ATen _upsample_bicubic2d_aa (a = -0.5, support 2 max(scale, 1)) - up, down and mixed."""
+    img = torch.rand(2, 3, Hh, Ww, generator=torch.Generator().manual_seed(OH))
+    ref = F.interpolate(img, (OH, OW), mode="bicubic", align_corners=False, antialias=True)      # CPU reference (ATen)
+    assert float((H.resize_bicubic_aa(img, OH, OW).cpu() - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,Hh,Ww,Cc,G", [(2, 24, 30, 256, 1), (2, 24, 30, 256, 8), (1, 111, 77, 128, 4), (3, 50, 41, 32, 1), (1, 97, 130, 64, 2)])
+def test_groupnorm_relu(H, prec, B, Hh, Ww, Cc, G):
+    """ResidualConvBlock norms (v1.py:44,47): GroupNorm(1, C) and GroupNorm(C / 32, C), eps 1e-5, followed by ReLU; slabs of 2048 pixels per
+    block (multi-slab and ragged last slab covered)."""
+    g = torch.Generator().manual_seed(Cc + G)
+    x = torch.randn(B, Cc, Hh, Ww, generator=g) * 2 + 0.7
+    w, b = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    xin = x.half().float() if prec else x
+    ref = F.relu(F.group_norm(xin.cuda(), G, w.cuda(), b.cuda(), 1e-5)).permute(0, 2, 3, 1)
+    out = H.groupnorm_relu(prec, x.permute(0, 2, 3, 1), w, b, G)
+    assert relmax(out, ref) < (2e-5 if prec == 0 else 2e-3)

@@ -1,0 +1,97 @@
+"""GPU: MoGe-1 (`moge.model.v1.MoGeModel`) through the v1 mirror -> `moge_create_v1 / moge_v1_forward / moge_v1_infer`
+against the committed fixtures of the REAL reference v1 class (tests/golden/v1_*.npz) and the live CPU oracle (oracle/moge_oracle_v1.py).
+Same gates as the MoGe-2 parity tests: fp32 mode every pixel within 1e-3 and the mask bit-exact; fp16 mode inside 2x the reference's own
+fp16-vs-fp32 drift."""
+import os
+
+import pytest
+import torch
+
+from tests.golden_util import CASE_BY_NAME, SLOW_CASES, check_fp16, check_fp32, fp16_band, load_case, rel_err, subsample
+
+pytestmark = pytest.mark.gpu
+V1 = [n for n, c in CASE_BY_NAME.items() if c.get("version") == "v1"]
+_models = {}
+
+
+def get_model(case, tmp_path_factory):
+    from moge_amd.model import import_model_class_by_version
+    from oracle import moge_oracle_v1 as O1
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    key = (case["config"], case["seed"])
+    if key not in _models:
+        cfg = O1.named_configs()[case["config"]]
+        sd = O1.synth_state_dict(cfg, case["seed"], case["sane"])
+        path = os.path.join(str(tmp_path_factory.mktemp("ckpt")), "model.pt")
+        O1.save_checkpoint(path, cfg, sd)
+        _models[key] = import_model_class_by_version("v1").from_pretrained(path).to("cuda").eval()
+    return _models[key]
+
+
+def sub(out, st):
+    return {k: subsample(k, v.cpu().numpy(), st) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("name", V1)
+def test_v1_fp32_mode_matches_reference_golden_and_oracle(name, tmp_path_factory):
+    from oracle import moge_oracle_v1 as O1
+    case, cfg, sd, x, gold, meta = load_case(name)
+    model = get_model(case, tmp_path_factory)
+    kw = dict(case["kwargs"]); kw["use_fp16"] = False
+    out = model.float().infer(x, **kw)
+    st = case.get("stride", 1)
+    g = {k[6:]: v for k, v in gold.items() if k.startswith("infer.")}
+    seen = check_fp32(sub(out, st), g)
+    print(f"[parity v1 fp32] {name}: " + " ".join(f"{k}={v:.1e}" for k, v in seen.items()))
+    if name not in SLOW_CASES:
+        ref = O1.infer(cfg, sd, x, **{k: v for k, v in kw.items() if k != "use_fp16"})
+        check_fp32(out, ref)
+        # raw forward outputs (points after the remap, mask without activation: v1.py:289-297)
+        nt = kw.get("num_tokens") or int(cfg["num_tokens_range"][0] + (kw.get("resolution_level", 9) / 9) * (cfg["num_tokens_range"][1] - cfg["num_tokens_range"][0]))
+        xb = x if x.dim() == 4 else x[None]
+        fwd = model.forward(xb, nt)
+        rf = O1.forward(cfg, sd, xb, nt)
+        for k in rf:
+            assert rel_err(fwd[k].cpu().numpy(), rf[k].numpy()) < 5e-4, k
+
+
+@pytest.mark.parametrize("name", V1)
+def test_v1_fp16_mode_within_reference_fp16_band(name, tmp_path_factory):
+    case, cfg, sd, x, gold, meta = load_case(name)
+    model = get_model(case, tmp_path_factory)
+    kw = dict(case["kwargs"]); kw["use_fp16"] = True
+    st = case.get("stride", 1)
+    band = fp16_band(meta)
+    g = {k[6:]: v for k, v in gold.items() if k.startswith("infer.")}
+    try:
+        out = model.float().infer(x, **kw)
+        out_h = model.half().infer(x, **kw)
+    finally:
+        model.float()
+    for tag, o in (("autocast", out), ("half", out_h)):
+        seen = check_fp16(sub(o, st), g, band)
+        print(f"[parity v1 fp16 {tag}] {name}: " + " ".join(f"{k}={v:.1e}/{band.get(k, 0):.1e}" for k, v in seen.items()))
+
+
+def test_v1_properties_and_errors(tmp_path_factory):
+    case = CASE_BY_NAME["v1_tiny_b2"]
+    model = get_model(case, tmp_path_factory)
+    x = torch.rand(3, 3, 84, 112, generator=torch.Generator().manual_seed(2))
+    a = model.infer(x, num_tokens=100)
+    b = model.infer(x, num_tokens=100)
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{k} not deterministic"
+    one = model.infer(x[1], num_tokens=100)
+    for k in a:
+        u, v = a[k][1], one[k]
+        fin = torch.isfinite(u) if u.dtype != torch.bool else torch.ones_like(u)
+        assert torch.equal(u[fin], v[fin]), f"{k}: batch item depends on its batch"
+    assert set(a) == {"points", "intrinsics", "depth", "mask"} and a["mask"].dtype == torch.bool
+    assert torch.isinf(a["depth"][~a["mask"]]).all()
+    with pytest.raises(ValueError):
+        model.infer(x, num_tokens=100, fov_x=torch.tensor([50.0, 60.0]))
+    from moge_amd import _lib as L
+    import ctypes as C
+    o = L.Outputs()
+    assert L.lib.moge_forward(model._handle, x.cuda().data_ptr(), 0, 3, 84, 112, 6, 8, C.byref(o), None) == -1      # v2 entry point on a v1 handle

@@ -21,7 +21,11 @@ def test_oracle_matches_reference_golden(name):
     assert weights_digest(sd) == meta["weights_sha256"], "synthetic checkpoint generator drifted"
     kw = {k: v for k, v in case["kwargs"].items() if k != "use_fp16"}
     tr = {}
-    out = O.infer(cfg, sd, x, trace=tr, onnx_compatible_mode=bool(case.get("onnx")), **kw)
+    if case.get("version") == "v1":
+        from oracle import moge_oracle_v1 as O1
+        out = O1.infer(cfg, sd, x, trace=tr, **kw)
+    else:
+        out = O.infer(cfg, sd, x, trace=tr, onnx_compatible_mode=bool(case.get("onnx")), **kw)
     st = case.get("stride", 1)
     ill = not case["sane"]
     assert {"infer." + k for k in out} == {k for k in gold if k.startswith("infer.")}
