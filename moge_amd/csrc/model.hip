@@ -587,7 +587,7 @@ static int get_pos(moge_handle* h, int rows, int cols, hipStream_t st, const flo
     }
     float* p;
     HIPCHK(hipMalloc(&p, (size_t)(1 + rows * cols) * h->cfg.embed_dim * sizeof(float)));
-    LCHK(launch_posembed(M(h, "encoder.backbone.pos_embed"), p, h->cfg.embed_dim, rows, cols, h->onnx_mode, st));
+    LCHK(launch_posembed(M(h, h->bb + "pos_embed"), p, h->cfg.embed_dim, rows, cols, h->onnx_mode, st));
     h->pos_cache.push_back({rows, cols, h->onnx_mode, p});
     *out = p;
     return 0;

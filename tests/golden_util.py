@@ -51,6 +51,7 @@ def rel_err(a, b, floor=1.0):
 FP32_TOL = 1e-3            # fp32 mode: every pixel within 1e-3 relative (oracle.metrics: per-pixel, norm-relative), mask bit-exact
 ILL_TOL = 5e-2             # ill-posed checkpoint: p99.9 (the LM trajectory amplifies 1e-7 forward noise; so does the reference between thread counts)
 FP16_FACTOR = 2.0          # fp16 mode: at most 2x the drift of the reference's OWN fp16 path against its fp32 path on the same case
+FLIP_SLACK = 4              # pixels
 FP16_FLOOR = dict(points=5e-4, depth=5e-4, normal=2e-3, intrinsics=1e-4, metric_scale=5e-4, mask=1e-4)   # where the reference's drift is ~0 (e.g. fov_x given)
 
 
@@ -103,12 +104,13 @@ def check_fp16(out: dict, ref32: dict, band: dict) -> dict:
     for k in ref32:
         a, b = _arr(out[k]), _arr(ref32[k])
         if b.dtype == np.bool_:
-            frac = float((a != b).sum()) / b.size
-            seen[k] = frac
-            assert frac <= flips_allowed, f"mask: {frac:.2e} of the pixels differ (allowed {flips_allowed:.2e})"
+            nflip = int((a != b).sum())
+            seen[k] = nflip / b.size
+            # flips are discrete events: the small fixtures (25 k pixels) see 2 in the reference itself - allow FLIP_SLACK pixels on top of the fraction
+            assert nflip <= flips_allowed * b.size + FLIP_SLACK, f"mask: {nflip}/{b.size} pixels differ (allowed {flips_allowed:.2e} of them + {FLIP_SLACK})"
             continue
         e, nmis, n = MX.pixel_errors(k, a, b)
-        assert nmis <= flips_allowed * n + 0.5, f"{k}: non-finite pattern differs on {nmis}/{n} entries"
+        assert nmis <= flips_allowed * n + FLIP_SLACK, f"{k}: non-finite pattern differs on {nmis}/{n} entries"
         if not e.size:
             continue
         val = float(np.quantile(e, 0.999))
