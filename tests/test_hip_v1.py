@@ -95,3 +95,20 @@ def test_v1_properties_and_errors(tmp_path_factory):
     import ctypes as C
     o = L.Outputs()
     assert L.lib.moge_forward(model._handle, x.cuda().data_ptr(), 0, 3, 84, 112, 6, 8, C.byref(o), None) == -1      # v2 entry point on a v1 handle
+
+
+def test_panorama_view_batching_matches_per_view_infer(tmp_path_factory):
+    """infer_panorama.py:97-104 with the v1 model (the script's default): batches of 4 views with a per-view fov_x tensor."""
+    import numpy as np
+    from moge_amd.panorama import infer_panorama_views, intrinsics_to_fov_x_deg
+    model = get_model(CASE_BY_NAME["v1_tiny_b2"], tmp_path_factory)
+    rng = np.random.default_rng(3)
+    views = [(rng.random((64, 64, 3)) * 255).astype(np.uint8) for _ in range(6)]
+    Ks = [np.array([[0.5 + 0.05 * i, 0, 0.5], [0, 0.5 + 0.05 * i, 0.5], [0, 0, 1.0]]) for i in range(6)]
+    dist, masks = infer_panorama_views(model, views, Ks, batch_size=4, num_tokens=64)
+    assert len(dist) == len(masks) == 6 and dist[0].shape == (64, 64) and masks[0].dtype == bool
+    assert abs(float(intrinsics_to_fov_x_deg(Ks[0])[0]) - 90.0) < 1e-4
+    for i in (0, 5):
+        x = torch.tensor(views[i] / 255, dtype=torch.float32).permute(2, 0, 1)
+        one = model.infer(x, fov_x=float(intrinsics_to_fov_x_deg(Ks[i])[0]), apply_mask=False, num_tokens=64)
+        assert np.array_equal(one["points"].norm(dim=-1).cpu().numpy(), dist[i]) and np.array_equal(one["mask"].cpu().numpy(), masks[i])
