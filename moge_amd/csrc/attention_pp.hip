@@ -72,7 +72,9 @@ constexpr float AP_PSUM_LIMIT = 16384.f;
 //      sums: the decision is known right after the K Q^T chain, so the exponentials are free to interleave with the P V MFMAs (with the
 //      sum-based guard the branch sits between the last exponential and the first P V MFMA and serialises the two)
 constexpr int AP_VAR_DEFAULT = 0;
+constexpr int AP_KERN_DEFAULT = 1;      // 0: attn_pp16_kernel, 1: attn_pp16m_kernel (row sums on the matrix pipe)
 constexpr float AP_SCORE_LIMIT = 15.f;
+constexpr float AP_ROWSUM_LIMIT = 49152.f;      // attn_pp16m: FULL row sum of a tile (64 keys) below this -> every P < 49152 < 65504 (fp16 max)
 template <int VAR>
 __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
                                                            f16* __restrict__ out, int Ntok, int nh) {
@@ -196,7 +198,8 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
             }
 #pragma unroll
             for (int db = 0; db < 4; db++) {
-                const u32x4 vf = tr_pair(va[db] + (32 * s2) * 128, va[db] + (32 * s2 + 4) * 128);
+                // ablation 32: the V^T operand of step 0 reused for step 1 (half the transposed LDS reads; wrong results)
+                const u32x4 vf = tr_pair(va[db] + (32 * ((VAR & 32) ? 0 : s2)) * 128, va[db] + (32 * ((VAR & 32) ? 0 : s2) + 4) * 128);
 #pragma unroll
                 for (int qb = 0; qb < 2; qb++) mma16<f16>(o[db][qb], vf, pf[qb]);
             }
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         sc[kb][qb][r] = (VAR & 1) ? sc[kb][qb][r] * 1e-3f : __builtin_amdgcn_exp2f(sc[kb][qb][r]);
-                        if (kb & 1) ps1 += sc[kb][qb][r]; else ps0 += sc[kb][qb][r];
+                        if (!(VAR & 16) || (kb == 0 && r == 0)) { if (kb & 1) ps1 += sc[kb][qb][r]; else ps0 += sc[kb][qb][r]; }   // ablation 16: no row-sum adds
                     }
                 psum[qb] = ps0 + ps1;
                 trig |= !(psum[qb] < AP_PSUM_LIMIT);
@@ -344,6 +347,261 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// attn_pp16m_kernel: attn_pp16_kernel with the softmax ROW SUMS taken by the matrix pipe.  rocprof + ablations of attn_pp16_kernel (tools/kbench
+// KB_ABL, profiles/r02i_kbench_attn_abl.log): the kernel is ISSUE-bound, not MFMA- or LDS-bound - per 16-cycle MFMA a SIMD has ~3 further issue
+// slots, the tile needs ~6 (one v_exp_f32 = several slots, one row-sum add, half a convert, 0.75 LDS reads per MFMA): MFMA pipe 48 % busy.
+// Removing the 32 row-sum adds alone was worth +18 %, adds + overflow guard +23 %.  Here:
+//   * l += 1^T P^T is two extra MFMAs per query block and tile (A operand = a register of fp16 ones): every lane of a query receives the
+//     FULL row sum of the tile (no partial sums, no final cross-lane reduction) - 4 MFMAs replace 32 v_add_f32 + the guard's compares;
+//   * the same number is the overflow guard: it is formed from the fp16 P values BEFORE any P V MFMA of the tile is issued; a P that
+//     overflowed fp16 makes it +inf, any sum >= 2^14 sends the tile to the exact (re-max) path as before.
+// The normaliser is now the sum of the fp16-rounded P (exactly what multiplies V) instead of the fp32 P; the exact path (first / last
+// tile, guard trips) sums in fp32 and broadcasts the row sum to the query's four lanes so that l has one meaning everywhere.
+// ------------------------------------------------------------------------------------------------------------------------
+// (Requesting the tile's V^T operands behind the K Q^T MFMAs, so that their LDS latency passes under the exponentials, needs > 168 registers =
+// 2 waves per SIMD: measured 783-800 TF/s against 938-944 for this form - the third wave is worth more than the exposed read latency.)
+__global__ __launch_bounds__(256, 3) void attn_pp16m_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
+                                                            f16* __restrict__ out, int Ntok, int nh) {
+    constexpr int NW = 4, NPW = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * AP_STAGE
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int bh = blockIdx.y;
+    const int b = bh / nh, head = bh - b * nh;
+    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+
+    u32x4 qf[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+        const int qrow = q0 + qb * 16 + l15;
+        const f16* qp = q + ((size_t)bh * Ntok + (qrow < Ntok ? qrow : Ntok - 1)) * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) qf[qb][ks] = *reinterpret_cast<const u32x4*>(qp + 32 * ks + 8 * g4);
+    }
+    const char* kbase = reinterpret_cast<const char*>(k + (size_t)bh * Ntok * 64);
+    const char* vbase = reinterpret_cast<const char*>(v + (size_t)bh * Ntok * 64);
+    const int prow = lane >> 3, pch = lane & 7;
+    int drow[NPW];
+    unsigned doff[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; i++) {
+        const int p = wave + NW * i;
+        const int row = (p & 7) * 8 + prow;
+        drow[i] = row;
+        const int ksw = ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
+        const int vsw = (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
+        doff[i] = (unsigned)(row * 128 + ((pch ^ (p >= 8 ? vsw : ksw)) << 4));
+    }
+    const int ntiles = (Ntok + 63) >> 6;
+    auto issue = [&](int t) {
+        char* st = smem + (t % 3) * AP_STAGE;
+        const char* kt = uniform_ptr(kbase + (size_t)t * 8192);
+        const char* vt = uniform_ptr(vbase + (size_t)t * 8192);
+        if (t < ntiles - 1) {
+#pragma unroll
+            for (int i = 0; i < NPW; i++) {
+                const int p = wave + NW * i;
+                __builtin_amdgcn_global_load_lds(AP_GPTR((p >= 8 ? vt : kt) + doff[i]), AP_LPTR(st + p * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPW; i++) {
+                const int p = wave + NW * i;
+                const int over = t * 64 + drow[i] - (Ntok - 1);
+                const unsigned off = doff[i] - (over > 0 ? (unsigned)over * 128u : 0u);
+                __builtin_amdgcn_global_load_lds(AP_GPTR((p >= 8 ? vt : kt) + off), AP_LPTR(st + p * 1024), 16, 0, 0);
+            }
+        }
+    };
+    const int kswl = ((l15 >> 1) & 1) | ((l15 >> 2) << 1);
+    int kaddr[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) kaddr[ks] = (8 * (l15 >> 2) + (l15 & 3)) * 128 + (((4 * ks + g4) ^ kswl) << 4);
+    const int vswl = (((l15 >> 3) & 1) << 1) | ((g4 & 1) << 2);
+    int vaddr[4];
+#pragma unroll
+    for (int db = 0; db < 4; db++)
+        vaddr[db] = 8192 + (8 * g4 + (l15 >> 2)) * 128 + ((((2 * db) ^ vswl) | ((l15 & 3) >> 1)) << 4) + (l15 & 1) * 8;
+
+    f32x4 o[4][2];
+    f32x4 negs[2];
+    float m_run[2], l_run[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+#pragma unroll
+        for (int db = 0; db < 4; db++) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        negs[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m_run[qb] = -1e30f; l_run[qb] = 0.f;
+    }
+    issue(0);
+    if (ntiles > 1) issue(1);
+
+    int stage = 0;
+    const char* ka[2];
+    const char* va[4];
+    f32x4 sc[4][2];
+    float psum[2];
+    auto tile_head = [&](int t) {
+        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntiles) issue(t + 2);
+        const int so = stage * AP_STAGE;
+        stage = stage == 2 ? 0 : stage + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) ka[ks] = smem + (kaddr[ks] + so);
+#pragma unroll
+        for (int db = 0; db < 4; db++) va[db] = smem + (vaddr[db] + so);
+    };
+    auto pack = [&](int qb, u32x4 (&pf)[2]) {          // P^T operands of the two 32-key steps of query block qb
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            f16x8 hp;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { hp[r] = (f16)sc[2 * s2][qb][r]; hp[4 + r] = (f16)sc[2 * s2 + 1][qb][r]; }
+            pf[s2] = __builtin_bit_cast(u32x4, hp);
+        }
+    };
+    auto pv_block = [&](int qb, const u32x4 (&pf)[2]) {
+        l_run[qb] += psum[qb];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int db = 0; db < 4; db++) {
+                const u32x4 vf = tr_pair(va[db] + (32 * s2) * 128, va[db] + (32 * s2 + 4) * 128);
+                mma16<f16>(o[db][qb], vf, pf[s2]);
+            }
+    };
+    auto exact_block = [&](int t, bool last, int qb) {      // raise m to the true running max, rescale O and l, P = exp2(s - m), P V: one query block
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) {
+            const int koff = (32 * (kb >> 1) + 4 * (kb & 1)) * 128;
+            const u32x4 kf0 = *reinterpret_cast<const u32x4*>(ka[0] + koff), kf1 = *reinterpret_cast<const u32x4*>(ka[1] + koff);
+            sc[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma16<f16>(sc[kb][qb], kf0, qf[qb][0]);
+            mma16<f16>(sc[kb][qb], kf1, qf[qb][1]);
+        }
+        if (last) {
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int key = t * 64 + 32 * (kb >> 1) + 8 * g4 + 4 * (kb & 1) + r;
+                    if (key >= Ntok) sc[kb][qb][r] = -1e30f;
+                }
+        }
+        float mx = sc[0][qb][0];
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) mx = fmaxf(mx, sc[kb][qb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run[qb], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+        m_run[qb] = m_new;
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int db = 0; db < 4; db++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[db][qb][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; r++) negs[qb][r] = -m_new;
+        float ps = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                sc[kb][qb][r] = __builtin_amdgcn_exp2f(sc[kb][qb][r] - m_new);
+                ps += sc[kb][qb][r];
+            }
+        ps += __shfl_xor(ps, 16);                          // full row sum in all four lanes of the query (l is a full sum in this kernel)
+        ps += __shfl_xor(ps, 32);
+        psum[qb] = ps;
+        u32x4 pf[2];
+        pack(qb, pf);
+        pv_block(qb, pf);
+    };
+    auto qk_block = [&](int qb, const u32x4 (&kf)[4][2]) {
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++)
+            sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[kb][0]), __builtin_bit_cast(f16x8, qf[qb][0]), negs[qb], 0, 0, 0);
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) mma16<f16>(sc[kb][qb], kf[kb][1], qf[qb][1]);
+    };
+    u32x4 ones;                                             // fp16 1.0 x 8: the A operand of the row-sum MFMA
+#pragma unroll
+    for (int i = 0; i < 4; i++) ones[i] = 0x3c003c00u;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    tile_head(0);
+    exact_block(0, ntiles == 1, 0);
+    exact_block(0, ntiles == 1, 1);
+    int t = 1;
+    for (;;) {
+        bool hit = false;
+        for (; t < ntiles - 1; t++) {                // ---- hot loop ----
+            tile_head(t);
+            u32x4 kf[4][2];
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++) {
+                const int koff = (32 * (kb >> 1) + 4 * (kb & 1)) * 128;
+                kf[kb][0] = *reinterpret_cast<const u32x4*>(ka[0] + koff);
+                kf[kb][1] = *reinterpret_cast<const u32x4*>(ka[1] + koff);
+            }
+            qk_block(0, kf);
+            qk_block(1, kf);
+            u32x4 pf[2][2];                          // [query block][32-key step]
+            f32x4 lt[2];                             // this tile's row sums (every register / lane of a query holds the same number)
+#pragma unroll
+            for (int qb = 0; qb < 2; qb++) {
+#pragma unroll
+                for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) sc[kb][qb][r] = __builtin_amdgcn_exp2f(sc[kb][qb][r]);
+                pack(qb, pf[qb]);
+                lt[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ones), __builtin_bit_cast(f16x8, pf[qb][0]), zero4, 0, 0, 0);
+                mma16<f16>(lt[qb], ones, pf[qb][1]);
+            }
+            const bool trig = !(lt[0][0] < AP_ROWSUM_LIMIT) | !(lt[1][0] < AP_ROWSUM_LIMIT);
+            if (__builtin_expect(__any(trig), 0)) { hit = true; break; }
+#pragma unroll
+            for (int qb = 0; qb < 2; qb++) l_run[qb] += lt[qb][0];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                for (int db = 0; db < 4; db++) {
+                    const u32x4 vf = tr_pair(va[db] + (32 * s2) * 128, va[db] + (32 * s2 + 4) * 128);
+#pragma unroll
+                    for (int qb = 0; qb < 2; qb++) mma16<f16>(o[db][qb], vf, pf[qb][s2]);
+                }
+        }
+        if (!hit) break;
+        exact_block(t, false, 0);                    // tile t again from LDS (its barrier and DMA issue are done)
+        exact_block(t, false, 1);
+        t++;
+    }
+    if (ntiles > 1) {
+        tile_head(ntiles - 1);
+        exact_block(ntiles - 1, true, 0);
+        exact_block(ntiles - 1, true, 1);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+        const float inv = 1.f / l_run[qb];               // already the full row sum
+        const int qrow = q0 + qb * 16 + l15;
+        if (qrow < Ntok) {
+            f16* op = out + ((size_t)b * Ntok + qrow) * ((size_t)nh * 64) + head * 64;
+#pragma unroll
+            for (int db = 0; db < 4; db++)
+                store4(op + 16 * db + 4 * g4, o[db][qb][0] * inv, o[db][qb][1] * inv, o[db][qb][2] * inv, o[db][qb][3] * inv);
+        }
+    }
+}
+
 // (A software-pipelined variant - K Q^T of tile t issued under the softmax of tile t-1, two S buffers, four-stage ring, 2 waves per SIMD -
 // was written and measured: correct, 860 TF/s against 920 for the kernel above.  With the schedule left to the compiler the exps still
 // cluster (18 in a row between MFMAs) and the second S buffer costs register moves / spills; it needs a hand-placed instruction stream.)
@@ -351,6 +609,11 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
 static int launch_attn_pp16(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
     constexpr int smem = 3 * AP_STAGE;
     dim3 grid((Ntok + 127) / 128, B * nh);
+    if (moge_tune_get("ATTN_KERN", AP_KERN_DEFAULT) == 1) {             // attn_pp16m_kernel: row sums on the matrix pipe
+        if (int rc = set_dyn_lds<attn_pp16m_kernel>(smem)) return rc;
+        hipLaunchKernelGGL(attn_pp16m_kernel, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
+        return (int)hipGetLastError();
+    }
 #define AP_LAUNCH_VAR(V) do { if (int rc = set_dyn_lds<attn_pp16_kernel<V>>(smem)) return rc; \
         hipLaunchKernelGGL(attn_pp16_kernel<V>, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh); \
         return (int)hipGetLastError(); } while (0)
@@ -363,6 +626,12 @@ static int launch_attn_pp16(const void* q, const void* k, const void* v, void* o
     case 6: AP_LAUNCH_VAR(6);
     case 8: AP_LAUNCH_VAR(8);
     case 12: AP_LAUNCH_VAR(12);
+    case 16: AP_LAUNCH_VAR(16);
+    case 18: AP_LAUNCH_VAR(18);
+    case 19: AP_LAUNCH_VAR(19);
+    case 32: AP_LAUNCH_VAR(32);
+    case 50: AP_LAUNCH_VAR(50);
+    case 51: AP_LAUNCH_VAR(51);
     default: return -1;
     }
 #else

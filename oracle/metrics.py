@@ -5,7 +5,8 @@ scale and not with an absolute floor of 1:
 
   points      ||a - b||_2 / max(||b||_2, FLOOR_FRAC * median ||b||_2)          per pixel (3-vector)
   depth       |a - b|     / max(|b|,     FLOOR_FRAC * median |b|)              per pixel
-  normal      ||a - b||_2                                                      per pixel (b is a unit vector, or 0 outside the mask)
+  normal      ||a - b||_2                                                      per pixel inside BOTH masks (b is a unit vector; pixels that are
+                                                                               0 = masked in exactly one array are mask flips, counted apart)
   intrinsics  |a - b|     / max(|b|, FLOOR_FRAC)                               per entry (entries are 0, 0.5, 1, fx, fy)
   other       |a - b|     / max(|b|,     FLOOR_FRAC * median |b|)
 
@@ -36,7 +37,13 @@ def pixel_errors(name: str, a, b):
         with np.errstate(invalid="ignore"):
             d = np.linalg.norm(np.where(both[..., None], a - b, 0.0), axis=-1)[both]
         if name == "normal":
-            return d, int((fa != fb).sum()), int(fa.size)
+            # outside the validity mask a normal is exactly 0 (v2.py:289): a pixel that is 0 in one array and a unit vector in the other is a
+            # MASK FLIP (error 1 by construction) - counted with the pattern mismatches, not in the error distribution; pixels masked in
+            # both arrays carry no information and are left out like the +inf pixels of points / depth
+            za = (np.where(both[..., None], a, 1.0) == 0).all(-1)
+            zb = (np.where(both[..., None], b, 1.0) == 0).all(-1)
+            keep = ~za[both] & ~zb[both]
+            return d[keep], int((fa != fb).sum() + (za != zb).sum()), int(fa.size)
         nb = np.linalg.norm(np.where(both[..., None], b, 0.0), axis=-1)[both]
         floor = FLOOR_FRAC * (np.median(nb) if nb.size else 1.0)
         return d / np.maximum(nb, max(floor, 1e-30)), int((fa != fb).sum()), int(fa.size)

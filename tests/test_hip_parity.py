@@ -89,7 +89,7 @@ def test_fp16_mode_within_reference_fp16_band(MoGeModel, name, tmp_path_factory)
     model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory)
     kw = dict(case["kwargs"]); kw["use_fp16"] = True
     st = case.get("stride", 1)
-    band = fp16_band(meta)
+    band = fp16_band(meta, gold)
     g = golden_infer(gold)
     model.onnx_compatible_mode = bool(case.get("onnx"))
     try:
@@ -117,7 +117,7 @@ def test_fp16_throughput_kernels_in_the_model_match_reference_golden(MoGeModel, 
     model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory)
     kw = dict(case["kwargs"]); kw["use_fp16"] = True
     st = case.get("stride", 1)
-    band, g = fp16_band(meta), golden_infer(gold)
+    band, g = fp16_band(meta, gold), golden_infer(gold)
     try:
         model.half()
         base = model.infer(x, **kw)
@@ -334,5 +334,6 @@ def test_fp16_mode_on_constant_images_stays_in_band(MoGeModel, tmp_path_factory,
     for k in ("points", "depth", "intrinsics"):
         a = out[k].float().cpu().numpy()
         assert np.isfinite(a).all(), k
-    band = fp16_band(load_case("tiny_b2_up")[5])            # same model: the reference's fp16 drift measured on an ordinary image
+    _c = load_case("tiny_b2_up")
+    band = fp16_band(_c[5], _c[4])            # same model: the reference's fp16 drift measured on an ordinary image
     check_fp16({k: out[k] for k in ref}, ref, {k: 2 * v for k, v in band.items()})

@@ -62,7 +62,7 @@ def test_v1_fp16_mode_within_reference_fp16_band(name, tmp_path_factory):
     model = get_model(case, tmp_path_factory)
     kw = dict(case["kwargs"]); kw["use_fp16"] = True
     st = case.get("stride", 1)
-    band = fp16_band(meta)
+    band = fp16_band(meta, gold)
     g = {k[6:]: v for k, v in gold.items() if k.startswith("infer.")}
     try:
         out = model.float().infer(x, **kw)

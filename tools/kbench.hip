@@ -353,13 +353,16 @@ static int bench_attn(int iters) {
         ref_attn<<<ns, 256, 0, st>>>(q, k, v, dbh, dq, c.Ntok, ref);
         CK(hipStreamSynchronize(st));
         // exp: ATTN_EXP (32x32x16 kernels), var: ATTN_VAR bits of attn_pp16_kernel - both need a library built with --experiments
-        struct Var { const char* name; int kind, exp, var; };
-        std::vector<Var> vars = {{"pp16", 1, 0, 0}};
+        struct Var { const char* name; int kind, exp, var; int kern = 0; };
+        std::vector<Var> vars = {{"pp16", 1, 0, 0, 0}, {"pp16m", 1, 0, 0, 1}};
         if (getenv("KB_EXP")) vars = {{"old(vT)", 0, 0, 0}, {"x:pp32 nw4", 1, 1, 0}, {"pp16", 1, 0, 0}, {"x:noexp", 1, 0, 1}, {"x:noguard", 1, 0, 2}, {"x:ks-outer", 1, 0, 4},
                                       {"x:ks+noguard", 1, 0, 6}, {"x:maxguard", 1, 0, 8}, {"x:ks+maxguard", 1, 0, 12}};
+        if (getenv("KB_ABL")) vars = {{"pp16", 1, 0, 0}, {"x:noguard", 1, 0, 2}, {"x:nosum", 1, 0, 16}, {"x:nosum+noguard", 1, 0, 18}, {"x:nosum+ng+noexp", 1, 0, 19}, {"x:halfVreads", 1, 0, 32},
+                                      {"x:hV+nosum+ng", 1, 0, 50}, {"x:hV+nosum+ng+noexp", 1, 0, 51}};
         for (const Var& va : vars) {
             moge_tune_set("ATTN_EXP", va.exp);
             moge_tune_set("ATTN_VAR", va.var);
+            moge_tune_set("ATTN_KERN", va.kern);
             auto run = [&]() { return va.kind == 0 ? launch_attention<f16>(q, k, vT, out, c.B, c.nh, c.Ntok, Npad, st) : launch_attention_pp(q, k, v, out, c.B, c.nh, c.Ntok, st); };
             CK(hipMemsetAsync(out, 0, n * 2, st));
             int rc = run();
