@@ -33,7 +33,7 @@ def main(tag):
         "kernel": "gemm_pp128m16_kernel", "launches": calls,
         "fetch_bytes_per_launch": round(fb / calls), "write_bytes_per_launch": round(wb / calls),
         "traffic_bytes_per_launch": round((fb + wb) / calls),
-        "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs, --kernel-trace only) of `python bench.py --steps 3 "
+        "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs, --kernel-trace only) of `python bench.py --steps 2 "
                   f"--warmup 1` with MOGE_BATCH_SPLIT=0; profiles/{tag}_pmc_FETCH_SIZE.csv + profiles/{tag}_pmc_WRITE_SIZE.csv; KiB -> bytes; "
                   "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); Infinity-Cache hits are "
                   "counted, so this is fabric traffic = an upper bound on HBM bytes",
