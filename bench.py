@@ -15,7 +15,7 @@ The workload is the SAME at every N (moge-2-vitl, the config BASELINE.json's met
 form one weak-scaling curve; `--config moge-2-vitl-normal` is BASELINE configs[3], `--shape mixed` configs[4].
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline        the dominant kernel, gemm_pp128m16_kernel (every launch of it and nothing else: profiler class gemm_pp): algorithmic FLOPs /
+  roofline        the dominant kernel, gemm_pp128p_kernel (every launch of it and nothing else: profiler class gemm_pp): algorithmic FLOPs /
                   HIP-event time on the launch stream over the same K steps run single-stream right after the timed region; `traffic` =
                   fabric bytes per launch from the committed rocprofv3 PMC passes (moge_amd/pmc_traffic.json, default workload only)
   rccl            N>1: ranks RCCL saw (all-reduce of ones), bytes and seconds of the one-time weight broadcast
@@ -274,7 +274,7 @@ def main():
         if prof is not None:
             gm = prof["gemm_pp"] if prof["gemm_pp"]["launches"] else prof["gemm"]
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
-            res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp128m16_kernel: all of its launches and only those (ViT qkv / proj / fc1 / fc2 + summed out-projection, "
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp128p_kernel (persistent ping-pong GEMM): all of its launches and only those (ViT qkv / proj / fc1 / fc2 + summed out-projection, "
                                                               "v_mfma_f32_16x16x32_f16)" if prof["gemm_pp"]["launches"] else "gemm_glds_kernel / gemm_kernel (latency-regime GEMMs; no ping-pong launch in this workload)",
                                "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4),
                                "traffic": None, "avg_launch_ms": round(gm["ms"] / max(gm["launches"], 1), 4), "launches": gm["launches"],

@@ -277,164 +277,9 @@ __device__ __forceinline__ void pp_epilogue16(const GemmArgs& g, f32x4 (&acc)[8]
     }
 }
 
-template <int EPK>
-__global__ __launch_bounds__(256, 1) void gemm_pp4w16_kernel(const GemmArgs g) {
-    constexpr int BM = 256, BN = 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 160 KiB
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi = lane >> 5, l31 = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int nbn = g.N / BN;
-    int wg;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    }
-    int bm, bn;
-    {
-        const int nbm = (g.M + BM - 1) / BM;
-        const int grp_cols = 4, per_grp = nbm * grp_cols;
-        const int cg = wg / per_grp, rem = wg - cg * per_grp;
-        const int cols = min(grp_cols, nbn - cg * grp_cols);
-        bm = rem / cols;
-        bn = cg * grp_cols + (rem - bm * cols);
-    }
-    const int m0 = bm * BM, n0 = bn * BN;
-    const int nkt = g.K >> 6;
-
-    // DMA pieces (8 rows x 128 B).  W: rows (wave + 4 kw) * 8, kw = 0..7.  A lo / hi (k = 0..3): rows (k >> 1) * 128 [+ 64] + (k & 1) * 32 + wave * 8.
-    // All piece bases are multiples of 8 with (base >> 1) & 7 = 4 * (wave & 1): one swizzle term per lane.
-    const int prow = lane >> 3;
-    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) + (lane >> 4));
-    const char* baseW = reinterpret_cast<const char*>(g.w) + (size_t)n0 * g.ldw * 2;
-    const char* baseA = reinterpret_cast<const char*>(g.a) + (size_t)m0 * g.lda * 2;
-    unsigned offW[8], offAlo[4], offAhi[4];
-    const int mlast = g.M - 1 - m0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) offW[k] = (unsigned)(((wave + 4 * k) * 8 + prow) * g.ldw * 2 + lchunk * 16);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int r0 = (k >> 1) * 128 + (k & 1) * 32 + wave * 8 + prow, r1 = r0 + 64;
-        r0 = r0 < mlast ? r0 : mlast;
-        r1 = r1 < mlast ? r1 : mlast;
-        offAlo[k] = (unsigned)(r0 * g.lda * 2 + lchunk * 16);
-        offAhi[k] = (unsigned)(r1 * g.lda * 2 + lchunk * 16);
-    }
-    auto issue_w = [&](int t, int k0) {           // 4 of the 8 W pieces of K-tile t
-        char* base = smem + 98304 + (t & 1) * 32768;
-        const char* gw = uniform_ptr(baseW + (size_t)t * 128);
-#pragma unroll
-        for (int k = k0; k < k0 + 4; k++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[k]), PP_LPTR(base + (wave + 4 * k) * 1024), 16, 0, 0);
-    };
-    auto issue_a = [&](int t, int slot, int hi_rows) {
-        char* base = smem + slot * 32768 + hi_rows * 8192;
-        const char* ga = uniform_ptr(baseA + (size_t)t * 128);
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + (hi_rows ? offAhi[k] : offAlo[k])), PP_LPTR(base + ((k >> 1) * 128 + (k & 1) * 32 + wave * 8) * 128), 16, 0, 0);
-    };
-
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const int sx = (l15 >> 1) & 7;
-    const int a_off = (wm * 128 + l15) * 128 + ((g4 ^ sx) << 4);             // K-step k2 (32 halves): a_off ^ (k2 * 64); 16-row block i: + i * 2048
-    const int w_off = (wn * 128 + l15) * 128 + ((g4 ^ sx) << 4);
-
-    f32x4 acc[8][8];                             // [16-row block][16-column block] of the wave's 128 x 128
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // prologue: the issue order continues the steady-state queue  L(s): W(s+2) A_hi(s+2) A_lo(s+3)
-    issue_a(0, 0, 0); issue_w(0, 0); issue_w(0, 4); issue_a(0, 0, 1);
-    if (nkt > 1) { issue_a(1, 1, 0); issue_w(1, 0); issue_w(1, 4); issue_a(1, 1, 1); }
-    if (nkt > 2) issue_a(2, 2, 0);
-    if (nkt > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");          // A_lo(0), W(0) landed
-    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    u32x4 af[4][2], wf[8][2];                    // [16-row block][K-step of 32]
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) wf[j][ks] = *reinterpret_cast<const u32x4*>(smem + 98304 + (w_off ^ (ks * 64)) + j * 2048);
-#pragma unroll
-        for (int i = 0; i < 4; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(smem + (a_off ^ (ks * 64)) + i * 2048);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    int sa = 0;                                   // t mod 3
-    for (int t = 0; t < nkt; t++) {
-        const char* sl = smem + sa * 32768;
-        const int sn = sa == 2 ? 0 : sa + 1;
-        const int sa2 = sa == 0 ? 2 : sa - 1;                                              // (t + 2) mod 3
-        const char* sl_n = smem + sn * 32768;
-        const char* slw_n = smem + 98304 + ((t + 1) & 1) * 32768;
-        // ======== L(t) ========
-        if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // ======== C_a(t) ========
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-#pragma unroll
-            for (int ih = 0; ih < 2; ih++) {                 // two 16-row blocks at a time: 16 MFMAs, then their A registers are reloaded
-#pragma unroll
-                for (int i = 2 * ih; i < 2 * ih + 2; i++)
-#pragma unroll
-                    for (int j = 0; j < 8; j++) mma16<f16>(acc[i][j], wf[j][ks], af[i][ks]);
-#pragma unroll
-                for (int i = 2 * ih; i < 2 * ih + 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 64)) + (4 + i) * 2048);
-                const int c = ks * 2 + ih;
-                if (c < 2) { if (t + 2 < nkt) issue_w(t + 2, c * 4); }
-                else if (c == 2) { if (t + 2 < nkt) issue_a(t + 2, sa2, 1); }
-                else { if (t + 3 < nkt) issue_a(t + 3, sa, 0); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // ======== C_b(t) ========
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-#pragma unroll
-            for (int ih = 0; ih < 2; ih++) {
-#pragma unroll
-                for (int i = 2 * ih; i < 2 * ih + 2; i++)
-#pragma unroll
-                    for (int j = 0; j < 8; j++) mma16<f16>(acc[4 + i][j], wf[j][ks], af[i][ks]);
-#pragma unroll
-                for (int i = 2 * ih; i < 2 * ih + 2; i++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl_n + (a_off ^ (ks * 64)) + i * 2048);
-                if (ih == 1) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) wf[j][ks] = *reinterpret_cast<const u32x4*>(slw_n + (w_off ^ (ks * 64)) + j * 2048);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        sa = sn;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the (unused) fragment reads of the last C_b
-    __builtin_amdgcn_s_barrier();                            // every wave is done with the rings: private epilogue regions
-    asm volatile("" ::: "memory");
-    pp_epilogue16<EPK>(g, acc, 0, smem, wave, lane, m0 + wm * 128, n0 + wn * 128);
-    pp_epilogue16<EPK>(g, acc, 4, smem, wave, lane, m0 + wm * 128, n0 + wn * 128 + 64);
-}
-
-template <int EPK>
-static int launch_pp4w16(const GemmArgs& g, hipStream_t st) {
-    constexpr int smem = 163840;
-    constexpr auto kern = gemm_pp4w16_kernel<EPK>;
-    if (int rc = set_dyn_lds<kern>(smem)) return rc;
-    const long nbm = (g.M + 255) / 256, nbn = g.N / 256;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(256), smem, st, g);
-    return (int)hipGetLastError();
-}
+#ifdef MOGE_EXPERIMENTS
+#include "experiments/gemm_pp4w16_exp.inc"     // 4-wave form (128 x 128 per wave): slower on every hot-path shape, tools/kbench A-B builds only
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------------
 // gemm_pp128 (A3 rings, 8 waves, ping-pong) with v_mfma_f32_16x16x32_f16: per phase 4 row blocks x 4 column blocks x 2 K-steps of 32
@@ -579,6 +424,432 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128m16_kernel(const GemmArgs g)
     pp_epilogue16<EPK, 4>(g, acc, 0, smem, wave, lane, m0 + wm * 128, n0 + wn * 64);
 }
 
+// ---- the epilogue of the persistent kernel: staging region of SROWS (64 / 32) rows per wave, 128 / SROWS row passes ------------------
+// Split in two so that the kernel can request the NEXT tile's first DMA pieces in between:
+//   pp_epi_pre   every load the epilogue needs before its first store (bias / LayerScale / folded-LN vectors, the first residual rows).
+//                Issued BEFORE the DMA prefetch: vmcnt retires in order, so a load issued behind the prefetch would be waited for
+//                together with it (the compiler's s_waitcnt vmcnt(0) in front of the first use exposed the whole prefetch latency).
+//   pp_epi_run   arithmetic, staging, stores.  All stores are raw buffer stores without branches (rows >= M are given an offset outside
+//                the descriptor and dropped): the staging reads of a pass are issued together instead of one read-wait-store per row, and
+//                the number of memory instructions behind the prefetch is a constant - the tile-head wait counts them (PP_TRAIL).
+template <int EPKX, int SROWS> struct PpEpiPre {
+    f32x4 bq[4], lq[4], wuq[4], wvq[4];
+    float mu[8], rs[8], u[8], vv[8];
+    f32x4 x0[SROWS / 8];
+    ResidBufs rb;
+    __amdgpu_buffer_rsrc_t ob;
+    float scale;
+    bool fold;
+};
+constexpr unsigned PP_OOB = 0xffffff00u;
+
+template <int EPKX, int SROWS>
+__device__ __forceinline__ void pp_epi_pre(const GemmArgs& g, PpEpiPre<EPKX, SROWS>& P, int lane, int mw, int nw) {
+    constexpr int EPK = EpkBase<EPKX>::K;
+    constexpr bool FOLD = EpkBase<EPKX>::FOLD;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int M = g.M;
+    if constexpr (EPK == EPK_RESID) {
+        P.rb = pp_resid_bufs(g);
+        P.fold = g.x16 != nullptr;
+        pp_resid_load<SROWS>(P.rb, lane, mw, nw, P.x0);
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int n = nw + jj * 16 + 4 * g4;
+            P.bq[jj] = *reinterpret_cast<const f32x4*>(g.bias + n);
+            P.lq[jj] = *reinterpret_cast<const f32x4*>(g.gamma + n);
+        }
+    } else {
+        P.scale = 1.f;
+        if constexpr (EPK == EPK_QKV) P.scale = nw < g.D ? g.qscale : 1.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { P.u[i] = 0.f; P.vv[i] = 0.f; P.mu[i] = 0.f; P.rs[i] = 1.f; }
+        if constexpr (EPK == EPK_UV) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int m = mw + i * 16 + l15;
+                m = m < M ? m : M - 1;
+                const int x = m % g.pixW, y = (m / g.pixW) % g.pixH;
+                P.u[i] = linspace_at(g.uv.u0, g.uv.u1, g.uv.ustep, g.pixW, x);
+                P.vv[i] = linspace_at(g.uv.v0, g.uv.v1, g.uv.vstep, g.pixH, y);
+            }
+        }
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int m = mw + i * 16 + l15;
+                m = m < M ? m : M - 1;
+                const f32x2 t = *reinterpret_cast<const f32x2*>(g.ln_mr + 2 * (size_t)m);
+                P.mu[i] = t[0]; P.rs[i] = t[1];
+            }
+        }
+        const bool has_bias = g.bias != nullptr;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int n = nw + jj * 16 + 4 * g4;
+            P.bq[jj] = f32x4{0.f, 0.f, 0.f, 0.f}; P.lq[jj] = P.bq[jj]; P.wuq[jj] = P.bq[jj]; P.wvq[jj] = P.bq[jj];
+            if (has_bias) P.bq[jj] = *reinterpret_cast<const f32x4*>(g.bias + n);
+            if constexpr (FOLD) P.lq[jj] = *reinterpret_cast<const f32x4*>(g.ln_c + n);
+            if constexpr (EPK == EPK_UV) {
+                P.wuq[jj] = *reinterpret_cast<const f32x4*>(g.uv.wu + n);
+                P.wvq[jj] = *reinterpret_cast<const f32x4*>(g.uv.wv + n);
+            }
+        }
+        // output descriptor: exactly the bytes the GEMM may write (pp_persistent_ok() has checked they fit 32-bit offsets)
+        if constexpr (EPK == EPK_QKV) {
+            const int which = nw / g.D;
+            P.ob = __builtin_amdgcn_make_buffer_rsrc(which == 0 ? g.q : (which == 1 ? g.k : g.vT), 0, (int)((unsigned)M * (unsigned)g.nh * 128u), 0x00020000);
+        } else if constexpr (EPK == EPK_CONVT) {
+            P.ob = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)((unsigned)M * (unsigned)g.Cout * 8u), 0x00020000);
+        } else {
+            P.ob = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)((unsigned)M * (unsigned)g.ldc * 2u), 0x00020000);
+        }
+    }
+}
+
+// staging rows (64 f16 columns, 16-byte chunks swizzled by row & 7) -> global memory, SROWS / 8 unconditional 16-byte buffer stores per lane
+template <int SROWS, int EPK>
+__device__ __forceinline__ void pp_store_rows_buf(const GemmArgs& g, __amdgpu_buffer_rsrc_t ob, const char* R, int lane, int mw, int nw) {
+    const int rr = lane >> 3, cc = lane & 7;
+    const int M = g.M;
+    const int mfirst = mw + rr;
+    u32x4 v[SROWS / 8];
+#pragma unroll
+    for (int it = 0; it < SROWS / 8; it++) {
+        const int row = it * 8 + rr;
+        v[it] = *reinterpret_cast<const u32x4*>(R + row * 128 + ((cc ^ (row & 7)) << 4));
+    }
+    if constexpr (EPK == EPK_QKV) {
+        const int which = nw / g.D;
+        const int head = (nw - which * g.D) >> 6;
+        const int Ntok = g.Ntok;
+        const unsigned base = (unsigned)head * (unsigned)Ntok * 128u + (unsigned)cc * 16u;
+        const unsigned bstride = (unsigned)g.nh * (unsigned)Ntok * 128u;
+        int b0 = mfirst / Ntok;
+        int t0 = mfirst - b0 * Ntok;
+#pragma unroll
+        for (int it = 0; it < SROWS / 8; it++) {
+            unsigned off = base + (unsigned)b0 * bstride + (unsigned)t0 * 128u;
+            if (mfirst + it * 8 >= M) off = PP_OOB;
+            t0 += 8;
+            if (t0 >= Ntok) { t0 -= Ntok; b0 += 1; }
+            __builtin_amdgcn_raw_buffer_store_b128(v[it], ob, (int)off, 0, 0);
+        }
+    } else if constexpr (EPK == EPK_CONVT) {
+        const int Cout = g.Cout, pixW = g.pixW, pixH = g.pixH;
+        const int qd = nw / Cout;
+        const int co0 = nw - qd * Cout, dy = qd >> 1, dx = qd & 1;
+        int px = mfirst % pixW;
+        const int t = mfirst / pixW;
+        int py = t % pixH, pb = t / pixH;
+#pragma unroll
+        for (int it = 0; it < SROWS / 8; it++) {
+            unsigned off = ((((unsigned)pb * 2u * pixH + 2u * py + dy) * (2u * pixW)) + 2u * px + dx) * ((unsigned)Cout * 2u) + (unsigned)(co0 + cc * 8) * 2u;
+            if (mfirst + it * 8 >= M) off = PP_OOB;
+            px += 8;
+            if (px >= pixW) { px -= pixW; py += 1; if (py >= pixH) { py = 0; pb += 1; } }
+            __builtin_amdgcn_raw_buffer_store_b128(v[it], ob, (int)off, 0, 0);
+        }
+    } else {
+        const unsigned ldc2 = (unsigned)g.ldc * 2u;
+        const unsigned off0 = (unsigned)mfirst * ldc2 + (unsigned)(nw + cc * 8) * 2u;
+#pragma unroll
+        for (int it = 0; it < SROWS / 8; it++)
+            __builtin_amdgcn_raw_buffer_store_b128(v[it], ob, (int)(mfirst + it * 8 < M ? off0 + (unsigned)it * 8u * ldc2 : PP_OOB), 0, 0);
+    }
+}
+
+// mid(): called once, at the first point behind which the epilogue has no load left that the COMPILER waits for (it places s_waitcnt vmcnt(0)
+// in front of the first use of any ordinary load while LDS-DMA is in flight): the kernel requests the next tile's first pieces there.
+// Behind it follow PpTrail<> unconditional stores per lane.
+template <int EPKX, int SROWS> struct PpTrail { static constexpr int N = EpkBase<EPKX>::K == EPK_RESID ? SROWS / 8 : 16; };
+template <int EPKX, int SROWS, class Mid>
+__device__ __forceinline__ void pp_epi_run(const GemmArgs& g, f32x4 (&acc)[8][4], PpEpiPre<EPKX, SROWS>& P, char* R, int lane, int mw, int nw, Mid mid) {
+    constexpr int EPK = EpkBase<EPKX>::K;
+    constexpr bool FOLD = EpkBase<EPKX>::FOLD;
+    constexpr int NI = SROWS / 16, NP = 128 / SROWS;
+    const int l15 = lane & 15, g4 = lane >> 4;
+
+    if constexpr (EPK == EPK_RESID) {
+        f32x4 x1[SROWS / 8];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[i][jj][e] = resid_term(P.lq[jj][e], acc[i][jj][e], P.bq[jj][e]);
+#pragma unroll
+        for (int p = 0; p < 2 * NP; p++) {                   // pass p: rows (p >> 1) * SROWS .., columns (p & 1) * 32 ..
+            const int ih = p >> 1, J = p & 1;
+            f32x4 (&xc)[SROWS / 8] = (p & 1) ? x1 : P.x0;
+            f32x4 (&xn)[SROWS / 8] = (p & 1) ? P.x0 : x1;
+#pragma unroll
+            for (int jh = 0; jh < 2; jh++)
+#pragma unroll
+                for (int ii = 0; ii < NI; ii++) {
+                    const int row = ii * 16 + l15;
+                    *reinterpret_cast<f32x4*>(R + row * 128 + (((jh * 4 + g4) ^ (row & 7)) << 4)) = acc[ih * NI + ii][J * 2 + jh];
+                }
+            pp_resid_add<SROWS>(R, lane, xc);
+            if (p + 1 < 2 * NP) pp_resid_load<SROWS>(P.rb, lane, mw + ((p + 1) >> 1) * SROWS, nw + ((p + 1) & 1) * 32, xn);
+            else mid();
+            pp_resid_store<SROWS>(P.rb, P.fold, lane, mw + ih * SROWS, nw + J * 32, xc);
+        }
+    } else {
+#pragma unroll
+        for (int ih = 0; ih < NP; ih++) {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+                for (int ii = 0; ii < NI; ii++) {
+                    const int row = ii * 16 + l15, i = ih * NI + ii;
+                    const f16x4 hv = pp_quad_f16<EPK, FOLD>(acc[i][jj], P.bq[jj], P.scale, P.wuq[jj], P.u[i], P.wvq[jj], P.vv[i], P.mu[i], P.rs[i], P.lq[jj]);
+                    *reinterpret_cast<f16x4*>(R + row * 128 + ((((jj * 2 + (g4 >> 1)) ^ (row & 7)) << 4) | ((g4 & 1) << 3))) = hv;
+                }
+            if (ih == 0) mid();
+            pp_store_rows_buf<SROWS, EPK>(g, P.ob, R, lane, mw + ih * SROWS, nw);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// gemm_pp128p_kernel: gemm_pp128m16_kernel as a PERSISTENT kernel - one workgroup per CU walks a list of output tiles.
+// Why: a K = 1024 tile is a 23 us main loop (16 ring steps) + ~8 us of workgroup launch, cold prologue (144 KiB of DMA before the first
+// MFMA) and epilogue; with one 160 KiB workgroup per CU nothing of that overlaps (the next workgroup cannot start before this one has
+// left).  Here the next tile's first ring pieces (A step 0, W steps 0 and 1: 96 KiB) are requested BEFORE the epilogue of the current
+// tile and land while it runs; the epilogue stages through the other 64 KiB of the ring (A slots 1 and 2, 8 KiB per wave, 64-row passes).
+// Tiles: each XCD owns a contiguous range of the (grouped) tile order, its workgroups (blockIdx & 7 = XCD) take consecutive tiles of it,
+// so the A rows / W columns a round works on are shared in that XCD's L2 as in the one-tile-per-workgroup kernel.
+// Queue order of a tile's DMA: A0 W0 W1 | epilogue loads, stores | A1 A2lo | A2hi W2 A3lo ... : the steady-state vmcnt(10) of the ring
+// (leaves A(t+2)lo A(t+2)hi W(t+2) A(t+3)lo) holds from t = 0 on; the tile-head wait is vmcnt(6) (A1 A2lo stay in flight).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int EPK, int SROWS>
+__global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
+    constexpr int WN = 4, BM = 256, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * 32 KiB (A ring) + 2 * 32 KiB (W ring)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nbn = g.N / BN, nbm = (g.M + BM - 1) / BM;
+    int li, cnt, start, wgs_x;                               // this workgroup's position in its XCD's tile range
+    {
+        const int ntiles = nbm * nbn, nwg = gridDim.x, xcd = blockIdx.x & 7;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        cnt = q + (xcd < r ? 1 : 0);
+        start = xcd * q + min(xcd, r);
+        wgs_x = (nwg - xcd + 7) >> 3;
+        li = blockIdx.x >> 3;
+    }
+    if (li >= cnt) return;
+    const int nkt = g.K >> 6;
+
+    const int prow = lane >> 3;
+    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) + (lane >> 4));
+    unsigned offW[4], offA[4];     // A: 0,1 = lo rows (8w, 128+8w)   2,3 = hi rows (64+8w, 192+8w)
+#pragma unroll
+    for (int k = 0; k < 4; k++) offW[k] = (unsigned)(((wave + 8 * k) * 8 + prow) * g.ldw * 2 + lchunk * 16);
+    const char* baseW;
+    const char* baseA;
+    int m0n, n0n;
+    auto setup = [&](int idx) {                               // tile idx of the grouped order (4 tile columns per group, rows inside)
+        const int wg = start + idx;
+        const int grp_cols = g.dbg > 0 ? g.dbg : 8, per_grp = nbm * grp_cols;
+        const int cg = wg / per_grp, rem = wg - cg * per_grp;
+        const int cols = min(grp_cols, nbn - cg * grp_cols);
+        const int bm = rem / cols;
+        const int bn = cg * grp_cols + (rem - bm * cols);
+        m0n = bm * BM; n0n = bn * BN;
+        baseW = reinterpret_cast<const char*>(g.w) + (size_t)n0n * g.ldw * 2;
+        baseA = reinterpret_cast<const char*>(g.a) + (size_t)m0n * g.lda * 2;
+        const int mlast = g.M - 1 - m0n;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int arow = (k & 1) * 128 + (k >> 1) * 64 + wave * 8 + prow;
+            arow = arow < mlast ? arow : mlast;
+            offA[k] = (unsigned)(arow * g.lda * 2 + lchunk * 16);
+        }
+    };
+    auto issue_w = [&](int t) {
+        char* base = smem + 98304 + (t & 1) * 32768;
+        const char* gw = uniform_ptr(baseW + (size_t)t * 128);
+#pragma unroll
+        for (int kw = 0; kw < 4; kw++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[kw]), PP_LPTR(base + (wave + 8 * kw) * 1024), 16, 0, 0);
+    };
+    auto issue_a = [&](int t, int slot, int hi_rows) {
+        char* base = smem + slot * 32768;
+        const char* ga = uniform_ptr(baseA + (size_t)t * 128);
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + offA[hi_rows * 2 + k]), PP_LPTR(base + (k * 128 + hi_rows * 64 + wave * 8) * 128), 16, 0, 0);
+    };
+    auto prefetch = [&]() {                                   // the pieces that do not touch the staging region (A slots 1, 2)
+        // straight-line (K >= 192 is a launch condition): a branch in here makes the compiler wait vmcnt(0) for the epilogue's loads behind it
+        issue_a(0, 0, 0); issue_a(0, 0, 1);
+        issue_w(0);
+        issue_w(1);
+    };
+
+    const int sx = (l15 >> 1) & 7;
+    const int a_off = (wm * 128 + l15) * 128 + ((g4 ^ sx) << 4);
+    const int w_off = (wn * 64 + l15) * 128 + ((g4 ^ sx) << 4);
+    char* R = smem + 32768 + wave * (SROWS * 128);
+
+#ifdef MOGE_EXPERIMENTS
+    // tools/kbench KB_TS: s_memtime stamps (100 MHz) of waves 0 and 4 of one workgroup over its first 6 tiles
+    unsigned long long* ts = (g.dbg_ts && blockIdx.x == 8 && lane == 0 && (wave & 3) == 0) ? g.dbg_ts + (wave >> 2) * 48 : nullptr;
+    int ts_tile = 0;
+#define PP_STAMP(k) do { if (ts && ts_tile < 6) ts[ts_tile * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PP_STAMP(k) do { } while (0)
+#endif
+    setup(li);
+    prefetch();
+    bool first = true;
+    for (;;) {
+        const int m0 = m0n, n0 = n0n;
+        PP_STAMP(0);
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // tile head: the prefetched pieces (A0 W0 W1) are OLDER than the previous epilogue's last PP_TRAIL memory instructions (stores);
+        // those may stay in flight
+        constexpr int PP_TRAIL = PpTrail<EPK, SROWS>::N, POST = 6;
+        issue_a(1, 1, 0); issue_a(1, 1, 1);
+        issue_a(2, 2, 0);
+        if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(POST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(POST + PP_TRAIL) : "memory");
+        first = false;
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(1);
+
+        u32x4 af[4][2], wf[4][2];
+        int sa = 0;
+        for (int t = 0; t < nkt; t++) {
+            const char* sl = smem + sa * 32768;
+            const char* slw = smem + 98304 + (t & 1) * 32768;
+            const int sa2 = sa == 0 ? 2 : sa - 1;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                if (half == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ks++) wf[j][ks] = *reinterpret_cast<const u32x4*>(slw + (w_off ^ (ks * 64)) + j * 2048);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 64)) + (half * 4 + i) * 2048);
+                if (half == 0) {
+                    if (t + 2 < nkt) issue_a(t + 2, sa2, 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
+                    if (t + 3 < nkt) {
+                        issue_w(t + 2);
+                        issue_a(t + 3, sa, 0);
+                        asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+                    } else if (t + 2 < nkt) {
+                        issue_w(t + 2);
+                        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    }
+                }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) mma16<f16>(acc[half * 4 + i][j], wf[j][ks], af[i][ks]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" ::: "memory");
+                if (!(grp == 1 && half == 1 && t == nkt - 1)) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sa = sa == 2 ? 0 : sa + 1;
+        }
+        // every LDS read of the ring is complete (the other group's last load segment ended before the barrier this wave has passed)
+        PP_STAMP(2);
+        PpEpiPre<EPK, SROWS> pre;
+        pp_epi_pre<EPK, SROWS>(g, pre, lane, m0 + wm * 128, n0 + wn * 64);
+        li += wgs_x;
+        const bool more = li < cnt;
+        PP_STAMP(3);
+        auto mid = [&]() {
+            // every load of the epilogue has been issued long ago: tell the compiler they are complete (a real S_WAITCNT it accounts for: vmcnt(0), other
+            // counters untouched; some results are first USED later, and its own wait there would be vmcnt(0) behind the DMA), then
+            // request the next tile's first pieces - UNCONDITIONALLY (after the last tile: this tile's own pieces again, never read): a branch
+            // here would merge into a conservative wait as well
+            setup(more ? li : li - wgs_x);
+            if constexpr (EpkBase<EPK>::K != EPK_RESID) __builtin_amdgcn_s_waitcnt(0x0F70);      // (RESID: the last row loads were waited for by the add in front)
+            prefetch();
+            asm volatile("" ::: "memory");
+        };
+        pp_epi_run<EPK, SROWS>(g, acc, pre, R, lane, m0 + wm * 128, n0 + wn * 64, mid);
+        PP_STAMP(4);
+#ifdef MOGE_EXPERIMENTS
+        if (ts && ts_tile < 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(5); }      // store drain (perturbs: only the stamped waves wait)
+        ts_tile++;
+#endif
+        if (!more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break; }      // no DMA may land in this CU's LDS after the workgroup has left
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // all staging regions read: A slots 1 and 2 may be refilled
+        asm volatile("" ::: "memory");
+    }
+#undef PP_STAMP
+}
+
+static int pp_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+// the persistent kernel addresses its outputs through buffer descriptors with 32-bit byte offsets
+static bool pp_persistent_ok(const GemmArgs& g) {
+    if (g.K < 192) return false;                             // three ring steps: the kernel's prologue is written without branches
+    const unsigned long long lim = 0xfffff000ull;
+    const unsigned long long M = (unsigned long long)g.M + 256;
+    switch (g.epi) {
+    case EPI_RESID: return M * g.ldc * 4 < lim;
+    case EPI_QKV: return M * g.nh * 128 < lim;
+    case EPI_CONVT: return M * g.Cout * 8 < lim;
+    default: return M * g.ldc * 2 < lim;
+    }
+}
+
+template <int EPK, int SROWS>
+static int launch_pp128p(const GemmArgs& g, hipStream_t st) {
+    constexpr int smem = 163840;
+    constexpr auto kern = gemm_pp128p_kernel<EPK, SROWS>;
+    if (int rc = set_dyn_lds<kern>(smem)) return rc;
+    const long ntiles = (long)((g.M + 255) / 256) * (g.N / 256);
+    long cap = moge_tune_get("PP_GRID", 0);                  // tests: a small grid makes small problems walk many tiles per workgroup
+    if (cap <= 0) cap = pp_num_cus();
+    const long grid = ntiles < cap ? ntiles : cap;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, g);
+    return (int)hipGetLastError();
+}
+
 template <int EPK>
 static int launch_pp128m16(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = 163840;
@@ -656,7 +927,8 @@ static int epilogue_kind(const GemmArgs& g) {
     return EPK_STORE;
 }
 
-// PP_KERN: 0 = gemm_pp128m16_kernel (8 waves, ping-pong groups), 1 = gemm_pp4w16_kernel (4 waves, 128 x 128 per wave), -1 = by shape (default)
+// PP_KERN: 2 = gemm_pp128p_kernel (persistent; what -1, the default, selects; K < 192 or outputs beyond 4 GiB fall back to 0),
+// 0 = gemm_pp128m16_kernel (one tile per workgroup); -DMOGE_EXPERIMENTS builds: 1 = gemm_pp4w16_kernel (4 waves, 128 x 128 per wave)
 template <int EPK>
 static int launch_pp_any(const GemmArgs& g, hipStream_t st) {
 #ifdef MOGE_EXPERIMENTS
@@ -671,8 +943,12 @@ static int launch_pp_any(const GemmArgs& g, hipStream_t st) {
     }
 #endif
     int kern = moge_tune_get("PP_KERN", -1);
-    if (kern < 0) kern = 0;
-    return kern == 1 ? launch_pp4w16<EPK>(g, st) : launch_pp128m16<EPK>(g, st);
+    if (kern < 0) kern = 2;
+    if (kern == 2 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64>(g, st);
+#ifdef MOGE_EXPERIMENTS
+    if (kern == 1) return launch_pp4w16<EPK>(g, st);
+#endif
+    return launch_pp128m16<EPK>(g, st);
 }
 
 int launch_gemm_pp(const GemmArgs& g0, hipStream_t st) {

@@ -4,7 +4,7 @@ PyTorch fp32 reference of the same op, and bit-for-bit against the latency-regim
 Dispatch (gemm.hip launch_gemm): a GEMM goes to the ping-pong kernel when N % 256 == 0, K % 64 == 0 and it has at least PP_MIN_TILES
 (128) tiles of 256x256; everything smaller runs gemm_glds_kernel / gemm_kernel.  The tests pin the kernel under test explicitly:
   force = "pp"      moge_tune_set("PP_MIN_TILES", 0)   -> the ping-pong kernel for every eligible shape; PP_KERN picks which of the two
-                    product kernels (gemm_pp128m16_kernel: 8 waves; gemm_pp4w16_kernel: 4 waves x 128x128) - each test runs both
+                    product kernels (gemm_pp128p_kernel: persistent, the default; gemm_pp128m16_kernel: one tile per workgroup) - each test runs both
   force = "latency" moge_tune_set("GEMM_PP", 0)        -> gemm.hip only
 and also run the full BASELINE shapes (M = 32 x 3601 = 115232 = 450 x 256 + 32: a row tail) under the production dispatch.
 
@@ -29,10 +29,10 @@ def H():
     return hip_util
 
 
-@pytest.fixture(params=[0, 1], ids=["pp128m16", "pp4w16"])
+@pytest.fixture(params=[0, 2], ids=["pp128m16", "pp128p"])
 def kern(request):
-    """The two throughput kernels the library ships: gemm_pp128m16_kernel (8 waves) and gemm_pp4w16_kernel (4 waves); PP_KERN = -1 lets the
-    library choose by shape (the production setting)."""
+    """The throughput kernels the library ships: gemm_pp128p_kernel (persistent, the production default), gemm_pp128m16_kernel (one tile per
+    workgroup: its fallback); PP_KERN = -1 is the production setting."""
     return request.param
 
 
@@ -47,6 +47,8 @@ class Force:
         if self.mode == "pp":
             L.tune("PP_MIN_TILES", 0)
             L.tune("PP_KERN", self.kern)
+            if self.kern >= 2:
+                L.tune("PP_GRID", 24)      # persistent kernel: 3 workgroups per XCD, so even the small shapes walk several tiles each
         elif self.mode == "latency":
             L.tune("GEMM_PP", 0)
         return self
@@ -56,6 +58,7 @@ class Force:
         L.tune("PP_MIN_TILES", 128)
         L.tune("GEMM_PP", 1)
         L.tune("PP_KERN", -1)
+        L.tune("PP_GRID", 0)
 
 
 def h16(t):

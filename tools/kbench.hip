@@ -149,17 +149,18 @@ static int bench_gemm(const char* filter, int iters) {
         {"b4.proj", 4 * Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"b4.fc2", 4 * Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
     };
-    // kern: PP_KERN (0 = gemm_pp128m16_kernel, 1 = gemm_pp4w16_kernel);  exp: PP_EXP (library built with --experiments only: 1/2/3 = gemm_pp128
+    // kern: PP_KERN (0 = gemm_pp128m16_kernel, 2 = gemm_pp128p_kernel (persistent), 1 = gemm_pp4w16_kernel (--experiments));  exp: PP_EXP (library built with --experiments only: 1/2/3 = gemm_pp128
     // 32x32x16 form with A3 = 1/2/0, 4 = gemm_pp4w 32x32x16, 5 = 64-byte-row 256x256, 6 = 64-byte-row 256x128 two workgroups per CU)
     struct Variant { const char* name; int pp, glds, dbg, kern, exp; };
     auto apply = [](const Variant& v) {
         moge_tune_set("GEMM_PP", v.pp); moge_tune_set("PP_MIN_TILES", 0); moge_tune_set("GLDS_VARIANT", v.glds); moge_tune_set("PP_DBG", v.dbg);
         moge_tune_set("PP_KERN", v.kern); moge_tune_set("PP_EXP", v.exp);
     };
-    std::vector<Variant> variants = {{"glds2-m16", 0, 2, 0, 0, 0}, {"pp128-m16", 1, 2, 0, 0, 0}, {"pp4w-16", 1, 2, 0, 1, 0}};
+    std::vector<Variant> variants = {{"glds2-m16", 0, 2, 0, 0, 0}, {"pp128-m16", 1, 2, 0, 0, 0}, {"pp128p", 1, 2, 0, 2, 0}};
     if (getenv("KB_EXP")) variants = {{"pp128-m16", 1, 2, 0, 0, 0}, {"pp4w-16", 1, 2, 0, 1, 0}, {"x:pp128-a3", 1, 2, 0, 0, 1}, {"x:pp128-a3c", 1, 2, 0, 0, 2}, {"x:pp128-2buf", 1, 2, 0, 0, 3},
                                       {"x:pp4w-32", 1, 2, 0, 0, 4}, {"x:pp64", 1, 2, 0, 0, 5}, {"x:pp64-2wg", 1, 2, 0, 0, 6}};
-    if (getenv("KB_PP")) variants = {{"pp128-m16", 1, 2, 0, 0, 0}, {"pp4w-16", 1, 2, 0, 1, 0}};
+    if (getenv("KB_GC")) variants = {{"pp128p", 1, 2, 0, 2, 0}, {"pp128p gc2", 1, 2, 2, 2, 0}, {"pp128p gc8", 1, 2, 8, 2, 0}, {"pp128p gc16", 1, 2, 16, 2, 0}};
+    if (getenv("KB_PP")) variants = {{"pp128-m16", 1, 2, 0, 0, 0}, {"pp128p", 1, 2, 0, 2, 0}};
     int fails = 0;
     for (const Shape& s : shapes) {
         if (filter && !strstr(s.name, filter)) continue;
@@ -227,6 +228,19 @@ static int bench_gemm(const char* filter, int iters) {
                     printf("   ts wave %d: prologue %llu  mainloop %llu  epilogue-issue %llu  store-drain %llu  (memtime ticks)  clock %.0f MHz\n", w, hts[w * 8 + 1] - hts[w * 8],
                            hts[w * 8 + 2] - hts[w * 8 + 1], hts[w * 8 + 3] - hts[w * 8 + 2], hts[w * 8 + 4] - hts[w * 8 + 3],
                            100.0 * (double)(hts[w * 8 + 4] - hts[w * 8]) / (double)(hts[w * 8 + 7] - hts[w * 8 + 6]));
+                CK(hipFree(dts));
+            }
+            if (getenv("KB_TS") && v.pp && v.kern >= 2) {      // persistent kernel (library built with --experiments): per-tile stamps of one workgroup
+                unsigned long long* dts; CK(hipMalloc(&dts, 96 * 8)); CK(hipMemsetAsync(dts, 0, 96 * 8, st));
+                GemmArgs g2 = g; g2.dbg_ts = dts;
+                launch_gemm<f16>(g2, AMODE_LINEAR, st);
+                unsigned long long hts[96]; CK(hipMemcpyAsync(hts, dts, 96 * 8, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+                for (int w = 0; w < 2; w++)
+                    for (int t = 0; t < 6 && hts[w * 48 + t * 8 + 4]; t++) {
+                        const unsigned long long* q = hts + w * 48 + t * 8;
+                        printf("   ts wave %d tile %d: head %5.2f  mainloop %6.2f  epi-loads %5.2f  epilogue %5.2f  store-drain %5.2f   (tile start +%.2f)  [x100 clocks]\n", w * 4, t,
+                               (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01, (q[5] - q[4]) * 0.01, (q[0] - hts[w * 48]) * 0.01);      // "us" = 100 shader clocks
+                    }
                 CK(hipFree(dts));
             }
             const double ms = time_launches(g, iters, st);

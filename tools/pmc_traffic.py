@@ -2,7 +2,7 @@
 """profiles/<tag>_pmc_FETCH_SIZE.csv + profiles/<tag>_pmc_WRITE_SIZE.csv -> moge_amd/pmc_traffic.json (bench.py's roofline.traffic).
 
 Usage: python tools/pmc_traffic.py r01c          (after tools/profile_round.sh <tag> on the GPU box and copying the summaries)
-Per launch of the roofline kernel class (gemm_pp128_kernel, full-size launches only): KiB -> bytes, FETCH_SIZE doubled
+Per launch of the roofline kernel class (gemm_pp128p_kernel, full-size launches only): KiB -> bytes, FETCH_SIZE doubled
 (gfx950 tallies 128-byte requests at 64 B: MI355X_MICROARCH.md, HBM section), WRITE_SIZE as reported.
 """
 import json
@@ -25,12 +25,15 @@ def main(tag):
     W = load(os.path.join(ROOT, "profiles", f"{tag}_pmc_WRITE_SIZE.csv"))
     calls = fb = wb = 0
     for k, (c, f) in F.items():
-        if "gemm_pp128" in k[0] and k[1] >= 1000 and k in W:      # gemm_pp128m16_kernel<EPK> (and the 32x32x16 gemm_pp128_kernel of earlier rounds)
+        # full-size (batch 32) launches only: gemm_pp128p_kernel<EPK> is persistent (one workgroup per CU: 256 blocks; the batch-1 launches of
+        # the latency leg have fewer tiles than CUs), gemm_pp128m16_kernel<EPK> / gemm_pp128_kernel of earlier profiles have one block per tile
+        full = k[1] >= 256 if "gemm_pp128p" in k[0] else k[1] >= 1000
+        if "gemm_pp128" in k[0] and full and k in W:
             calls += c
             fb += c * f * 1024 * 2
             wb += c * W[k][1] * 1024
     out = {
-        "kernel": "gemm_pp128m16_kernel", "launches": calls,
+        "kernel": "gemm_pp128p_kernel", "launches": calls,
         "fetch_bytes_per_launch": round(fb / calls), "write_bytes_per_launch": round(wb / calls),
         "traffic_bytes_per_launch": round((fb + wb) / calls),
         "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs, --kernel-trace only) of `python bench.py --steps 2 "
