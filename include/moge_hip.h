@@ -259,6 +259,21 @@ int moge_test_posembed(const float* pos, float* out, int D, int rows, int cols, 
 int moge_test_recover(const float* points, const uint8_t* mask, const float* focal_in, int B, int H, int W,
                       float* focal, float* shift, int32_t* status, void* stream);
 
+/* ---- optimal-alignment solvers of the evaluation path (reference: moge/utils/alignment.py, called by moge/test/metrics.py:128-282) -------
+ * Stateless (no handle); every pointer is device memory; results are written asynchronously on `stream`.
+ * moge_align_l1: alignment.py:52-89 with trunc=None - per row r: a[r] = argmin_a sum_i w[r,i] |a x[r,i] - y[r,i]|, loss[r] = that sum,
+ * index[r] = the element whose ratio y/x the solution is.  1 <= n <= 15360 (a row is sorted inside one CU's LDS): otherwise MOGE_ERR_INVALID. */
+int moge_align_l1(const float* x, const float* y, const float* w, int rows, int n, float eps, float* a, float* loss, int32_t* index, void* stream);
+/* The anchor searches of alignment.py:163-212 (d = 1), :246-299 (d = 3, comp_mask 0b100) and :302-354 (d = 3, comp_mask 0b111) without their
+ * (anchors, n, d) temporaries: src / tgt (B, n, d), weight (B, n); row r solves batch element row_batch[r] with sample row_anchor[r] subtracted
+ * from the components selected by comp_mask (bit c = component c); outputs as moge_align_l1 over the n*d residuals (n*d <= 15360). */
+int moge_align_l1_anchored(const float* src, const float* tgt, const float* weight, int n, int d, int comp_mask, const int32_t* row_batch,
+                           const int32_t* row_anchor, int rows, float eps, float* scale, float* loss, int32_t* index, void* stream);
+/* scatter_min of alignment.py:13-20 along dim 0: per batch element the minimum loss over its rows and the (last) row attaining it; -1 if none */
+int moge_align_select(const float* loss, const int32_t* row_batch, int rows, int batch, float* min_loss, int32_t* min_row, void* stream);
+/* alignment.py:399-415: per row the least-squares (a, b) of sqrt(w) x a + b ~ sqrt(w) y; w may be NULL (all ones); x, y, w are (rows, n) */
+int moge_align_lstsq(const float* x, const float* y, const float* w, int rows, int n, float* a, float* b, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,10 @@ def _load() -> C.CDLL:
         "moge_test_groupnorm_relu": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, vp]),
         "moge_test_posembed": (C.c_int, [f32p, f32p, i32, i32, i32, vp]),
         "moge_test_recover": (C.c_int, [f32p, vp, f32p, i32, i32, i32, f32p, f32p, vp, vp]),
+        "moge_align_l1": (C.c_int, [f32p, f32p, f32p, i32, i32, C.c_float, f32p, f32p, vp, vp]),
+        "moge_align_l1_anchored": (C.c_int, [f32p, f32p, f32p, i32, i32, i32, vp, vp, i32, C.c_float, f32p, f32p, vp, vp]),
+        "moge_align_select": (C.c_int, [f32p, vp, i32, i32, f32p, vp, vp]),
+        "moge_align_lstsq": (C.c_int, [f32p, f32p, f32p, i32, i32, f32p, f32p, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export what the header declares
@@ -121,7 +125,8 @@ EXPORTS = ["moge_abi_version", "moge_last_error", "moge_create", "moge_create_v1
            "moge_master_blob", "moge_master_ready", "moge_set_precision", "moge_set_onnx_compatible_mode", "moge_workspace_bytes", "moge_forward", "moge_infer",
            "moge_postprocess", "moge_depth_edge_mask", "moge_sync", "moge_profile_enable", "moge_profile_read", "moge_debug_tap", "moge_tune_set", "moge_test_gemm",
            "moge_test_gemm_ex", "moge_test_layernorm", "moge_test_attention", "moge_test_conv3x3", "moge_test_convt2x2", "moge_test_preprocess",
-           "moge_test_resize_bicubic_aa", "moge_test_groupnorm_relu", "moge_test_posembed", "moge_test_recover"]
+           "moge_test_resize_bicubic_aa", "moge_test_groupnorm_relu", "moge_test_posembed", "moge_test_recover",
+           "moge_align_l1", "moge_align_l1_anchored", "moge_align_select", "moge_align_lstsq"]
 
 
 def check(code: int) -> None:

@@ -242,6 +242,7 @@ inline int set_dyn_lds(int bytes) {
 // host-side launchers (gemm.hip, gemm_pp.hip)
 template <typename T> int launch_gemm(const GemmArgs& g, int amode, hipStream_t st);
 bool gemm_pp_eligible(const GemmArgs& g);
+void moge_internal_set_error(const char* msg);      // model.hip: text behind moge_last_error()
 bool gemm_runs_pp(const GemmArgs& g);       // launch_gemm<f16>(g, AMODE_LINEAR) will take the ping-pong throughput kernel (profiler class)
 int launch_gemm_pp(const GemmArgs& g, hipStream_t st);
 bool conv_pp_eligible(const GemmArgs& g);

@@ -29,6 +29,7 @@ static int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+void moge_internal_set_error(const char* msg) { g_err = msg; }     // for the stateless entry points outside this file (alignment.hip)
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MOGE_ERR_HIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 #define LCHK(x) do { int e_ = (x); if (e_ != 0) return fail(e_ < 0 ? MOGE_ERR_INVALID : MOGE_ERR_HIP, "%s: launch failed (%d: %s) (%s:%d)", #x, e_, e_ > 0 ? hipGetErrorString((hipError_t)e_) : "unsupported shape", __FILE__, __LINE__); } while (0)
 #define CHK(x) do { int e_ = (x); if (e_ != 0) return e_; } while (0)
