@@ -8,7 +8,7 @@ import sys
 
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
-    name = re.sub(r"\(.*", "", r["Kernel_Name"])[:60]
+    name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))[:60]
     gs = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
     wg = int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", 1)) or 1)
     blocks = gs // max(wg, 1)

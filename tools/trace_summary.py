@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
-    name = re.sub(r"\(.*", "", r["Kernel_Name"])
+    name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
     name = re.sub(r"^void ", "", name)[:60]
     gs = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
     wg = int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", 1)) or 1)
