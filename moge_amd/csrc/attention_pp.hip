@@ -383,36 +383,30 @@ __global__ __launch_bounds__(256, 3) void attn_pp16m_kernel(const f16* __restric
     const char* kbase = reinterpret_cast<const char*>(k + (size_t)bh * Ntok * 64);
     const char* vbase = reinterpret_cast<const char*>(v + (size_t)bh * Ntok * 64);
     const int prow = lane >> 3, pch = lane & 7;
-    int drow[NPW];
-    unsigned doff[NPW];
+    // DMA source offsets of this lane's pieces: doff for every tile but the last, doff_last for the last one (rows past Ntok - 1 re-read row
+    // Ntok - 1; they are masked in exact_block).  Both are loop constants: computing the clamp at issue time put 4 VALU per piece into every
+    // iteration of an issue-bound loop (the compiler merges the two sides of `t < ntiles - 1` and selects between the addresses).
+    unsigned doff[NPW], doff_last[NPW];
+    const int ntiles = (Ntok + 63) >> 6;
 #pragma unroll
     for (int i = 0; i < NPW; i++) {
         const int p = wave + NW * i;
         const int row = (p & 7) * 8 + prow;
-        drow[i] = row;
         const int ksw = ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
         const int vsw = (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
         doff[i] = (unsigned)(row * 128 + ((pch ^ (p >= 8 ? vsw : ksw)) << 4));
+        const int over = (ntiles - 1) * 64 + row - (Ntok - 1);
+        doff_last[i] = doff[i] - (over > 0 ? (unsigned)over * 128u : 0u);
     }
-    const int ntiles = (Ntok + 63) >> 6;
     auto issue = [&](int t) {
         char* st = smem + (t % 3) * AP_STAGE;
         const char* kt = uniform_ptr(kbase + (size_t)t * 8192);
         const char* vt = uniform_ptr(vbase + (size_t)t * 8192);
-        if (t < ntiles - 1) {
+        const bool last = t >= ntiles - 1;
 #pragma unroll
-            for (int i = 0; i < NPW; i++) {
-                const int p = wave + NW * i;
-                __builtin_amdgcn_global_load_lds(AP_GPTR((p >= 8 ? vt : kt) + doff[i]), AP_LPTR(st + p * 1024), 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NPW; i++) {
-                const int p = wave + NW * i;
-                const int over = t * 64 + drow[i] - (Ntok - 1);
-                const unsigned off = doff[i] - (over > 0 ? (unsigned)over * 128u : 0u);
-                __builtin_amdgcn_global_load_lds(AP_GPTR((p >= 8 ? vt : kt) + off), AP_LPTR(st + p * 1024), 16, 0, 0);
-            }
+        for (int i = 0; i < NPW; i++) {
+            const int p = wave + NW * i;
+            __builtin_amdgcn_global_load_lds(AP_GPTR((p >= 8 ? vt : kt) + (last ? doff_last[i] : doff[i])), AP_LPTR(st + p * 1024), 16, 0, 0);
         }
     };
     const int kswl = ((l15 >> 1) & 1) | ((l15 >> 2) << 1);
