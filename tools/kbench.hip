@@ -137,6 +137,9 @@ static int bench_gemm(const char* filter, int iters) {
         {"convT1", B * 14400, 512, 256, EPI_CONVT, ACT_NONE, 0, 0, 0, 128, 120, 120, 0},
         {"convT2", B * 57600, 256, 128, EPI_CONVT, ACT_NONE, 0, 0, 0, 64, 240, 240, 0},
         {"vitb.qkv", 8 * Ntok, 2304, 768, EPI_QKV, ACT_NONE, 768, 12, Ntok, 0, 0, 0, 0},
+        {"vitb.proj", 8 * Ntok, 768, 768, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
+        {"vitb.fc1", 8 * Ntok, 3072, 768, EPI_STORE, ACT_GELU, 0, 0, 0, 0, 0, 0, 0},
+        {"vitb.fc2", 8 * Ntok, 768, 3072, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"vits.qkv", 8 * Ntok, 1152, 384, EPI_QKV, ACT_NONE, 384, 6, Ntok, 0, 0, 0, 0},
         {"vits.fc2", 8 * Ntok, 384, 1536, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"tailM", 700, 1024, 1024, EPI_STORE, ACT_GELU, 0, 0, 0, 0, 0, 0, 0},
