@@ -16,6 +16,9 @@
 // (in place allowed), the pixel-shuffle store of the 4-phase "bilinear x2 + 3x3" resampler (EPI_CONVT), and a fused 1x1
 // SIDE INPUT: out += W2 . a2 (same pixel, C2 = Cin channels) - the head's `x + in_l(neck_l)` (modules.py:245) runs as extra
 // K-steps (centre tap of a2's halo) instead of a separate HBM-bound pass over the level's activations.
+// PERSISTENT for the forms that fit one workgroup per CU (BN = 128, or two halo buffers): a workgroup walks a list of tiles and requests the next
+// tile's first halo image from the epilogue of the current one (the epilogue stages through the weight ring, so both halo buffers are free);
+// the single-image 64-channel form (two workgroups per CU) keeps one tile per workgroup.  See PERSIST in the kernel.
 // Tile width TW = 16, or 32 for the 64-channel layers (64 px x 64 ch per wave: 16 fragment reads per 16 MFMAs instead of 12
 // per 8 - that configuration is LDS-read bound).
 #include "common.h"
@@ -58,6 +61,10 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     constexpr int WN = BN / 64, WM = 8 / WN, TM = TW * 16 / 32 / WM, TN = 2;
     constexpr int HALO_W = Halo<TW>::W, HALO_PX = Halo<TW>::PX, HALO_PIECES = Halo<TW>::PIECES, HALO_BYTES = Halo<TW>::BYTES, HPW = Halo<TW>::HPW;
     constexpr int LOG_TW = TW == 16 ? 4 : 5;
+    // The forms that fit ONE workgroup per CU walk a tile list (see below); the single-image 64-channel form fits two per CU, which overlap each
+    // other's prologue and epilogue already - persistent it measured 4-6 % slower (its 9-step tiles are short, and the weight ring, which the
+    // persistent epilogue stages through, can only be refilled at the tile head): it keeps one tile per workgroup.
+    constexpr bool PERSIST = !(BN == 64 && NH == 1);
     constexpr int NWP = BN / 64;                                         // weight pieces (8 rows x 128 B) per wave per K-step
     constexpr int WSLOT = BN * 128;
     constexpr int LDS_W = NH * HALO_BYTES;                                // weight ring behind the two halo buffers
@@ -73,46 +80,69 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     const int H = g.H, W = g.W, C = g.C;
     const int tx_n = (W + TW - 1) / TW, ty_n = (H + 15) >> 4;
     const int nbn = g.N / BN;
-    int wg;
+    // PERSISTENT: a workgroup walks a list of tiles.  Each XCD owns a contiguous range of the tile order (channel block fastest, then x, y,
+    // image), its workgroups (blockIdx & 7 = XCD) take consecutive tiles of it round by round - neighbouring tiles share halo pixels and the
+    // weight tile in that XCD's L2.  Why persistent: an s_memtime timeline (tools/kbench KB_TS, round 2) put 5-6 k clocks of a 64-channel
+    // tile's 17-20 k into the PROLOGUE (cold halo DMA from HBM before the first MFMA), 15-18 % for the 128 / 256-channel tiles: here the next
+    // tile's first halo image is requested from the epilogue of the current one and lands while it runs.
+    int li, cnt, start, wgs_x;
     {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+        const int ntiles = (int)(((long)g.M / ((long)H * W)) * ty_n * tx_n * nbn), nwg = gridDim.x;
+        const int nx = nwg < 8 ? nwg : 8, xcd = blockIdx.x % nx;          // (fewer than 8 workgroups: as many ranges as workgroups)
+        const int q = ntiles / nx, r = ntiles % nx;
+        cnt = q + (xcd < r ? 1 : 0);
+        start = xcd * q + min(xcd, r);
+        wgs_x = (nwg - xcd + nx - 1) / nx;
+        li = blockIdx.x / nx;
     }
-    const int bn = wg % nbn;
-    int t = wg / nbn;
-    const int tx = t % tx_n; t /= tx_n;
-    const int ty = t % ty_n;
-    const int b = t / ty_n;
-    const int y0 = ty * 16, x0 = tx * TW, n0 = bn * BN;
+    if (li >= cnt) return;
+    int b, y0, x0, n0;                                  // the tile this workgroup is computing / storing
     const int nchunks = NH == 1 ? 1 : (C >> 6);        // NH == 1: Cin == 64, straight-line 9-step K loop
     const int nside = (NH > 1 && g.a2) ? (C >> 6) : 0;  // fused 1x1 side input: one centre-tap K-step per 64 channels of a2
     const int nkt1 = nchunks * 9;
     const int nkt = nkt1 + nside;
 
     // ---- DMA sources ----------------------------------------------------------------------------------------------
-    const char* in_b = reinterpret_cast<const char*>(g.a) + (size_t)b * H * W * C * 2;
-    const char* in2_b = reinterpret_cast<const char*>(g.a2) + (size_t)b * H * W * C * 2;      // side input: same NHWC shape
     const int prow = lane >> 3, pch = lane & 7;
+    const char* in_b;                   // image base of the tile whose inputs are being requested (conv input / side input: same NHWC shape)
+    const char* in2_b;
+    const char* w_b;
+    const char* w2_b;                   // [N][C] 1x1 weights of the side input
     unsigned hoff[HPW];                 // byte offset of this lane's source chunk for halo piece i (chunk 0 of Cin)
+    int sb, sy0, sx0, sn0;              // coordinates of that tile
+    auto setup = [&](int idx) {
+        // (opaque per call: the per-piece halo coordinates below are tile-invariant, and hoisted out of the tile loop they cost ~20 VGPRs that the
+        //  128-register forms can only keep in scratch)
+        int prow_t = prow, pch_t = pch;
+        if constexpr (PERSIST) asm volatile("" : "+v"(prow_t), "+v"(pch_t));
+        const int wgt = start + idx;
+        const int bn_ = wgt % nbn;
+        int t = wgt / nbn;
+        const int tx = t % tx_n; t /= tx_n;
+        const int ty = t % ty_n;
+        sb = t / ty_n; sy0 = ty * 16; sx0 = tx * TW; sn0 = bn_ * BN;
+        in_b = reinterpret_cast<const char*>(g.a) + (size_t)sb * H * W * C * 2;
+        in2_b = reinterpret_cast<const char*>(g.a2) + (size_t)sb * H * W * C * 2;
+        w_b = reinterpret_cast<const char*>(g.w) + (size_t)sn0 * g.ldw * 2;
+        w2_b = reinterpret_cast<const char*>(g.w2) + (size_t)sn0 * C * 2;
 #pragma unroll
-    for (int i = 0; i < HPW; i++) {
-        int piece = wave + 8 * i;
-        piece = piece < HALO_PIECES ? piece : HALO_PIECES - 1;
-        int hp = piece * 8 + prow;
-        // chunk swizzle by the halo COLUMN: sw = (hx >> 1) & 7.  A 16-lane ds_read_b128 group covers 16 consecutive columns (split over
-        // two image rows for the 16-wide tile); with an even row pitch the LDS half-row bit is hx & 1, so (hx & 1, (hx >> 1) & 7) = hx mod 16
-        // is distinct for every lane of the group at every tap shift: conflict-free (the linear-index swizzle was 2-way on 4 lanes)
-        // (16x16x32 form: keyed on the column itself, hx & 7 - conflict-free for all three tap shifts of its 16-lane fragment groups, found by search)
-        const int sw = ((EPI & 8) ? (hp % HALO_W) : ((hp % HALO_W) >> 1)) & 7;      // padding pixels of the last piece: any consistent value
-        hp = hp < HALO_PX ? hp : HALO_PX - 1;
-        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-        int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-        yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);                    // replicate padding (modules.py:53)
-        xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
-        hoff[i] = (unsigned)(((yy * W + xx) * C) * 2 + ((pch ^ sw) << 4));
-    }
-    const char* w_b = reinterpret_cast<const char*>(g.w) + (size_t)n0 * g.ldw * 2;
-    const char* w2_b = reinterpret_cast<const char*>(g.w2) + (size_t)n0 * C * 2;               // [N][C] 1x1 weights of the side input
+        for (int i = 0; i < HPW; i++) {
+            int piece = wave + 8 * i;
+            piece = piece < HALO_PIECES ? piece : HALO_PIECES - 1;
+            int hp = piece * 8 + prow_t;
+            // chunk swizzle by the halo COLUMN: sw = (hx >> 1) & 7.  A 16-lane ds_read_b128 group covers 16 consecutive columns (split over
+            // two image rows for the 16-wide tile); with an even row pitch the LDS half-row bit is hx & 1, so (hx & 1, (hx >> 1) & 7) = hx mod 16
+            // is distinct for every lane of the group at every tap shift: conflict-free (the linear-index swizzle was 2-way on 4 lanes)
+            // (16x16x32 form: keyed on the column itself, hx & 7 - conflict-free for all three tap shifts of its 16-lane fragment groups, found by search)
+            const int sw = ((EPI & 8) ? (hp % HALO_W) : ((hp % HALO_W) >> 1)) & 7;      // padding pixels of the last piece: any consistent value
+            hp = hp < HALO_PX ? hp : HALO_PX - 1;
+            const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+            int yy = sy0 - 1 + hy, xx = sx0 - 1 + hx;
+            yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);                    // replicate padding (modules.py:53)
+            xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+            hoff[i] = (unsigned)(((yy * W + xx) * C) * 2 + ((pch_t ^ sw) << 4));
+        }
+    };
     int wrow[NWP];                      // weight-tile row and swizzled chunk offset of this lane in piece i
     unsigned wsw[NWP];
 #pragma unroll
@@ -160,40 +190,22 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
 
     f32x16 acc[TM][TN];
     f32x4 acc16[2 * TM][4];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2 * TM; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- prologue -----------------------------------------------------------------------------------------------------
-    issue_halo(0);
-    issue_w(0);
-    issue_w(1);                                   // nkt >= 9
-    issue_w(2);
-    wait_vm_lgkm<2 * NWP>();
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-
     const int ntot = nchunks + nside;                // halo images consumed: conv chunks, then side chunks
     // one K-step: fragments of (halo image, tap), weights of step kt; DMA for step kt+3 (+ the next halo image at the first step of
     // an image); counted wait; barrier; 16 / 8 MFMAs; barrier.  halo_age: steps since the last halo issue (its 6-10 pieces may
     // still be in flight during the issuing step and the one after).
     int kt = 0, halo_age = 2;
+    // The halo fragment addresses depend on (lane, tap) only: left alone, the compiler hoists all of them out of the tile loop (tens of VGPRs)
+    // and reloads them from scratch in every K-step - behind vmcnt(0).  l15t is made opaque once per tile so they are recomputed per tap
+    // (6 VALU) as in the one-tile-per-workgroup kernel.
+    int l15t = l15;
     auto kstep = [&](const char* halo, int dy, int dx, bool first_of_image, int image, bool relu) {
         const char* wsl = smem + LDS_W + (kt & 3) * WSLOT;
         u32x4 af[TM][4], wf[TN][4];          // M16: viewed as af16[2*TM][2] / wf16[4][2] (same register count)
         if constexpr (M16) {
 #pragma unroll
             for (int i = 0; i < 2 * TM; i++) {
-                const int hx = l15 + 1 + dx;
+                const int hx = l15t + 1 + dx;
                 const int hp = (wm * 2 * TM + i + 1 + dy) * HALO_W + hx;
                 const int a0 = hp * 128 + ((g4 ^ (hx & 7)) << 4);
 #pragma unroll
@@ -271,6 +283,40 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
         __builtin_amdgcn_sched_barrier(0);
         kt++;
     };
+    setup(li);
+    issue_halo(0);
+    bool first = true;
+    for (;;) {                                      // ======== one tile per iteration ========
+    b = sb; y0 = sy0; x0 = sx0; n0 = sn0;
+    if constexpr (PERSIST) asm volatile("" : "+v"(l15t));
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * TM; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- tile head: the first halo image is already on its way (requested by the previous tile's epilogue / above) -------------------
+    if (!first) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // every wave has read its epilogue staging region back: the weight ring is free
+        asm volatile("" ::: "memory");
+    }
+    first = false;
+    kt = 0; halo_age = 2;
+    issue_w(0);
+    issue_w(1);                                   // nkt >= 9
+    issue_w(2);
+    wait_vm_lgkm<2 * NWP>();                      // in order: the halo image, the previous epilogue's stores and W(0) are behind this
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
     for (int c = 0; c < nchunks; c++) {
         const char* halo = smem + (c & (NH - 1)) * HALO_BYTES;
 #pragma unroll
@@ -279,11 +325,34 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     for (int c2 = 0; c2 < nside; c2++) kstep(smem + ((nchunks + c2) & (NH - 1)) * HALO_BYTES, 0, 0, true, nchunks + c2, false);
 
     // ---- epilogue: bias / uv / ReLU in registers, transpose through LDS, (residual add,) 16-byte pixel-row stores -------------
-    char* R = smem + wave * (WROWS * 128);
-    const int rr = lane >> 3, cc = lane & 7;
+    // Staging region of this wave: in the WEIGHT RING (every wave has passed the last barrier: all fragment reads are done), so that both halo
+    // buffers are free for the next tile's first image while this epilogue runs.
+    char* R = smem + (PERSIST ? LDS_W : 0) + wave * (WROWS * 128);
+    int rr = lane >> 3, cc = lane & 7;
+    if constexpr (PERSIST) asm volatile("" : "+v"(rr), "+v"(cc));          // (per tile: keeps the store-loop address arithmetic out of loop-invariant registers)
     const int nw = n0 + wn * 64;
     const float lo = g.act == ACT_RELU ? 0.f : -3.0e38f;        // branch-free optional ReLU
     const bool has_bias = g.bias != nullptr;
+    f16* const outp = reinterpret_cast<f16*>(g.out);
+    const f16* const addp = reinterpret_cast<const f16*>(g.add);
+    // (1) The compiler waits vmcnt(0) for an ordinary load while LDS-DMA is in flight, so nothing may be loaded behind the halo prefetch
+    //     further down: the per-channel vectors are loaded (and used) by the arithmetic in front of it, the residual rows (x + conv(x),
+    //     modules.py:66) are requested here - all of them before the first store as well: vmcnt counts stores too and retires in order.
+    f16x8 addv[WROWS / 8];
+    auto load_skip_rows = [&]() {
+        if constexpr (!CONVT) {
+            if (addp) {
+    #pragma unroll
+                for (int it = 0; it < WROWS / 8; it++) {
+                    const int mp = wm * WROWS + it * 8 + rr;
+                    int y = y0 + (mp >> LOG_TW), x = x0 + (mp & (TW - 1));
+                    y = y < H ? y : H - 1; x = x < W ? x : W - 1;
+                    addv[it] = *reinterpret_cast<const f16x8*>(addp + (((size_t)b * H + y) * W + x) * g.ldadd + nw + cc * 8);
+                }
+            }
+        }
+    };
+    if constexpr (PERSIST) load_skip_rows();         // early: their latency passes under the arithmetic below (they must be in before the prefetch)
     if constexpr (M16) {
         // 16x16x32 accumulators: block i = tile row wm*2*TM + i, lane: pixel x0 + l15, channels nw + jj*16 + 4*g4 .. +3
         float u0[2 * TM], u1[2 * TM], v0[2 * TM], v1[2 * TM];
@@ -388,21 +457,16 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
             }
         }
     }
-    f16* const outp = reinterpret_cast<f16*>(g.out);
-    const f16* const addp = reinterpret_cast<const f16*>(g.add);
-    // residual add (x + conv(x), modules.py:66): ALL rows of the skip input are loaded before the first store - vmcnt counts stores too and
-    // retires in order, so a {load row; add; store row} loop would wait for the previous row's store before every add
-    f16x8 addv[WROWS / 8];
-    if constexpr (!CONVT) {
-        if (addp) {
-#pragma unroll
-            for (int it = 0; it < WROWS / 8; it++) {
-                const int mp = wm * WROWS + it * 8 + rr;
-                int y = y0 + (mp >> LOG_TW), x = x0 + (mp & (TW - 1));
-                y = y < H ? y : H - 1; x = x < W ? x : W - 1;
-                addv[it] = *reinterpret_cast<const f16x8*>(addp + (((size_t)b * H + y) * W + x) * g.ldadd + nw + cc * 8);
-            }
-        }
+    // (2) the accumulators are in the staging region (registers free): the next tile's coordinates and halo offsets, then its first halo image
+    if constexpr (!PERSIST) load_skip_rows();        // one tile per workgroup: where the loads always were (fewer live registers in the arithmetic)
+    bool more = false;
+    if constexpr (PERSIST) {
+        li += wgs_x;
+        more = li < cnt;
+        if (more) setup(li);
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // a real S_WAITCNT vmcnt(0) the compiler accounts for: the loads above are complete
+        if (more) issue_halo(0);
+        asm volatile("" ::: "memory");
     }
 #pragma unroll
     for (int it = 0; it < WROWS / 8; it++) {
@@ -428,6 +492,8 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
             }
         }
     }
+    if (!more) break;
+    }                                               // ======== next tile ========
 }
 
 template <int BN, int TW, int NH, int EPI>
@@ -437,7 +503,17 @@ int launch_conv_cfg(const GemmArgs& g, hipStream_t st) {
     if (int rc = set_dyn_lds<kern>(smem)) return rc;
     const long B = (long)g.M / ((long)g.H * g.W);
     const long tiles = B * ((g.H + 15) / 16) * ((g.W + TW - 1) / TW) * (g.N / BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), smem, st, g);
+    // persistent: as many workgroups as the chip holds at once (LDS: two per CU for the single-image 64-channel form, one otherwise)
+    int dev = 0, ncu = 256;
+    hipDeviceProp_t prop;
+    static int cached_cus = 0;
+    if (!cached_cus) cached_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    ncu = cached_cus;
+    long slots = (BN == 64 && NH == 1) ? tiles : (long)ncu;          // (the two-per-CU form: one tile per workgroup, see PERSIST)
+    const long cap = moge_tune_get("CONV_GRID", 0);      // tests: a small grid makes small problems walk many tiles per workgroup
+    if (cap > 0 && !(BN == 64 && NH == 1)) slots = cap;
+    const long grid = tiles < slots ? tiles : slots;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, g);
     return (int)hipGetLastError();
 }
 

@@ -637,12 +637,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
     const int nbn = g.N / BN, nbm = (g.M + BM - 1) / BM;
     int li, cnt, start, wgs_x;                               // this workgroup's position in its XCD's tile range
     {
-        const int ntiles = nbm * nbn, nwg = gridDim.x, xcd = blockIdx.x & 7;
-        const int q = ntiles >> 3, r = ntiles & 7;
+        const int ntiles = nbm * nbn, nwg = gridDim.x;
+        const int nx = nwg < 8 ? nwg : 8, xcd = blockIdx.x % nx;          // (fewer than 8 workgroups: as many ranges as workgroups)
+        const int q = ntiles / nx, r = ntiles % nx;
         cnt = q + (xcd < r ? 1 : 0);
         start = xcd * q + min(xcd, r);
-        wgs_x = (nwg - xcd + 7) >> 3;
-        li = blockIdx.x >> 3;
+        wgs_x = (nwg - xcd + nx - 1) / nx;
+        li = blockIdx.x / nx;
     }
     if (li >= cnt) return;
     const int nkt = g.K >> 6;

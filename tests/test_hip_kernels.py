@@ -90,6 +90,30 @@ def test_conv3x3(H, prec, B, Hh, Ww, Cin, Cout, relu):
     assert relmax(out, ref) < TOL[prec]
 
 
+@pytest.mark.parametrize("grid", [3, 13])
+@pytest.mark.parametrize("B,Hh,Ww,Cin,Cout,relu", [(3, 50, 37, 64, 64, True), (2, 40, 70, 128, 128, False), (2, 33, 21, 256, 256, True)])
+def test_conv3x3_persistent_walks_tiles(H, grid, B, Hh, Ww, Cin, Cout, relu):
+    """conv_pp_kernel is persistent (a workgroup walks a list of tiles, the next tile's halo is requested from the epilogue of the current one).
+    A small workgroup cap makes these small problems walk several tiles per workgroup - with 3 workgroups also the 'fewer ranges than XCDs'
+    split - and the result must be the one-tile-per-workgroup result bit for bit (cap = number of tiles)."""
+    from moge_amd import _lib as L
+    g = torch.Generator().manual_seed(Cin + Hh)
+    x = torch.randn(B, Hh, Ww, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    outs = []
+    for cap in (grid, 1 << 20):
+        L.tune("CONV_GRID", cap)
+        try:
+            outs.append(H.conv3x3(1, x, w, b, relu_in=relu))
+        finally:
+            L.tune("CONV_GRID", 0)
+    assert torch.equal(outs[0], outs[1])
+    xin = F.relu(x) if relu else x
+    ref = F.conv2d(F.pad(xin.permute(0, 3, 1, 2).cuda(), (1, 1, 1, 1), mode="replicate"), w.cuda(), b.cuda()).permute(0, 2, 3, 1)
+    assert relmax(outs[0], ref) < TOL[1]
+
+
 @pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("Cin,Cout,Hh,Ww", [(64, 32, 11, 7), (64, 32, 19, 33), (128, 64, 9, 21)])
 def test_conv3x3_fused_bilinear_up2(H, prec, Cin, Cout, Hh, Ww):
