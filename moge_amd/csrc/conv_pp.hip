@@ -87,7 +87,9 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     // tile's first halo image is requested from the epilogue of the current one and lands while it runs.
     int li, cnt, start, wgs_x;
     {
-        const int ntiles = (int)(((long)g.M / ((long)H * W)) * ty_n * tx_n * nbn), nwg = gridDim.x;
+        const int nwg = gridDim.x;
+        // (one tile per workgroup: the grid IS the tile count - no division in front of every tile)
+        const int ntiles = PERSIST ? (g.M / (H * W)) * ty_n * tx_n * nbn : nwg;
         const int nx = nwg < 8 ? nwg : 8, xcd = blockIdx.x % nx;          // (fewer than 8 workgroups: as many ranges as workgroups)
         const int q = ntiles / nx, r = ntiles % nx;
         cnt = q + (xcd < r ? 1 : 0);
