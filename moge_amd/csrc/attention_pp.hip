@@ -362,15 +362,25 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
 // (Requesting the tile's V^T operands behind the K Q^T MFMAs, so that their LDS latency passes under the exponentials, needs > 168 registers =
 // 2 waves per SIMD: measured 783-800 TF/s against 938-944 for this form - the third wave is worth more than the exposed read latency.)
 __global__ __launch_bounds__(256, 3) void attn_pp16m_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
-                                                            f16* __restrict__ out, int Ntok, int nh) {
+                                                            f16* __restrict__ out, int Ntok, int nh, int xcd_remap) {
     constexpr int NW = 4, NPW = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * AP_STAGE
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g4 = lane >> 4;
-    const int bh = blockIdx.y;
+    // XCD-aware order: workgroups are dispatched round-robin over the 8 XCDs in linear block order, so with (x = query block, y = head) the 29
+    // query blocks of a head land on all 8 L2s and every L2 streams every head's K / V.  Remapped so that a head's query blocks run on ONE XCD
+    // (XCD x takes heads x, x + 8, ...): its K / V tiles are fetched into one L2 once.
+    int bh = blockIdx.y, qblk = blockIdx.x;
+    if (((gridDim.y & 7) == 0) && xcd_remap) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int x = lin & 7, s = lin >> 3;
+        const int hs = s / (int)gridDim.x;
+        bh = x + 8 * hs;
+        qblk = s - hs * (int)gridDim.x;
+    }
     const int b = bh / nh, head = bh - b * nh;
-    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+    const int q0 = qblk * (NW * 32) + wave * 32;
 
     u32x4 qf[2][2];
 #pragma unroll
@@ -605,7 +615,8 @@ static int launch_attn_pp16(const void* q, const void* k, const void* v, void* o
     dim3 grid((Ntok + 127) / 128, B * nh);
     if (moge_tune_get("ATTN_KERN", AP_KERN_DEFAULT) == 1) {             // attn_pp16m_kernel: row sums on the matrix pipe
         if (int rc = set_dyn_lds<attn_pp16m_kernel>(smem)) return rc;
-        hipLaunchKernelGGL(attn_pp16m_kernel, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh);
+        hipLaunchKernelGGL(attn_pp16m_kernel, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh,
+                           moge_tune_get("ATTN_XCD", 1));
         return (int)hipGetLastError();
     }
 #define AP_LAUNCH_VAR(V) do { if (int rc = set_dyn_lds<attn_pp16_kernel<V>>(smem)) return rc; \
