@@ -8,7 +8,7 @@ cp moge_amd/lib/libmoge_hip.so /tmp/new_lib.so
 for r in $(seq $rounds); do
   for v in old new; do
     if [ $v = old ]; then cp tools/_ab/old/libmoge_hip.so moge_amd/lib/libmoge_hip.so; else cp /tmp/new_lib.so moge_amd/lib/libmoge_hip.so; fi
-    python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pcie 2>/dev/null | python3 -c "
+    python bench.py $AB_ARGS --steps 6 --warmup 2 --no-cpu-baseline --no-pcie 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 kc = d.get('kernel_classes', {})
