@@ -288,6 +288,10 @@ def main():
                 res["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
                 res["roofline"]["traffic_unit"] = "bytes per launch (fabric reads x2-corrected + writes)"
                 res["roofline"]["traffic_source"] = tj["source"]
+                if tj.get("clock_ghz"):
+                    # shader clock the kernel actually held in the PMC pass (the chip clocks to its power budget: 2.4 GHz is what `peak` assumes)
+                    res["roofline"]["clock_ghz"] = tj["clock_ghz"]
+                    res["roofline"]["mfma_busy_at_that_clock"] = tj.get("mfma_busy_at_that_clock")
             tot_ms = sum(v["ms"] for v in prof.values())
             tot_fl = sum(v["flops"] for v in prof.values())
             res["kernel_classes"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),

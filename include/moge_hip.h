@@ -244,6 +244,22 @@ int moge_test_attention(int precision, const float* q, const float* k, const flo
 /* 3x3 replicate-padded conv, NHWC: x (B,H,W,Cin), w (Cout,Cin,3,3) torch layout, y (B,H,W,Cout); relu_in applies ReLU to x */
 int moge_test_conv3x3(int precision, const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
                       int Cin, int Cout, int relu_in, void* stream);
+/* The same conv with the pieces the decoder fuses into it (conv_pp.hip flavours), each against F.conv2d / F.pixel_shuffle in tests/:
+ *   y = [add +] act(conv3x3(relu_in ? relu(x) : x) + bias [+ side_w . side] [+ wu u(x) + wv v(y)])          modules.py:53-66, 148-181, 245
+ *   up2: bilinear x2 + 3x3 as the 4-phase conv + pixel shuffle, y (B,2H,2W,Cout), uv at the OUTPUT resolution    modules.py:155-159
+ *   w2 != NULL: the fused residual block  y = x + conv2(relu(conv1(relu(x)) + bias)) + bias2  in ONE launch       modules.py:47-68
+ * All pointers DEVICE fp32, NHWC maps, torch weight layouts (Cout,Cin,3,3) / side_w (Cout,Cin). */
+typedef struct moge_test_conv_args {
+    int32_t precision, B, H, W, Cin, Cout;
+    int32_t relu_in, act, up2;               /* act: 0 none 1 relu */
+    const float* x; const float* w; const float* bias;
+    const float* add;                        /* (B,H,W,Cout) or NULL */
+    const float* side; const float* side_w;  /* fused 1x1 side input (fp16, Cin == Cout) or NULL */
+    const float* wu; const float* wv; float u0, u1, v0, v1;
+    const float* w2; const float* bias2;     /* fused residual block (fp16, Cin == Cout == 64) or NULL */
+    float* y;
+} moge_test_conv_args;
+int moge_test_conv_ex(const moge_test_conv_args* args, void* stream);
 /* ConvTranspose2d k2 s2, NHWC: x (B,H,W,Cin), w (Cin,Cout,2,2) torch layout, y (B,2H,2W,Cout) */
 int moge_test_convt2x2(int precision, const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
                        int Cin, int Cout, void* stream);

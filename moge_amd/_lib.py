@@ -61,6 +61,15 @@ class TestGemmArgs(C.Structure):
                 ("q_out", C.c_void_p), ("k_out", C.c_void_p), ("v_out", C.c_void_p), ("nh", C.c_int32), ("Ntok", C.c_int32), ("qscale", C.c_float)]
 
 
+class TestConvArgs(C.Structure):
+    """moge_test_conv_args (tests only): one 3x3 conv through the pieces the decoder fuses into it."""
+    _fields_ = [("precision", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+                ("relu_in", C.c_int32), ("act", C.c_int32), ("up2", C.c_int32),
+                ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("add", C.c_void_p), ("side", C.c_void_p), ("side_w", C.c_void_p),
+                ("wu", C.c_void_p), ("wv", C.c_void_p), ("u0", C.c_float), ("u1", C.c_float), ("v0", C.c_float), ("v1", C.c_float),
+                ("w2", C.c_void_p), ("bias2", C.c_void_p), ("y", C.c_void_p)]
+
+
 class MogeError(RuntimeError):
     pass
 
@@ -100,6 +109,7 @@ def _load() -> C.CDLL:
         "moge_test_layernorm": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, vp]),
         "moge_test_attention": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, vp]),
         "moge_test_conv3x3": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, vp]),
+        "moge_test_conv_ex": (C.c_int, [C.POINTER(TestConvArgs), vp]),
         "moge_test_convt2x2": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, vp]),
         "moge_test_preprocess": (C.c_int, [f32p, f32p, i32, i32, i32, i32, i32, vp]),
         "moge_test_resize_bicubic_aa": (C.c_int, [f32p, f32p, i32, i32, i32, i32, i32, vp]),
@@ -124,7 +134,7 @@ lib = _load()
 EXPORTS = ["moge_abi_version", "moge_last_error", "moge_create", "moge_create_v1", "moge_v1_forward", "moge_v1_infer", "moge_destroy", "moge_load_weights", "moge_alloc_master",
            "moge_master_blob", "moge_master_ready", "moge_set_precision", "moge_set_onnx_compatible_mode", "moge_workspace_bytes", "moge_forward", "moge_infer",
            "moge_postprocess", "moge_depth_edge_mask", "moge_sync", "moge_profile_enable", "moge_profile_read", "moge_debug_tap", "moge_tune_set", "moge_test_gemm",
-           "moge_test_gemm_ex", "moge_test_layernorm", "moge_test_attention", "moge_test_conv3x3", "moge_test_convt2x2", "moge_test_preprocess",
+           "moge_test_gemm_ex", "moge_test_layernorm", "moge_test_attention", "moge_test_conv3x3", "moge_test_conv_ex", "moge_test_convt2x2", "moge_test_preprocess",
            "moge_test_resize_bicubic_aa", "moge_test_groupnorm_relu", "moge_test_posembed", "moge_test_recover",
            "moge_align_l1", "moge_align_l1_anchored", "moge_align_select", "moge_align_lstsq"]
 

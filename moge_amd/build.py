@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmoge_hip.so")
-SOURCES = ["gemm.hip", "gemm_pp.hip", "conv_pp.hip", "attention.hip", "attention_pp.hip", "elementwise.hip", "post.hip", "alignment.hip", "model.hip", "test_api.hip"]
+SOURCES = ["gemm.hip", "gemm_pp.hip", "conv_pp.hip", "conv_rb.hip", "attention.hip", "attention_pp.hip", "elementwise.hip", "post.hip", "alignment.hip", "model.hip", "test_api.hip"]
 HEADERS = ["common.h", "launchers.h", os.path.join("..", "..", "include", "moge_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

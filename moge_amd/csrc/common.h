@@ -221,6 +221,9 @@ struct GemmArgs {
     unsigned long long* dbg_ts;   // gemm_pp128: optional s_memtime stamps of one block (tools/kbench)
     int stagger;           // gemm_pp128: number of start-phase classes (0/1 = off)
     int dbg;               // gemm_pp ablation bits (tools/kbench only): 1 no DMA, 2 no LDS reads, 4 no MFMA, 8 no barriers
+    // conv_rb.hip (fused residual block, modules.py:47-68): out = add + conv2(relu(conv1(relu(a)) + bias)) + rb_bias2; w / rb_w2 = [C][9C]
+    const void* rb_w2;
+    const float* rb_bias2;
 };
 
 // Opt a kernel into more than 64 KiB of dynamic LDS.  The attribute is per DEVICE and a process may drive several (one host thread per
@@ -239,6 +242,19 @@ inline int set_dyn_lds(int bytes) {
     return 0;
 }
 
+// CU count of the CURRENT device (persistent kernels size their grids with it).  Cached per device id: a process may drive several GPUs,
+// and partition modes (SPX / CPX) give devices of one box different counts.
+inline int pp_device_cus() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < 64 && cus[dev]) return cus[dev];
+    hipDeviceProp_t p;
+    const int n = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    if (dev >= 0 && dev < 64) cus[dev] = n;
+    return n;
+}
+
 // host-side launchers (gemm.hip, gemm_pp.hip)
 template <typename T> int launch_gemm(const GemmArgs& g, int amode, hipStream_t st);
 bool gemm_pp_eligible(const GemmArgs& g);
@@ -247,5 +263,7 @@ bool gemm_runs_pp(const GemmArgs& g);       // launch_gemm<f16>(g, AMODE_LINEAR)
 int launch_gemm_pp(const GemmArgs& g, hipStream_t st);
 bool conv_pp_eligible(const GemmArgs& g);
 int launch_conv_pp(const GemmArgs& g, hipStream_t st);
+bool conv_rb_eligible(const GemmArgs& g);   // conv_rb.hip: fp16 residual block with the intermediate map kept in LDS (C = 64)
+int launch_conv_rb(const GemmArgs& g, hipStream_t st);
 // runtime tuning / A-B switches (tests, tools/kbench): see tune.cpp-style table in gemm.hip
 int moge_tune_get(const char* key, int dflt);

@@ -58,6 +58,12 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     // lane >> 4), accumulators f32x4[2*TM][4]; the halo / weight LDS layouts, DMA, waits and barriers are unchanged.  TW = 16 only.
     constexpr bool M16 = (EPI & 8) != 0;
     static_assert(!M16 || TW == 16, "16x16x32 path: 16-pixel-wide tiles");
+    // EPI bit 4: the fused 1x1 side input of a 64-channel layer WITHOUT a second halo buffer: a 1x1 conv needs only the tile's own pixels, so
+    // each lane loads its four B fragments of the side map (2 pixel blocks x 2 K-steps, 64 bytes) straight into registers at the tile head and
+    // the side conv is a tenth K-step on them.  Keeps the single-image form's 73 KiB of LDS = TWO workgroups per CU (the two-halo-buffer form
+    // of round 2 fits one: 1176 us against ~600 us for the plain conv of the same shape).
+    constexpr bool SIDE_REG = (EPI & 16) != 0;
+    static_assert(!SIDE_REG || (M16 && BN == 64 && NH == 1), "register side input: single-image 64-channel form");
     constexpr int WN = BN / 64, WM = 8 / WN, TM = TW * 16 / 32 / WM, TN = 2;
     constexpr int HALO_W = Halo<TW>::W, HALO_PX = Halo<TW>::PX, HALO_PIECES = Halo<TW>::PIECES, HALO_BYTES = Halo<TW>::BYTES, HPW = Halo<TW>::HPW;
     constexpr int LOG_TW = TW == 16 ? 4 : 5;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     if (li >= cnt) return;
     int b, y0, x0, n0;                                  // the tile this workgroup is computing / storing
     const int nchunks = NH == 1 ? 1 : (C >> 6);        // NH == 1: Cin == 64, straight-line 9-step K loop
-    const int nside = (NH > 1 && g.a2) ? (C >> 6) : 0;  // fused 1x1 side input: one centre-tap K-step per 64 channels of a2
+    const int nside = SIDE_REG ? 1 : ((NH > 1 && g.a2) ? (C >> 6) : 0);  // fused 1x1 side input: one centre-tap K-step per 64 channels of a2
     const int nkt1 = nchunks * 9;
     const int nkt = nkt1 + nside;
 
@@ -201,10 +207,19 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     // and reloads them from scratch in every K-step - behind vmcnt(0).  l15t is made opaque once per tile so they are recomputed per tap
     // (6 VALU) as in the one-tile-per-workgroup kernel.
     int l15t = l15;
-    auto kstep = [&](const char* halo, int dy, int dx, bool first_of_image, int image, bool relu) {
+    u32x4 sidef[SIDE_REG ? 2 * TM : 1][2];      // SIDE_REG: B fragments of the side map (pixel block i, K-step ks)
+    auto kstep = [&](const char* halo, int dy, int dx, bool first_of_image, int image, bool relu, bool from_regs = false) {
         const char* wsl = smem + LDS_W + (kt & 3) * WSLOT;
         u32x4 af[TM][4], wf[TN][4];          // M16: viewed as af16[2*TM][2] / wf16[4][2] (same register count)
         if constexpr (M16) {
+            if (from_regs) {
+                if constexpr (SIDE_REG) {
+#pragma unroll
+                    for (int i = 0; i < 2 * TM; i++)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ks++) af[i >> 1][(i & 1) * 2 + ks] = sidef[i][ks];
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < 2 * TM; i++) {
                 const int hx = l15t + 1 + dx;
@@ -212,6 +227,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
                 const int a0 = hp * 128 + ((g4 ^ (hx & 7)) << 4);
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) af[i >> 1][(i & 1) * 2 + ks] = *reinterpret_cast<const u32x4*>(halo + (a0 ^ (ks * 64)));
+            }
             }
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -286,6 +302,18 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
         kt++;
     };
     setup(li);
+    if constexpr (SIDE_REG) {
+        // ordinary loads, issued BEFORE the first DMA: every counted wait below is for something younger, so (vmcnt is in order) they have
+        // landed with the tile-head wait; the compiler's own wait in front of their use sits in the last K-step, when nothing else is in flight
+#pragma unroll
+        for (int i = 0; i < 2 * TM; i++) {
+            int y = sy0 + wm * 2 * TM + i, x = sx0 + l15;
+            y = y < H ? y : H - 1; x = x < W ? x : W - 1;
+            const char* sp = in2_b + ((size_t)y * W + x) * C * 2 + g4 * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) sidef[i][ks] = *reinterpret_cast<const u32x4*>(sp + ks * 64);
+        }
+    }
     issue_halo(0);
     bool first = true;
     for (;;) {                                      // ======== one tile per iteration ========
@@ -324,6 +352,8 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) kstep(halo, tap / 3 - 1, tap % 3 - 1, tap == 0, c, true);
     }
+    if constexpr (SIDE_REG) kstep(smem, 0, 0, false, nchunks, false, true);
+    else
     for (int c2 = 0; c2 < nside; c2++) kstep(smem + ((nchunks + c2) & (NH - 1)) * HALO_BYTES, 0, 0, true, nchunks + c2, false);
 
     // ---- epilogue: bias / uv / ReLU in registers, transpose through LDS, (residual add,) 16-byte pixel-row stores -------------
@@ -374,11 +404,15 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
                 }
             }
         }
+        // all four bias vectors requested together and unconditionally (conv_pp_eligible requires a bias): a load under `if (has_bias)` is a
+        // branch + vmcnt(0) per vector - four dependent L2 round trips in every tile's epilogue (cdna guide 5, ".s-level traps" (c))
+        f32x4 bvs[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) bvs[jj] = *reinterpret_cast<const f32x4*>(g.bias + nw + jj * 16 + 4 * g4);
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
             const int n = nw + jj * 16 + 4 * g4;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (has_bias) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+            const f32x4 bv = bvs[jj];
             f32x4 wu = {0.f, 0.f, 0.f, 0.f}, wv = wu;
             int pdy = 0, pdx = 0;
             if constexpr (HAS_UV) {
@@ -506,11 +540,7 @@ int launch_conv_cfg(const GemmArgs& g, hipStream_t st) {
     const long B = (long)g.M / ((long)g.H * g.W);
     const long tiles = B * ((g.H + 15) / 16) * ((g.W + TW - 1) / TW) * (g.N / BN);
     // persistent: as many workgroups as the chip holds at once (LDS: two per CU for the single-image 64-channel form, one otherwise)
-    int dev = 0, ncu = 256;
-    hipDeviceProp_t prop;
-    static int cached_cus = 0;
-    if (!cached_cus) cached_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    ncu = cached_cus;
+    const int ncu = pp_device_cus();
     long slots = (BN == 64 && NH == 1) ? tiles : (long)ncu;          // (the two-per-CU form: one tile per workgroup, see PERSIST)
     const long cap = moge_tune_get("CONV_GRID", 0);      // tests: a small grid makes small problems walk many tiles per workgroup
     if (cap > 0 && !(BN == 64 && NH == 1)) slots = cap;
@@ -523,7 +553,7 @@ int launch_conv_cfg(const GemmArgs& g, hipStream_t st) {
 
 // AMODE_CONV3 problems the halo kernel takes (f16): Cin multiple of 64, N = 64 or a multiple of 128, plain / pixel-shuffle store
 bool conv_pp_eligible(const GemmArgs& g) {
-    if ((g.C & 63) || g.K != 9 * g.C || g.ldw != 9 * g.C) return false;
+    if ((g.C & 63) || g.K != 9 * g.C || g.ldw != 9 * g.C || !g.bias) return false;
     if (g.N != 64 && (g.N & 127)) return false;
     if (g.H < 1 || g.W < 1 || (long)g.M % ((long)g.H * g.W) != 0) return false;
     if ((long)g.H * g.W * g.C * 2 >= (1L << 31)) return false;                     // 32-bit halo offsets
@@ -538,6 +568,9 @@ bool conv_pp_eligible(const GemmArgs& g) {
 template <int BN, int TW, int NH>
 static int launch_conv_epi(const GemmArgs& g, hipStream_t st) {
     const int e = (g.uv.wu ? 1 : 0) | (g.epi == EPI_CONVT ? 2 : 0) | (g.relu_in ? 4 : 0);
+    if constexpr (BN == 64 && TW == 16 && NH == 1) {
+        if (g.a2) return e == 0 ? launch_conv_cfg<BN, TW, NH, 8 | 16>(g, st) : -1;      // register side input (plain store only: what the heads use)
+    }
 #ifdef MOGE_EXPERIMENTS
     if (TW == 32 || moge_tune_get("CONV_M16", 1) == 0) {       // the v_mfma_f32_32x32x16_f16 form (tools/kbench A-B only)
         switch (e) {
@@ -564,7 +597,9 @@ static int launch_conv_epi(const GemmArgs& g, hipStream_t st) {
 }
 
 int launch_conv_pp(const GemmArgs& g, hipStream_t st) {
-    const bool one_image = g.C == 64 && !g.a2;           // a single halo image: one buffer
+    // a single halo image: one buffer.  A 64-channel layer with a side input runs on the single-buffer form too (side fragments in registers)
+    const bool side_reg = g.C == 64 && g.N == 64 && g.a2 && !g.uv.wu && !g.relu_in && g.epi == EPI_STORE && moge_tune_get("CONV_SIDE_REG", 1);
+    const bool one_image = g.C == 64 && (!g.a2 || side_reg);
     if (g.N == 64) {
         // 32-pixel-wide tiles (64 px x 64 ch per wave) when the image is wide enough to fill them
 #ifdef MOGE_EXPERIMENTS

@@ -815,15 +815,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
 #undef PP_STAMP
 }
 
-static int pp_num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-    }
-    return n;
-}
+static int pp_num_cus() { return pp_device_cus(); }      // per device (common.h)
 
 // the persistent kernel addresses its outputs through buffer descriptors with 32-bit byte offsets
 static bool pp_persistent_ok(const GemmArgs& g) {

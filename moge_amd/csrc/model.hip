@@ -491,7 +491,17 @@ template <typename T>
 static int run_gemm(moge_handle* h, const GemmArgs& g, int amode, int cls, hipStream_t st, double kalgo = 0) {
     const double k = kalgo > 0 ? kalgo : (double)g.K;
     const double flops = 2.0 * g.M * (double)g.N * k;
-    const double bytes = ((double)g.M * k + (double)g.N * k + (double)g.M * g.N) * sizeof(T);
+    // COMPULSORY bytes of the launch (what an ideal kernel moves once): operands + weights + every output / read-modify-write the epilogue owns.
+    // A 3x3 conv reads its input MAP once (M x C, not the 9x im2col rows); the fused side input is a second map; a residual add reads one more.
+    const double e = sizeof(T);
+    double bytes = (double)g.N * k * e;                                                       // weights
+    if (amode == AMODE_CONV3) bytes += (double)g.M * g.C * e * (g.a2 ? 2 : 1);                 // input map (+ side map)
+    else bytes += (double)g.M * k * e;                                                        // A rows
+    switch (g.epi) {
+    case EPI_RESID: bytes += (double)g.M * g.N * (8.0 + (g.x16 ? 2.0 : 0.0)) + (g.ln_part ? (double)g.M * (g.N / 32) * 8.0 : 0.0); break;   // fp32 x read + write, fp16 copy, LN partials
+    case EPI_PATCH: bytes += (double)g.M * g.N * 8.0; break;                                  // + pos read, fp32 x write
+    default: bytes += (double)g.M * g.N * e * (g.add ? 2 : 1); break;                         // STORE / QKV / CONVT: the outputs (+ the added map)
+    }
     if (cls == MOGE_KC_GEMM && amode == AMODE_LINEAR && std::is_same<T, f16>::value && gemm_runs_pp(g)) cls = MOGE_KC_GEMM_PP;
     ProfScope ps(h, st, cls, flops, bytes);
     LCHK(launch_gemm<T>(g, amode, st));
@@ -556,15 +566,36 @@ static int convT2(moge_handle* h, const T* in, const T* w, const float* biasT, T
     return run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_CONV, st);
 }
 
+// n residual blocks x = x + conv2(relu(conv1(relu(x))))   (modules.py:47-68 with norms = Identity) on x, tmp = scratch of the same size.
+// Returns the result in *res: x, or tmp when `may_swap` and an odd number of blocks ran FUSED - the fused kernel (conv_rb.hip: both convs in one
+// launch, the intermediate map never leaves LDS) cannot run in place, a neighbouring tile still needs the input pixels it would overwrite.
 template <typename T>
-static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* x, T* tmp, int B, int Hh, int Ww, int C, hipStream_t st) {
+static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* x, T* tmp, int B, int Hh, int Ww, int C, hipStream_t st, bool may_swap = false,
+                      T** res = nullptr) {
+    T* cur = x; T* oth = tmp;
     for (int j = 0; j < n; j++) {
-        // x = x + conv2(relu(conv1(relu(x))))   (modules.py:47-68 with norms = Identity)
-        CHK(conv3x3<T>(h, x, P<T>(h, name + S(".res%d.%d.w1", l, j)), M(h, name + S(".res_blocks.%d.%d.layers.2.bias", l, j)), tmp, B, Hh, Ww, C, C, 1,
-                       ACT_RELU, nullptr, nullptr, st));
-        CHK(conv3x3<T>(h, tmp, P<T>(h, name + S(".res%d.%d.w2", l, j)), M(h, name + S(".res_blocks.%d.%d.layers.5.bias", l, j)), x, B, Hh, Ww, C, C, 0,
-                       ACT_NONE, x, nullptr, st));
+        const T* w1 = P<T>(h, name + S(".res%d.%d.w1", l, j)); const T* w2 = P<T>(h, name + S(".res%d.%d.w2", l, j));
+        const float* b1 = M(h, name + S(".res_blocks.%d.%d.layers.2.bias", l, j)); const float* b2 = M(h, name + S(".res_blocks.%d.%d.layers.5.bias", l, j));
+        if (std::is_same<T, f16>::value && moge_tune_get("CONV_RB", 1) && (may_swap || ((n - j) >= 2) || cur != x)) {
+            // (without may_swap the result must end in x: fuse blocks in pairs, or the last one when the data currently sits in tmp)
+            GemmArgs g = gemm_args();
+            g.a = cur; g.H = Hh; g.W = Ww; g.C = C; g.relu_in = 1; g.w = w1; g.ldw = 9 * C; g.M = B * Hh * Ww; g.N = C; g.K = 9 * C;
+            g.epi = EPI_STORE; g.act = ACT_NONE; g.bias = b1; g.out = oth; g.ldc = C; g.add = cur; g.ldadd = C; g.pixW = Ww; g.pixH = Hh;
+            g.rb_w2 = w2; g.rb_bias2 = b2;
+            if (conv_rb_eligible(g)) {
+                // algorithmic work = the two convs; bytes = input map + both weight sets + output map (the skip rows are the input map again, from L2)
+                ProfScope ps(h, st, MOGE_KC_CONV, 2.0 * 2.0 * g.M * (double)C * 9.0 * C, (2.0 * g.M * C + 2.0 * 9.0 * C * C) * sizeof(T));
+                LCHK(launch_conv_rb(g, st));
+                std::swap(cur, oth);
+                continue;
+            }
+        }
+        if (cur != x) return fail(MOGE_ERR_INVALID, "res_blocks: internal buffer order");      // (unreachable: an unfused block only follows an even number of fused ones)
+        CHK(conv3x3<T>(h, cur, w1, b1, oth, B, Hh, Ww, C, C, 1, ACT_RELU, nullptr, nullptr, st));
+        CHK(conv3x3<T>(h, oth, w2, b2, cur, B, Hh, Ww, C, C, 0, ACT_NONE, cur, nullptr, st));
     }
+    if (res) *res = cur;
+    else if (cur != x) return fail(MOGE_ERR_INVALID, "res_blocks: result left in the scratch buffer");
     return 0;
 }
 
@@ -812,7 +843,11 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
                 CHK(conv1x1<T>(h, N[l], P<T>(h, name + S(".in%d.w", l)), M(h, name + S(".input_blocks.%d.bias", l)), Sc[nxt], (long)B * Hh * Ww, co, co, Sc[nxt],
                                nullptr, Ww, Hh, st));
             cur = nxt;
-            CHK(res_blocks<T>(h, name, l, c.head_res_blocks[l], Sc[cur], Sc[(cur + 1) % 3], B, Hh, Ww, co, st));
+            {
+                T* r = nullptr;                 // fused blocks ping-pong between the two buffers: follow the result
+                CHK(res_blocks<T>(h, name, l, c.head_res_blocks[l], Sc[cur], Sc[(cur + 1) % 3], B, Hh, Ww, co, st, true, &r));
+                if (r != Sc[cur]) cur = (cur + 1) % 3;
+            }
         }
         {
             ProfScope ps(h, st, MOGE_KC_POST, 0, (double)B * (rows << 4) * (cols << 4) * c.dims[4] * sizeof(T));
@@ -1080,9 +1115,13 @@ int moge_create_v1(const moge_v1_config* cfg, int device, moge_handle** out) {
     if (c.n_taps < 1 || c.n_taps > MOGE_MAX_TAPS) return fail(MOGE_ERR_INVALID, "bad n_taps");
     if (c.n_up < 1 || c.n_up > MOGE_V1_MAX_UP) return fail(MOGE_ERR_INVALID, "bad number of upsample stages");
     if (c.dim_proj % 32 != 0 || c.dim_proj <= 0) return fail(MOGE_ERR_INVALID, "dim_proj must be a positive multiple of 32");
-    for (int i = 0; i < c.n_up; i++)
-        if (c.dim_upsample[i] % 32 != 0 || c.dim_upsample[i] <= 0 || c.dim_upsample[i] > 512)
-            return fail(MOGE_ERR_INVALID, "dim_upsample entries must be multiples of 32 (GroupNorm(C / 32, C)), <= 512");
+    for (int i = 0; i < c.n_up; i++) {
+        // GroupNorm(1, C) and GroupNorm(C / 32, C) run on gn_partial's fixed slabs: 256 threads must hold a whole number of pixel rows of
+        // C / 8 (fp16) and C / 4 (fp32) chunks - a power of two.  Rejected HERE, not at the first forward with a generic launch error.
+        const int C = c.dim_upsample[i];
+        if (C != 32 && C != 64 && C != 128 && C != 256 && C != 512)
+            return fail(MOGE_ERR_INVALID, "dim_upsample[%d] = %d: supported widths are 32, 64, 128, 256, 512 (GroupNorm(C / 32, C) slabs need a power of two)", i, C);
+    }
     if (c.last_conv_channels != 32 && c.last_conv_channels != 64 && c.last_conv_channels != 16)
         return fail(MOGE_ERR_INVALID, "last_conv_channels must be 16, 32 or 64");
     if (c.num_res_blocks < 0 || c.num_res_blocks > 8) return fail(MOGE_ERR_INVALID, "bad num_res_blocks");
@@ -1351,15 +1390,17 @@ int moge_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, i
     return post_impl(h, pl, out->points, nrm, mp, metric, fov_x_deg, flags, out, st);
 }
 
-static int v1_check(moge_handle* h, const void* image, int B, int H, int W, int rh, int rw) {
+static int v1_check(moge_handle* h, const void* image, int B, int H, int W, int rh, int rw, void* stream) {
     CHK(check_call(h, image, B, H, W, rh / 14, rw / 14, 1));
     if (rh < 14 || rw < 14) return fail(MOGE_ERR_INVALID, "resized image %dx%d is smaller than one 14x14 patch", rh, rw);
-    if (!h->pk_ready[h->prec]) CHK(moge_set_precision(h, h->prec, nullptr));
+    // lazy weight packing runs on the CALL's stream (as forward_dispatch does for v2): on the NULL stream it would race the forward of a
+    // caller that uses a hipStreamNonBlocking stream and never called moge_set_precision
+    if (!h->pk_ready[h->prec]) CHK(moge_set_precision(h, h->prec, stream));
     return 0;
 }
 
 int moge_v1_forward(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int resized_h, int resized_w, const moge_outputs* out, void* stream) {
-    CHK(v1_check(h, image, B, H, W, resized_h, resized_w));
+    CHK(v1_check(h, image, B, H, W, resized_h, resized_w, stream));
     if (!out) return fail(MOGE_ERR_INVALID, "null outputs");
     hipStream_t st = (hipStream_t)stream;
     CHK(ingest_image(h, image, img_dtype, B, H, W, st));
@@ -1371,7 +1412,7 @@ int moge_v1_forward(moge_handle* h, const void* image, int img_dtype, int B, int
 
 int moge_v1_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int resized_h, int resized_w, const float* fov_x_deg, int flags,
                   const moge_outputs* out, void* stream) {
-    CHK(v1_check(h, image, B, H, W, resized_h, resized_w));
+    CHK(v1_check(h, image, B, H, W, resized_h, resized_w, stream));
     if (!out || !out->points || !out->depth) return fail(MOGE_ERR_INVALID, "points and depth output buffers are required");
     hipStream_t st = (hipStream_t)stream;
     CHK(ingest_image(h, image, img_dtype, B, H, W, st));

@@ -158,6 +158,62 @@ static int t_conv3(const float* x, const float* w, const float* bias, float* y, 
     return 0;
 }
 
+// One 3x3 conv through the optional pieces the decoder fuses into it (conv_pp.hip flavours; gemm.hip takes the shapes / precision conv_pp
+// does not): ReLU prologue, activation, residual add, fused 1x1 side input, uv term, pixel-shuffle resampler (up2), fused residual block.
+template <typename T>
+static int t_conv_ex(const moge_test_conv_args& a, hipStream_t st) {
+    const int B = a.B, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, up2 = a.up2;
+    const int Ho = up2 ? 2 * H : H, Wo = up2 ? 2 * W : W;
+    const size_t nx = (size_t)B * H * W * Cin, ny = (size_t)B * Ho * Wo * Cout;
+    DevBuf xb, wb, yb, bb, addb, sideb, sidew, w2b;
+    TCHK(xb.alloc(nx * sizeof(T))); TCHK(wb.alloc((size_t)4 * Cout * 9 * Cin * sizeof(T))); TCHK(yb.alloc(ny * sizeof(T))); TCHK(bb.alloc(4 * Cout * sizeof(float)));
+    TL(to_t<T>(a.x, xb.p, (long)nx, st));
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.a = xb.p; g.H = H; g.W = W; g.C = Cin; g.relu_in = a.relu_in;
+    g.w = wb.p; g.ldw = 9 * Cin; g.M = B * H * W; g.K = 9 * Cin; g.out = yb.p; g.pixW = W; g.pixH = H; g.act = a.act;
+    if (up2) {
+        if (a.add || a.side || a.w2) return MOGE_ERR_INVALID;
+        TL(launch_pack_phase_conv<T>(a.w, wb.p, Cout, Cin, st));
+        TL(launch_repack<float>(a.bias, bb.p, 4, 1, 1, Cout, 0, 0, 0, 1, Cout, 0, 0, st));
+        g.N = 4 * Cout; g.epi = EPI_CONVT; g.bias = (const float*)bb.p; g.Cout = Cout;
+    } else {
+        TL(launch_repack<T>(a.w, wb.p, Cout, 9, 1, Cin, (long)Cin * 9, 1, 0, 9, (long)9 * Cin, Cin, 0, st));
+        g.N = Cout; g.epi = EPI_STORE; g.bias = a.bias; g.ldc = Cout;
+    }
+    if (a.wu) {
+        g.uv.wu = a.wu; g.uv.wv = a.wv; g.uv.u0 = a.u0; g.uv.u1 = a.u1; g.uv.v0 = a.v0; g.uv.v1 = a.v1;
+        g.uv.ustep = Wo > 1 ? (a.u1 - a.u0) / (float)(Wo - 1) : 0.f;
+        g.uv.vstep = Ho > 1 ? (a.v1 - a.v0) / (float)(Ho - 1) : 0.f;
+    }
+    if (a.add) {
+        TCHK(addb.alloc(ny * sizeof(T)));
+        TL(to_t<T>(a.add, addb.p, (long)ny, st));
+        g.add = addb.p; g.ldadd = Cout;
+    }
+    if (a.side) {
+        if (!a.side_w || Cin != Cout) return MOGE_ERR_INVALID;
+        TCHK(sideb.alloc(nx * sizeof(T))); TCHK(sidew.alloc((size_t)Cout * Cin * sizeof(T)));
+        TL(to_t<T>(a.side, sideb.p, (long)nx, st));
+        TL(to_t<T>(a.side_w, sidew.p, (long)Cout * Cin, st));
+        g.a2 = sideb.p; g.w2 = sidew.p;
+        if (!std::is_same<T, f16>::value || !conv_pp_eligible(g)) return MOGE_ERR_INVALID;      // only the halo kernel fuses the side input
+    }
+    if (a.w2) {                                   // fused residual block (modules.py:47-68): y = x + conv2(relu(conv1(relu(x)) + b1)) + b2
+        if (!std::is_same<T, f16>::value || up2 || a.side || a.add || a.wu || Cin != Cout || !a.bias2) return MOGE_ERR_INVALID;
+        TCHK(w2b.alloc((size_t)Cout * 9 * Cin * sizeof(T)));
+        TL(launch_repack<T>(a.w2, w2b.p, Cout, 9, 1, Cin, (long)Cin * 9, 1, 0, 9, (long)9 * Cin, Cin, 0, st));
+        GemmArgs r = g;
+        r.relu_in = 1; r.act = ACT_NONE; r.rb_w2 = w2b.p; r.rb_bias2 = a.bias2; r.add = xb.p; r.ldadd = Cin;
+        if (!conv_rb_eligible(r)) return MOGE_ERR_INVALID;
+        TL(launch_conv_rb(r, st));
+    } else {
+        TL(launch_gemm<T>(g, AMODE_CONV3, st));
+    }
+    TL(from_t<T>(yb.p, a.y, (long)ny, st));
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
 template <typename T>
 static int t_convt(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
     DevBuf xb, wb, yb, bb;
@@ -223,6 +279,12 @@ int moge_test_conv3x3(int precision, const float* x, const float* w, const float
     hipStream_t st = (hipStream_t)stream;
     const int up2 = (relu_in >> 1) & 1, relu = relu_in & 1;      // bit 1 of relu_in selects bilinear x2 + 3x3 (4-phase conv)
     return precision == MOGE_FP16 ? t_conv3<f16>(x, w, bias, y, B, H, W, Cin, Cout, relu, up2, st) : t_conv3<float>(x, w, bias, y, B, H, W, Cin, Cout, relu, up2, st);
+}
+
+int moge_test_conv_ex(const moge_test_conv_args* args, void* stream) {
+    if (!args) return MOGE_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    return args->precision == MOGE_FP16 ? t_conv_ex<f16>(*args, st) : t_conv_ex<float>(*args, st);
 }
 
 int moge_test_convt2x2(int precision, const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, void* stream) {

@@ -229,7 +229,9 @@ _SPECTRAL = np.array([[158, 1, 66], [213, 62, 79], [244, 109, 67], [253, 174, 97
 def colorize_depth(depth: np.ndarray, mask: Optional[np.ndarray] = None, normalize: bool = True) -> np.ndarray:
     """moge/utils/vis.py:7-18 (Spectral colour map over normalised disparity; matplotlib is not installed, the map is tabulated above)."""
     with np.errstate(divide="ignore", invalid="ignore"):
-        d = np.where((depth > 0) & np.isfinite(depth) & (True if mask is None else mask), depth, np.nan)
+        # exactly the reference's filter: an infinite depth (infer()'s masked pixels with apply_mask=True) PASSES `depth > 0`, becomes disparity
+        # 0, takes part in the quantile normalisation and is painted the colour map's far end - not black
+        d = np.where((depth > 0) & (True if mask is None else mask), depth, np.nan)
         disp = 1 / d
         if normalize and np.isfinite(disp).any():
             lo, hi = np.nanquantile(disp, 0.001), np.nanquantile(disp, 0.99)

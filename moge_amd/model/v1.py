@@ -41,6 +41,8 @@ class MoGeModel(_MoGeModelV2):
         taps = list(range(depth - intermediate_layers, depth)) if isinstance(intermediate_layers, int) else list(intermediate_layers)
         if not 1 <= len(dim_upsample) <= L.MOGE_V1_MAX_UP:
             raise NotImplementedError("1..4 upsample stages")
+        if any(d not in (32, 64, 128, 256, 512) for d in dim_upsample):
+            raise NotImplementedError(f"dim_upsample {list(dim_upsample)}: supported widths are 32, 64, 128, 256, 512 (GroupNorm slab kernels)")
         self.encoder = encoder
         self.remap_output = remap_output
         self.intermediate_layers = intermediate_layers
@@ -73,6 +75,7 @@ class MoGeModel(_MoGeModelV2):
         self.sync_on_infer = True
 
     BLOB_MAGIC = b"MOGE-MI355X-MASTER-BLOB-v1\n"
+    MODEL_VERSION = "v1"              # checked by read_blob_header: a MoGe-2 blob / sidecar is rejected (ValueError -> from_pretrained falls back to the checkpoint)
 
     def _create(self, h) -> int:
         return L.lib.moge_create_v1(C.byref(self._cfg), self._device.index, C.byref(h))

@@ -240,12 +240,14 @@ class MoGeModel:
     # as the library lays it out in HBM (order = f(config) only, `build_tables` in csrc/model.hip), i.e. what the RCCL broadcast ships.
     # Loading it is one H2D copy + the on-device packing kernels: no torch.load / unpickling, no per-tensor name lookup.
     BLOB_MAGIC = b"MOGE-MI355X-MASTER-BLOB-v1\n"
+    MODEL_VERSION = "v2"              # recorded in the blob header: a MoGe-1 blob (same container, moge_amd/model/v1.py) is not a MoGe-2 blob
 
     def save_blob(self, path: Union[str, Path]) -> None:
         """Write the device-resident fp32 master blob (+ model_config) to `path` (the model must be on a GPU with weights loaded)."""
         self._require_ready()
         blob = self.master_blob()
-        header = json.dumps({"model_config": self.model_config, "nbytes": int(blob.numel()), "layout": "moge_master_blob fp32, build_tables order"}).encode()
+        header = json.dumps({"model_version": self.MODEL_VERSION, "model_config": self.model_config, "nbytes": int(blob.numel()),
+                             "layout": "moge_master_blob fp32, build_tables order"}).encode()
         host = blob.cpu().numpy()
         with open(path, "wb") as f:
             f.write(self.BLOB_MAGIC)
@@ -262,6 +264,9 @@ class MoGeModel:
             n = int.from_bytes(f.read(8), "little")
             header = json.loads(f.read(n).decode())
             off = f.tell()
+        # (blobs written before the field existed are MoGe-2 blobs)
+        if header.get("model_version", "v2") != cls.MODEL_VERSION:
+            raise ValueError(f"{path}: master blob of model version {header.get('model_version')!r}, this class is {cls.MODEL_VERSION!r}")
         off += (-off) % 4096
         if os.path.getsize(path) != off + header["nbytes"]:
             raise ValueError(f"{path}: truncated master blob (expected {off + header['nbytes']} bytes)")

@@ -124,6 +124,10 @@ CASES = [
          kwargs=dict(use_fp16=False), stride=7),
     dict(name="vitl_normal_1036x518", config="moge-2-vitl-normal", seed=0, sane=True, input="rand", input_seed=1, shape=[1, 3, 1036, 518],
          kwargs=dict(use_fp16=False), stride=7),
+    # the bench workload again with a DINOv2-like residual stream (oracle.add_massive_activations: three residual channels at -380 ... +600
+    # and a common offset of 3 from block 2 on, all other channels O(1)): what the fp16 LayerNorm fold does when |x| / sigma is large
+    dict(name="vitl_518_t3600_massive", config="moge-2-vitl", seed=0, sane=True, massive=True, input="rand", input_seed=0, shape=[1, 3, 518, 518],
+         kwargs=dict(use_fp16=False), stride=7),
 ]
 CASES += [
     # MoGe-1 (moge/model/v1.py): real v1 class on synthetic checkpoints
@@ -142,8 +146,16 @@ def oracle_module(case: dict):
     return O1 if case.get("version") == "v1" else O
 
 
+def case_state_dict(case: dict, cfg: dict):
+    """The synthetic checkpoint of a case (every consumer - reference run, oracle, HIP tests - builds it through here)."""
+    sd = oracle_module(case).synth_state_dict(cfg, case["seed"], case["sane"])
+    if case.get("massive"):
+        O.add_massive_activations(sd, cfg)
+    return sd
+
+
 # the cases whose reference run takes more than a few seconds on 8 cores (the CPU suite replays the oracle on the fast ones only)
-SLOW_CASES = ("vits_house518", "vitb_normal_518_t3600", "vitl_518_t3600", "vitl_normal_518x1036", "vitl_normal_1036x518", "v1_vitl_518")
+SLOW_CASES = ("vits_house518", "vitb_normal_518_t3600", "vitl_518_t3600", "vitl_normal_518x1036", "vitl_normal_1036x518", "v1_vitl_518", "vitl_518_t3600_massive")
 
 
 def run_reference(case: dict):
@@ -152,7 +164,7 @@ def run_reference(case: dict):
     OM = oracle_module(case)
     MoGeModel = import_model_class_by_version(case.get("version", "v2"))
     cfg = OM.named_configs()[case["config"]]
-    sd = OM.synth_state_dict(cfg, case["seed"], case["sane"])
+    sd = case_state_dict(case, cfg)
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "model.pt")
         OM.save_checkpoint(path, cfg, sd)

@@ -226,6 +226,23 @@ def synth_state_dict(cfg: dict, seed: int = 0, sane_geometry: bool = True) -> Di
     return sd
 
 
+def add_massive_activations(sd: Dict[str, torch.Tensor], cfg: dict, block: int = 2,
+                            channels=((7, 450.0), (300, -380.0), (901, 600.0)), mean_offset: float = 3.0) -> Dict[str, torch.Tensor]:
+    """Put the residual stream into the numerical regime of PRETRAINED DINOv2 weights (SURVEY.md 7 hard-part 3; block.py:110-112): from
+    `block` on, a few residual channels sit hundreds of times above the rest ("massive activations") and every token carries a common
+    channel offset.  synth_state_dict keeps everything O(1) by construction, which never exercises what an fp16 path does with such a
+    stream (the reference's autocast path normalises in fp32 first: block.py:90,93).  Done through one block's LayerScale'd MLP bias:
+    x += gamma * (fc2(h) + b)  ->  b += offset / gamma on every channel, gamma[c] = 1 and b[c] = value on the outlier channels."""
+    p = f"encoder.backbone.blocks.{block}."
+    gam, b = sd[p + "ls2.gamma"], sd[p + "mlp.fc2.bias"]
+    b += mean_offset / gam
+    D = gam.numel()
+    for c, v in channels:
+        gam[c % D] = 1.0
+        b[c % D] = v
+    return sd
+
+
 def save_checkpoint(path: str, cfg: dict, sd: Dict[str, torch.Tensor]) -> None:
     """Reference checkpoint format (moge/scripts/train.py:379-383)."""
     torch.save({"model_config": cfg, "model": sd}, path)

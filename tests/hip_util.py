@@ -151,3 +151,35 @@ def groupnorm_relu(prec, x_nhwc, gamma, beta, groups):
     y = torch.empty_like(x)
     L.check(L.lib.moge_test_groupnorm_relu(prec, _p(x), _p(gamma), _p(beta), _p(y), B, H, W, Cc, groups, st()))
     return y
+
+
+def conv_ex(x_nhwc, w, bias, prec=1, relu_in=False, act=0, add=None, side=None, side_w=None, uv=None, up2=False, w2=None, bias2=None):
+    """One 3x3 conv through the pieces the decoder fuses into it (moge_test_conv_ex).  uv = (wu, wv, u0, u1, v0, v1) at the OUTPUT resolution;
+    w2 / bias2 select the fused residual block (conv_rb.hip)."""
+    import ctypes as C
+    keep = []
+
+    def dev(t):
+        if t is None:
+            return None
+        t = _f(t)
+        keep.append(t)
+        return t.data_ptr()
+
+    x = _f(x_nhwc)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+    y = torch.empty((B, Ho, Wo, Cout), device="cuda", dtype=torch.float32)
+    a = L.TestConvArgs()
+    a.precision, a.B, a.H, a.W, a.Cin, a.Cout = prec, B, H, W, Cin, Cout
+    a.relu_in, a.act, a.up2 = int(bool(relu_in)), act, int(bool(up2))
+    a.x, a.w, a.bias = x.data_ptr(), dev(w), dev(bias)
+    a.add, a.side, a.side_w = dev(add), dev(side), dev(side_w)
+    if uv is not None:
+        wu, wv, u0, u1, v0, v1 = uv
+        a.wu, a.wv, a.u0, a.u1, a.v0, a.v1 = dev(wu), dev(wv), u0, u1, v0, v1
+    a.w2, a.bias2 = dev(w2), dev(bias2)
+    a.y = y.data_ptr()
+    L.check(L.lib.moge_test_conv_ex(C.byref(a), st()))
+    return y

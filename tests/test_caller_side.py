@@ -107,8 +107,16 @@ def test_colorize_helpers():
     from moge_amd import io as IO
     d = np.linspace(0.5, 5.0, 200, dtype=np.float32).reshape(10, 20)
     d[0, 0] = np.inf
+    d[9, 0] = -1.0
     col = IO.colorize_depth(d)
-    assert col.shape == (10, 20, 3) and col.dtype == np.uint8 and (col[0, 0] == 0).all()
+    # moge/utils/vis.py:7-18: an infinite depth (a masked pixel of infer(apply_mask=True)) passes `depth > 0`, becomes disparity 0 and is painted
+    # the colour map's far end; only depth <= 0 / NaN pixels are black
+    assert col.shape == (10, 20, 3) and col.dtype == np.uint8 and (col[0, 0] == [94, 79, 162]).all() and (col[9, 0] == 0).all()
+    sky = d.copy(); sky[:4] = np.inf                              # > 0.1 % masked: the reference's min_disp becomes 0 and the whole image shifts
+    cs = IO.colorize_depth(sky)
+    disp = 1.0 / np.where(sky > 0, sky, np.nan)
+    lo, hi = np.nanquantile(disp, 0.001), np.nanquantile(disp, 0.99)
+    assert lo == 0.0 and (cs[:4] == [94, 79, 162]).all() and not (cs[5:] == col[5:]).all()
     near, far = col[0, 1].astype(int), col[-1, -1].astype(int)
     assert near[0] > near[2] and far[2] > far[0]                 # Spectral over 1 - disparity: near = red end, far = blue end
     n = np.zeros((2, 2, 3), dtype=np.float32); n[..., 2] = 1.0

@@ -29,14 +29,16 @@ def MoGeModel():
 _models = {}
 
 
-def get_model(MoGeModel, cfg_name, seed, sane, tmp_path_factory):
+def get_model(MoGeModel, cfg_name, seed, sane, tmp_path_factory, massive=False):
     from oracle import moge_oracle as O
-    key = (cfg_name, seed, sane)
+    key = (cfg_name, seed, sane, massive)
     if key not in _models:
         if len(_models) >= 3:                      # vitl / vitb models hold ~2 GB of device memory each: keep a few, not all
             _models.pop(next(iter(_models)))
         cfg = O.named_configs()[cfg_name]
         sd = O.synth_state_dict(cfg, seed, sane)
+        if massive:
+            O.add_massive_activations(sd, cfg)
         path = os.path.join(str(tmp_path_factory.mktemp("ckpt")), "model.pt")
         O.save_checkpoint(path, cfg, sd)
         _models[key] = (MoGeModel.from_pretrained(path).to("cuda").eval(), cfg, sd)      # through the reference's loader contract
@@ -59,7 +61,7 @@ def test_fp32_mode_matches_reference_golden_and_oracle(MoGeModel, name, tmp_path
     """Every fixture, incl. the BASELINE-size ones (moge-2-vitl 518x518 T=3600, moge-2-vitb-normal, the 518x1036 / 1036x518 grids 42x85 / 85x42)."""
     from oracle import moge_oracle as O
     case, cfg, sd, x, gold, meta = load_case(name)
-    model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory)
+    model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory, bool(case.get("massive")))
     kw = dict(case["kwargs"]); kw["use_fp16"] = False
     model.onnx_compatible_mode = bool(case.get("onnx"))        # docs/onnx.md: fixtures "tiny_onnx_mode_*" were made with the flag set
     try:
@@ -86,7 +88,7 @@ def test_fp16_mode_within_reference_fp16_band(MoGeModel, name, tmp_path_factory)
     """fp16 mode, both forms the reference has (.half() weights; fp32 weights + use_fp16=True), against the reference's fp32 golden inside
     2x the reference's own fp16 drift on that case."""
     case, cfg, sd, x, gold, meta = load_case(name)
-    model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory)
+    model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory, bool(case.get("massive")))
     kw = dict(case["kwargs"]); kw["use_fp16"] = True
     st = case.get("stride", 1)
     band = fp16_band(meta, gold)
@@ -114,7 +116,7 @@ def test_fp16_throughput_kernels_in_the_model_match_reference_golden(MoGeModel, 
     must (a) stay inside the reference-fp16 band of the fixture and (b) reproduce the single-image result bit for bit."""
     from moge_amd import _lib as L
     case, cfg, sd, x, gold, meta = load_case(name)
-    model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory)
+    model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory, bool(case.get("massive")))
     kw = dict(case["kwargs"]); kw["use_fp16"] = True
     st = case.get("stride", 1)
     band, g = fp16_band(meta, gold), golden_infer(gold)
@@ -160,7 +162,7 @@ def test_stage_taps_match_oracle(MoGeModel, tmp_path_factory):
     """Stage boundaries of one forward (fp32 mode): LayerNorm'ed ViT taps, cls token, encoder features, every neck level."""
     from oracle import moge_oracle as O
     case, cfg, sd, x, gold, meta = load_case("tiny_b2_up")
-    model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory)
+    model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory, bool(case.get("massive")))
     model.float()
     fwd = model.forward(x, case["kwargs"]["num_tokens"])
     tr = {}

@@ -512,6 +512,66 @@ static int bench_conv(const char* filter, int iters) {
     return fails;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fused residual block (conv_rb.hip) against the two conv_pp launches it replaces: bit-identical results, time of both
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void cmp_bits(const f16* a, const f16* b, size_t n, int* nbad) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned short x = __builtin_bit_cast(unsigned short, a[i]), y = __builtin_bit_cast(unsigned short, b[i]);
+        if (x != y) atomicAdd(nbad, 1);
+    }
+}
+static int bench_rb(int iters) {
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    struct Case { const char* name; int B, H, W; };
+    const Case cases[] = {{"L3 resblock 480x480 b32", 32, 480, 480}, {"L3 resblock 480x480 b16", 16, 480, 480}, {"L3 resblock 518x1036-grid b8", 8, 336, 680}, {"odd 50x37 b3", 3, 50, 37}};
+    int fails = 0;
+    const int rounds = getenv("KB_ROUNDS") ? atoi(getenv("KB_ROUNDS")) : 3;
+    for (const Case& c : cases) {
+        const size_t px = (size_t)c.B * c.H * c.W, n = px * 64, nw = (size_t)64 * 576;
+        f16 *x, *h, *y0, *y1, *w1, *w2; float *b1, *b2; int* dbad;
+        CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&h, n * 2)); CK(hipMalloc(&y0, n * 2)); CK(hipMalloc(&y1, n * 2)); CK(hipMalloc(&w1, nw * 2)); CK(hipMalloc(&w2, nw * 2));
+        CK(hipMalloc(&b1, 256)); CK(hipMalloc(&b2, 256)); CK(hipMalloc(&dbad, 4));
+        fill_f16<<<2048, 256, 0, st>>>(x, n, 31u, 1.0f);
+        fill_f16<<<256, 256, 0, st>>>(w1, nw, 32u, 0.06f);
+        fill_f16<<<256, 256, 0, st>>>(w2, nw, 33u, 0.06f);
+        fill_f32<<<1, 64, 0, st>>>(b1, 64, 34u, 0.5f, 0.f);
+        fill_f32<<<1, 64, 0, st>>>(b2, 64, 35u, 0.5f, 0.f);
+        GemmArgs g1; memset(&g1, 0, sizeof(g1));
+        g1.a = x; g1.H = c.H; g1.W = c.W; g1.C = 64; g1.relu_in = 1; g1.w = w1; g1.ldw = 576; g1.M = (int)px; g1.N = 64; g1.K = 576;
+        g1.epi = EPI_STORE; g1.act = ACT_RELU; g1.bias = b1; g1.out = h; g1.ldc = 64; g1.ldadd = 64; g1.pixW = c.W; g1.pixH = c.H;
+        GemmArgs g2 = g1; g2.a = h; g2.relu_in = 0; g2.w = w2; g2.act = ACT_NONE; g2.bias = b2; g2.out = y0; g2.add = x;
+        GemmArgs gr = g1; gr.act = ACT_NONE; gr.out = y1; gr.add = x; gr.rb_w2 = w2; gr.rb_bias2 = b2;
+        if (!conv_rb_eligible(gr)) { printf("rb %s: not eligible\n", c.name); fails++; continue; }
+        auto two = [&]() { launch_gemm<f16>(g1, AMODE_CONV3, st); launch_gemm<f16>(g2, AMODE_CONV3, st); };
+        auto one = [&]() { launch_conv_rb(gr, st); };
+        CK(hipMemsetAsync(y0, 0, n * 2, st)); CK(hipMemsetAsync(y1, 0xff, n * 2, st));
+        two(); one();
+        CK(hipMemsetAsync(dbad, 0, 4, st));
+        cmp_bits<<<2048, 256, 0, st>>>(y1, y0, n, dbad);
+        int hbad; CK(hipMemcpyAsync(&hbad, dbad, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+        double ms[2] = {0, 0}, mn[2] = {1e30, 1e30};
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int r = 0; r < rounds; r++)
+            for (int v = 0; v < 2; v++) {
+                if (v) one(); else two();
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < iters; i++) { if (v) one(); else two(); }
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                float t; CK(hipEventElapsedTime(&t, e0, e1)); t /= iters;
+                ms[v] += t; mn[v] = t < mn[v] ? t : mn[v];
+            }
+        const double fl = 2.0 * 2.0 * px * 64.0 * 576.0;          // algorithmic: the two convs
+        printf("resblock %-30s two launches %8.3f ms (min %.3f) %7.1f TF/s | fused %8.3f ms (min %.3f) %7.1f TF/s | differing values %d / %zu %s\n", c.name, ms[0] / rounds,
+               mn[0], fl / (ms[0] / rounds) / 1e9, ms[1] / rounds, mn[1], fl / (ms[1] / rounds) / 1e9, hbad, n, hbad ? "FAIL" : "bit-identical");
+        fflush(stdout);
+        if (hbad) fails++;
+        CK(hipFree(x)); CK(hipFree(h)); CK(hipFree(y0)); CK(hipFree(y1)); CK(hipFree(w1)); CK(hipFree(w2)); CK(hipFree(b1)); CK(hipFree(b2)); CK(hipFree(dbad));
+    }
+    return fails;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: kbench gemm|attn [filter] [iters]\n"); return 1; }
     CK(hipSetDevice(0));
@@ -520,6 +580,7 @@ int main(int argc, char** argv) {
     if (!strcmp(argv[1], "gemm")) return bench_gemm(filter, iters) ? 4 : 0;
     if (!strcmp(argv[1], "attn")) return bench_attn(iters) ? 4 : 0;
     if (!strcmp(argv[1], "conv")) return bench_conv(filter, iters) ? 4 : 0;
+    if (!strcmp(argv[1], "rb")) return bench_rb(iters) ? 4 : 0;
     fprintf(stderr, "unknown bench %s\n", argv[1]);
     return 1;
 }

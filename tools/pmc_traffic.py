@@ -32,8 +32,23 @@ def main(tag):
             calls += c
             fb += c * f * 1024 * 2
             wb += c * W[k][1] * 1024
+    # effective shader clock and MFMA-busy fraction of the same launches from the SQ / GRBM pass (tools/pmc_summary.py derives both per kernel:
+    # clock = GRBM_GUI_ACTIVE / 8 XCDs / duration, mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (that many cycles x 1024 SIMDs)), time-weighted
+    clock = util = tw = 0.0
+    mpath = os.path.join(ROOT, "profiles", f"{tag}_pmc_MFMA.csv")
+    if os.path.exists(mpath):
+        lines = open(mpath).read().strip().splitlines()
+        hdr = lines[0].split(",")
+        nc = len(hdr) - 1                              # columns after the kernel name
+        for ln in lines[1:]:
+            p = ln.rsplit(",", nc)
+            rec = dict(zip(hdr[1:], p[1:]))
+            if "gemm_pp128p" in p[0] and int(rec["blocks"]) >= 256 and "clock_ghz" in rec:
+                w = int(rec["calls"]) * float(rec["avg_us"])
+                clock += w * float(rec["clock_ghz"]); util += w * float(rec["mfma_util"]); tw += w
     out = {
         "kernel": "gemm_pp128p_kernel", "launches": calls,
+        "clock_ghz": round(clock / tw, 3) if tw else None, "mfma_busy_at_that_clock": round(util / tw, 3) if tw else None,
         "fetch_bytes_per_launch": round(fb / calls), "write_bytes_per_launch": round(wb / calls),
         "traffic_bytes_per_launch": round((fb + wb) / calls),
         "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs, --kernel-trace only) of `python bench.py --steps 2 "
