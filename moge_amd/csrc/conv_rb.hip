@@ -153,6 +153,10 @@ __global__ __launch_bounds__(512, 2) void conv_rb_kernel(const GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // optional s_memtime timeline of workgroup 0 (tools/kbench rb with KB_TS): wave 0 and wave 4, eight stamps per tile for the first six tiles
+    unsigned long long* const ts = (g.dbg_ts && blockIdx.x == 0 && (wave & 3) == 0) ? g.dbg_ts + (wave >> 2) * 64 : nullptr;
+    int ts_tile = 0;
+#define RB_STAMP(i) do { if (ts && ts_tile < 6 && lane == 0) ts[ts_tile * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
     f32x4 acc1[3][4], acc2[2][4];
     int b, y0, x0;
     setup(li);
@@ -161,6 +165,7 @@ __global__ __launch_bounds__(512, 2) void conv_rb_kernel(const GemmArgs g) {
     bool first = true;
     for (;;) {                                        // ======== one tile per iteration ========
         b = sb; y0 = sy0; x0 = sx0;
+        RB_STAMP(0);
         asm volatile("" : "+v"(l15t));
 #pragma unroll
         for (int i = 0; i < 3; i++)
@@ -173,6 +178,7 @@ __global__ __launch_bounds__(512, 2) void conv_rb_kernel(const GemmArgs g) {
         if (grp == 1) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        RB_STAMP(1);
 
         // ---- conv1 on the in-halo: mid position m = 16*blk + l15 (pitch 20), in-halo pixel of tap (dy, dx): q = m + 21 + 20*dy + dx -----------
 #pragma unroll
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(512, 2) void conv_rb_kernel(const GemmArgs g) {
         // ---- transition: every wave has read its last in-halo fragment (group 0's last barrier pairs with the one group 1 passes after its
         // step-8 reads): the in-halo buffer and weight slot 0 are free.  Next tile's coordinates, W(12), then the next in-halo image (after the
         // last tile the workgroup re-requests its own, which nobody reads: the request count stays a compile-time constant) -------------------
+        RB_STAMP(2);
         bool more;
         {
             const int nli = li + wgs_x;
@@ -255,6 +262,7 @@ __global__ __launch_bounds__(512, 2) void conv_rb_kernel(const GemmArgs g) {
         if (grp == 1) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        RB_STAMP(3);
 
         // ---- conv2 on the mid tile: output rows 2*wave + i, column l15 ------------------------------------------------------------------------
 #pragma unroll
@@ -287,6 +295,7 @@ __global__ __launch_bounds__(512, 2) void conv_rb_kernel(const GemmArgs g) {
         }
 
         // ---- epilogue: + b2, fp16, transposed through this wave's 4 KiB of the (dead) mid buffer, + x, 16-byte pixel-row stores ------------
+        RB_STAMP(4);
         char* R = smem + RB_LDS_MID + wave * 4096;
         int rr = lane >> 3, cc = lane & 7;
         asm volatile("" : "+v"(rr), "+v"(cc));
@@ -315,6 +324,7 @@ __global__ __launch_bounds__(512, 2) void conv_rb_kernel(const GemmArgs g) {
         const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(g.out) + (size_t)b * H * W * g.ldc * 2)), 0, H * W * g.ldc * 2, 0x00020000);
         __builtin_amdgcn_s_waitcnt(0x0F70);          // a real vmcnt(0) the compiler accounts for: the skip rows are in (the in-halo landed long ago)
+        RB_STAMP(5);
         if (more) { issue_w(0); issue_w(1); issue_w(2); }      // next tile's first weight steps, in FRONT of the stores (vmcnt is in order)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -325,11 +335,14 @@ __global__ __launch_bounds__(512, 2) void conv_rb_kernel(const GemmArgs g) {
             h += addv[it];                                     // fp16 + fp16 as the two-launch path (and the reference's .half() model): x + conv(x), modules.py:66
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), ob, (int)ooff[it], 0, 0);
         }
+        RB_STAMP(6);
+        ts_tile++;
         if (!more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break; }      // no DMA may land in this CU's LDS after the workgroup has left
         first = false;
     }                                                 // ======== next tile ========
 }
 
+#undef RB_STAMP
 }  // namespace
 
 // fp16, C = Cin = Cout = 64, ReLU prologue, plain residual (add = the block's own input), no uv / side input

@@ -1,0 +1,35 @@
+#!/bin/bash
+# One gpurun call of round 3: tools/gpu_call.sh <tag> <what...>   (what: tests kb_rb kb_conv kb_gemm kb_attn bench ab_conv ...)
+tag=$1; shift
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $root
+export TMPDIR=/tmp
+out=gpurun_out
+mkdir -p $out
+for what in "$@"; do
+  case $what in
+    tests)      timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $out/${tag}_pytest.log 2>&1; tail -25 $out/${tag}_pytest.log ;;
+    tests_new)  timeout 600 python -m pytest tests/test_hip_conv_ex.py tests/test_hip_parity.py -m gpu -q -p no:cacheprovider -s > $out/${tag}_pytest_new.log 2>&1; tail -30 $out/${tag}_pytest_new.log ;;
+    kb_rb)      KB_ROUNDS=3 timeout 300 ./tools/kbench rb - 10 > $out/${tag}_kbench_rb.log 2>&1; cat $out/${tag}_kbench_rb.log ;;
+    kb_conv)    timeout 300 ./tools/kbench conv - 10 > $out/${tag}_kbench_conv.log 2>&1; cat $out/${tag}_kbench_conv.log ;;
+    kb_gemm)    KB_PP=1 KB_ROUNDS=3 timeout 400 ./tools/kbench gemm - 10 > $out/${tag}_kbench_gemm.log 2>&1; grep -v "^ " $out/${tag}_kbench_gemm.log | head -80 ;;
+    kb_attn)    timeout 300 ./tools/kbench attn - 10 > $out/${tag}_kbench_attn.log 2>&1; cat $out/${tag}_kbench_attn.log ;;
+    bench)      timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pcie > $out/${tag}_bench.json 2> $out/${tag}_bench.err; cat $out/${tag}_bench.json ;;
+    bench_full) timeout 900 python bench.py > $out/${tag}_bench_full.json 2> $out/${tag}_bench_full.err; cat $out/${tag}_bench_full.json ;;
+    ab_conv)    # same box, alternating: new conv forms off / on
+                for r in 1 2; do
+                  for v in 0 1; do
+                    MOGE_CONV_RB=$v MOGE_CONV_SIDE_REG=$v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pcie 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline()); k = d['kernel_classes']
+print('conv forms $v: %.1f img/s  %.2f ms/step  conv %.2f ms  gemm_pp %.2f  attn %.2f  post %.2f' % (d['value'], d['ms_per_step'], k['conv']['ms_per_step'], k['gemm_pp']['ms_per_step'], k['attn']['ms_per_step'], k['post']['ms_per_step']))"
+                  done
+                done > $out/${tag}_ab_conv.log 2>&1; cat $out/${tag}_ab_conv.log ;;
+    kb_corun)   timeout 300 ./tools/kbench corun - 10 > $out/${tag}_kbench_corun.log 2>&1; cat $out/${tag}_kbench_corun.log ;;
+    kb_rb_ts)   KB_TS=1 KB_ROUNDS=1 timeout 300 ./tools/kbench rb - 5 > $out/${tag}_kbench_rb_ts.log 2>&1; cat $out/${tag}_kbench_rb_ts.log ;;
+    corun_trace) rm -rf /tmp/ct; rocprofv3 --kernel-trace --output-format csv -d /tmp/ct -o ct -- ./tools/kbench corun fc2 4 > $out/${tag}_corun_trace.log 2>&1
+                f=$(find /tmp/ct -name "*kernel_trace.csv" | head -1); python3 tools/corun_overlap.py $f >> $out/${tag}_corun_trace.log 2>&1; tail -40 $out/${tag}_corun_trace.log ;;
+    pcie)       timeout 600 python tools/pcie_check.py > $out/${tag}_pcie_check.log 2>&1; cat $out/${tag}_pcie_check.log ;;
+    *) echo "unknown step $what" ;;
+  esac
+done

@@ -562,6 +562,19 @@ static int bench_rb(int iters) {
                 float t; CK(hipEventElapsedTime(&t, e0, e1)); t /= iters;
                 ms[v] += t; mn[v] = t < mn[v] ? t : mn[v];
             }
+        if (getenv("KB_TS")) {
+            unsigned long long* dts; CK(hipMalloc(&dts, 128 * 8)); CK(hipMemsetAsync(dts, 0, 128 * 8, st));
+            GemmArgs g3 = gr; g3.dbg_ts = dts;
+            launch_conv_rb(g3, st);
+            unsigned long long hts[128]; CK(hipMemcpyAsync(hts, dts, 128 * 8, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+            for (int w = 0; w < 2; w++)
+                for (int t = 0; t < 6 && hts[w * 64 + t * 8 + 6]; t++) {
+                    const unsigned long long* q = hts + w * 64 + t * 8;
+                    printf("   ts wave %d tile %d: head-wait %5.2f  conv1 %6.2f  mid+transition %5.2f  conv2 %6.2f  epi-loads %5.2f  stage+stores %5.2f   (tile start +%.2f)  [x100 clocks]\n", w * 4, t,
+                           (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01, (q[5] - q[4]) * 0.01, (q[6] - q[5]) * 0.01, (q[0] - hts[w * 64]) * 0.01);
+                }
+            CK(hipFree(dts));
+        }
         const double fl = 2.0 * 2.0 * px * 64.0 * 576.0;          // algorithmic: the two convs
         printf("resblock %-30s two launches %8.3f ms (min %.3f) %7.1f TF/s | fused %8.3f ms (min %.3f) %7.1f TF/s | differing values %d / %zu %s\n", c.name, ms[0] / rounds,
                mn[0], fl / (ms[0] / rounds) / 1e9, ms[1] / rounds, mn[1], fl / (ms[1] / rounds) / 1e9, hbad, n, hbad ? "FAIL" : "bit-identical");
@@ -570,6 +583,73 @@ static int bench_rb(int iters) {
         CK(hipFree(x)); CK(hipFree(h)); CK(hipFree(y0)); CK(hipFree(y1)); CK(hipFree(w1)); CK(hipFree(w2)); CK(hipFree(b1)); CK(hipFree(b2)); CK(hipFree(dbad));
     }
     return fails;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// co-residency probe: a GEMM stream and an attention stream side by side.  The production GEMM (gemm_pp128p_kernel:
+// all 160 KiB of LDS, 2 x 238 VGPRs per SIMD) leaves no room on a CU, so two streams only overlap at kernel boundaries; a GEMM that leaves
+// room (gemm_glds_kernel 128x128: 64 KiB, 4 waves x 176 VGPRs) can share every SIMD with attention waves (48 KiB, 160 VGPRs).
+// Reported: time of each stream alone, wall time of both together, and the combined algorithmic TFLOP/s.
+// ---------------------------------------------------------------------------------------------------------------------
+#include <chrono>
+static int bench_corun(const char* filter, int iters) {
+    hipStream_t sg, sa;
+    CK(hipStreamCreateWithFlags(&sg, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+    const int Bh = 16, Ntok = 3601, nh = 16;
+    const size_t M = (size_t)Bh * Ntok;
+    struct GS { const char* name; int N, K, epi, act; };
+    const GS gs[] = {{"fc1", 4096, 1024, EPI_STORE, ACT_GELU}, {"fc2", 1024, 4096, EPI_STORE, ACT_NONE}, {"qkv-plain", 3072, 1024, EPI_STORE, ACT_NONE}};
+    // attention operands
+    const size_t BH = (size_t)Bh * nh, na = BH * Ntok * 64;
+    f16 *q, *k, *v, *ao;
+    CK(hipMalloc(&q, na * 2)); CK(hipMalloc(&k, na * 2)); CK(hipMalloc(&v, na * 2)); CK(hipMalloc(&ao, na * 2));
+    fill_f16<<<2048, 256, 0, sa>>>(q, na, 11u, 0.125f * 1.4426950408889634f * 4.0f);
+    fill_f16<<<2048, 256, 0, sa>>>(k, na, 12u, 1.0f);
+    fill_f16<<<2048, 256, 0, sa>>>(v, na, 13u, 1.0f);
+    CK(hipStreamSynchronize(sa));
+    const double fa = 4.0 * BH * (double)Ntok * Ntok * 64;
+    auto wall = [&](int ng, int nat, const GemmArgs& g) {
+        CK(hipDeviceSynchronize());
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < (ng > nat ? ng : nat); i++) {           // interleaved submission: neither stream starves for launches
+            if (i < ng) launch_gemm<f16>(g, AMODE_LINEAR, sg);
+            if (i < nat) launch_attention_pp(q, k, v, ao, Bh, nh, Ntok, sa);
+        }
+        CK(hipDeviceSynchronize());
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    for (const GS& s : gs) {
+        if (filter && !strstr(s.name, filter)) continue;
+        const size_t N = s.N, K = s.K;
+        f16 *A, *W, *out; float* bias;
+        CK(hipMalloc(&A, M * K * 2)); CK(hipMalloc(&W, N * K * 2)); CK(hipMalloc(&out, M * N * 2)); CK(hipMalloc(&bias, N * 4));
+        fill_f16<<<2048, 256, 0, sg>>>(A, M * K, 1u, 1.0f);
+        fill_f16<<<2048, 256, 0, sg>>>(W, N * K, 2u, 1.0f);
+        fill_f32<<<64, 256, 0, sg>>>(bias, N, 3u, 1.0f, 0.f);
+        CK(hipStreamSynchronize(sg));
+        GemmArgs g; memset(&g, 0, sizeof(g));
+        g.a = A; g.lda = (int)K; g.w = W; g.ldw = (int)K; g.M = (int)M; g.N = (int)N; g.K = (int)K; g.epi = s.epi; g.act = s.act; g.bias = bias; g.out = out; g.ldc = (int)N;
+        const double fg = 2.0 * M * N * K;
+        struct V { const char* name; int pp, glds; };
+        const V vs[] = {{"pp128p (160 KiB)", 1, 2}, {"glds 128x128 (64 KiB)", 0, 2}, {"glds 128x128 1buf (32 KiB)", 0, 1}};
+        for (const V& vv : vs) {
+            moge_tune_set("GEMM_PP", vv.pp); moge_tune_set("PP_MIN_TILES", 0); moge_tune_set("GLDS_VARIANT", vv.glds); moge_tune_set("PP_KERN", 2);
+            wall(2, 2, g);                                     // warm-up
+            const double tg0 = wall(1, 0, g), ta0 = wall(0, 1, g);
+            const int ng = iters * (int)(ta0 / tg0 + 0.5 > 1 ? ta0 / tg0 + 0.5 : 1), nat = iters;      // roughly equal stream lengths
+            double tg = 1e30, ta = 1e30, tb = 1e30;
+            for (int r = 0; r < 3; r++) {
+                const double a = wall(ng, 0, g), b = wall(0, nat, g), c = wall(ng, nat, g);
+                tg = a < tg ? a : tg; ta = b < ta ? b : ta; tb = c < tb ? c : tb;
+            }
+            printf("corun %-10s %-28s gemm x%-3d alone %8.3f ms (%7.1f TF/s) | attn x%-3d alone %8.3f ms (%7.1f TF/s) | together %8.3f ms = %.3f of the sum, %7.1f TF/s combined\n",
+                   s.name, vv.name, ng, tg, ng * fg / tg / 1e9, nat, ta, nat * fa / ta / 1e9, tb, tb / (tg + ta), (ng * fg + nat * fa) / tb / 1e9);
+            fflush(stdout);
+        }
+        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(out)); CK(hipFree(bias));
+    }
+    moge_tune_set("GEMM_PP", 1);
+    return 0;
 }
 
 int main(int argc, char** argv) {
@@ -581,6 +661,7 @@ int main(int argc, char** argv) {
     if (!strcmp(argv[1], "attn")) return bench_attn(iters) ? 4 : 0;
     if (!strcmp(argv[1], "conv")) return bench_conv(filter, iters) ? 4 : 0;
     if (!strcmp(argv[1], "rb")) return bench_rb(iters) ? 4 : 0;
+    if (!strcmp(argv[1], "corun")) return bench_corun(filter, iters);
     fprintf(stderr, "unknown bench %s\n", argv[1]);
     return 1;
 }
