@@ -72,7 +72,7 @@ constexpr float AP_PSUM_LIMIT = 16384.f;
 //      sums: the decision is known right after the K Q^T chain, so the exponentials are free to interleave with the P V MFMAs (with the
 //      sum-based guard the branch sits between the last exponential and the first P V MFMA and serialises the two)
 constexpr int AP_VAR_DEFAULT = 0;
-constexpr int AP_KERN_DEFAULT = 1;      // 0: attn_pp16_kernel, 1: attn_pp16m_kernel (row sums on the matrix pipe)
+constexpr int AP_KERN_DEFAULT = 3;      // 0: attn_pp16_kernel; 1 / 2 / 3: attn_pp16mq_kernel<2> / <4> / chosen by grid size (row sums on the matrix pipe)
 constexpr float AP_SCORE_LIMIT = 15.f;
 constexpr float AP_ROWSUM_LIMIT = 49152.f;      // attn_pp16m: FULL row sum of a tile (64 keys) below this -> every P < 49152 < 65504 (fp16 max)
 template <int VAR>
@@ -361,7 +361,15 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
 // ------------------------------------------------------------------------------------------------------------------------
 // (Requesting the tile's V^T operands behind the K Q^T MFMAs, so that their LDS latency passes under the exponentials, needs > 168 registers =
 // 2 waves per SIMD: measured 783-800 TF/s against 938-944 for this form - the third wave is worth more than the exposed read latency.)
-__global__ __launch_bounds__(256, 3) void attn_pp16m_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
+// ------------------------------------------------------------------------------------------------------------------------
+// attn_pp16mq_kernel<QB>: the kernel described above with QB 16-query blocks per wave (QB = 2: 32 queries per wave, 3 waves per SIMD - round 2's attn_pp16m_kernel; QB = 4: 64 queries per wave, 256 per
+// workgroup, 2 waves per SIMD).  VERDICT r02 item 3: the kernel is ISSUE-bound, so the experiment amortises everything that is per TILE and
+// not per query - the K fragment reads, the V^T transposed reads, the DMA issue, the barrier, the loop overhead - over twice the MFMAs
+// (per 64 queries and tile: 212 instructions instead of 256), and gives the scheduler four independent K Q^T -> exp -> P V chains per wave
+// to interleave.  Result and the reason it is / is not the default: DESIGN.md 4.3 (profiles/r03*_kbench_attn*.log).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int QB>
+__global__ __launch_bounds__(256, QB > 2 ? 2 : 3) void attn_pp16mq_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
                                                             f16* __restrict__ out, int Ntok, int nh, int xcd_remap) {
     constexpr int NW = 4, NPW = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * AP_STAGE
@@ -380,11 +388,11 @@ __global__ __launch_bounds__(256, 3) void attn_pp16m_kernel(const f16* __restric
         qblk = s - hs * (int)gridDim.x;
     }
     const int b = bh / nh, head = bh - b * nh;
-    const int q0 = qblk * (NW * 32) + wave * 32;
+    const int q0 = qblk * (NW * 16 * QB) + wave * (16 * QB);
 
-    u32x4 qf[2][2];
+    u32x4 qf[QB][2];
 #pragma unroll
-    for (int qb = 0; qb < 2; qb++) {
+    for (int qb = 0; qb < QB; qb++) {
         const int qrow = q0 + qb * 16 + l15;
         const f16* qp = q + ((size_t)bh * Ntok + (qrow < Ntok ? qrow : Ntok - 1)) * 64;
 #pragma unroll
@@ -429,11 +437,11 @@ __global__ __launch_bounds__(256, 3) void attn_pp16m_kernel(const f16* __restric
     for (int db = 0; db < 4; db++)
         vaddr[db] = 8192 + (8 * g4 + (l15 >> 2)) * 128 + ((((2 * db) ^ vswl) | ((l15 & 3) >> 1)) << 4) + (l15 & 1) * 8;
 
-    f32x4 o[4][2];
-    f32x4 negs[2];
-    float m_run[2], l_run[2];
+    f32x4 o[4][QB];
+    f32x4 negs[QB];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int qb = 0; qb < 2; qb++) {
+    for (int qb = 0; qb < QB; qb++) {
 #pragma unroll
         for (int db = 0; db < 4; db++) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
         negs[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -445,8 +453,8 @@ __global__ __launch_bounds__(256, 3) void attn_pp16m_kernel(const f16* __restric
     int stage = 0;
     const char* ka[2];
     const char* va[4];
-    f32x4 sc[4][2];
-    float psum[2];
+    f32x4 sc[4][QB];
+    float psum[QB];
     auto tile_head = [&](int t) {
         if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -542,9 +550,11 @@ __global__ __launch_bounds__(256, 3) void attn_pp16m_kernel(const f16* __restric
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     tile_head(0);
-    exact_block(0, ntiles == 1, 0);
-    exact_block(0, ntiles == 1, 1);
+#pragma unroll
+    for (int qb = 0; qb < QB; qb++) exact_block(0, ntiles == 1, qb);
     int t = 1;
+    u32x4 pf[QB][2];                             // [query block][32-key step]: the tile's P^T operands
+    f32x4 lt[QB];                                // this tile's row sums (every register / lane of a query holds the same number)
     for (;;) {
         bool hit = false;
         for (; t < ntiles - 1; t++) {                // ---- hot loop ----
@@ -556,12 +566,10 @@ __global__ __launch_bounds__(256, 3) void attn_pp16m_kernel(const f16* __restric
                 kf[kb][0] = *reinterpret_cast<const u32x4*>(ka[0] + koff);
                 kf[kb][1] = *reinterpret_cast<const u32x4*>(ka[1] + koff);
             }
-            qk_block(0, kf);
-            qk_block(1, kf);
-            u32x4 pf[2][2];                          // [query block][32-key step]
-            f32x4 lt[2];                             // this tile's row sums (every register / lane of a query holds the same number)
 #pragma unroll
-            for (int qb = 0; qb < 2; qb++) {
+            for (int qb = 0; qb < QB; qb++) qk_block(qb, kf);
+#pragma unroll
+            for (int qb = 0; qb < QB; qb++) {
 #pragma unroll
                 for (int kb = 0; kb < 4; kb++)
 #pragma unroll
@@ -570,31 +578,40 @@ __global__ __launch_bounds__(256, 3) void attn_pp16m_kernel(const f16* __restric
                 lt[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ones), __builtin_bit_cast(f16x8, pf[qb][0]), zero4, 0, 0, 0);
                 mma16<f16>(lt[qb], ones, pf[qb][1]);
             }
-            const bool trig = !(lt[0][0] < AP_ROWSUM_LIMIT) | !(lt[1][0] < AP_ROWSUM_LIMIT);
+            bool trig = false;
+#pragma unroll
+            for (int qb = 0; qb < QB; qb++) trig |= !(lt[qb][0] < AP_ROWSUM_LIMIT);
             if (__builtin_expect(__any(trig), 0)) { hit = true; break; }
 #pragma unroll
-            for (int qb = 0; qb < 2; qb++) l_run[qb] += lt[qb][0];
+            for (int qb = 0; qb < QB; qb++) l_run[qb] += lt[qb][0];
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
                 for (int db = 0; db < 4; db++) {
                     const u32x4 vf = tr_pair(va[db] + (32 * s2) * 128, va[db] + (32 * s2 + 4) * 128);
 #pragma unroll
-                    for (int qb = 0; qb < 2; qb++) mma16<f16>(o[db][qb], vf, pf[qb][s2]);
+                    for (int qb = 0; qb < QB; qb++) mma16<f16>(o[db][qb], vf, pf[qb][s2]);
                 }
         }
         if (!hit) break;
-        exact_block(t, false, 0);                    // tile t again from LDS (its barrier and DMA issue are done)
-        exact_block(t, false, 1);
+        // The decision is per 16-QUERY BLOCK, not per wave: a block whose own row sums stayed below the limit takes exactly the fast path's
+        // arithmetic (its P^T operands and row sums are still in registers), a block that tripped is redone exactly from LDS (tile t's barrier
+        // and DMA issue are done).  A query's result therefore does not depend on which other queries share its wave - i.e. not on QB, and
+        // not on which of the two instantiations a batch size selects.
+#pragma unroll
+        for (int qb = 0; qb < QB; qb++) {
+            if (__any(!(lt[qb][0] < AP_ROWSUM_LIMIT))) exact_block(t, false, qb);
+            else { psum[qb] = lt[qb][0]; pv_block(qb, pf[qb]); }
+        }
         t++;
     }
     if (ntiles > 1) {
         tile_head(ntiles - 1);
-        exact_block(ntiles - 1, true, 0);
-        exact_block(ntiles - 1, true, 1);
+#pragma unroll
+        for (int qb = 0; qb < QB; qb++) exact_block(ntiles - 1, true, qb);
     }
 #pragma unroll
-    for (int qb = 0; qb < 2; qb++) {
+    for (int qb = 0; qb < QB; qb++) {
         const float inv = 1.f / l_run[qb];               // already the full row sum
         const int qrow = q0 + qb * 16 + l15;
         if (qrow < Ntok) {
@@ -613,10 +630,21 @@ __global__ __launch_bounds__(256, 3) void attn_pp16m_kernel(const f16* __restric
 static int launch_attn_pp16(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
     constexpr int smem = 3 * AP_STAGE;
     dim3 grid((Ntok + 127) / 128, B * nh);
-    if (moge_tune_get("ATTN_KERN", AP_KERN_DEFAULT) == 1) {             // attn_pp16m_kernel: row sums on the matrix pipe
-        if (int rc = set_dyn_lds<attn_pp16m_kernel>(smem)) return rc;
-        hipLaunchKernelGGL(attn_pp16m_kernel, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh,
-                           moge_tune_get("ATTN_XCD", 1));
+    // attn_pp16mq_kernel<QB>: row sums on the matrix pipe; QB = 4 (64 queries per wave, 2 waves per SIMD) when the grid still fills the chip
+    // several times over, QB = 2 (3 waves per SIMD) otherwise - bit-identical results (see the kernel).  ATTN_KERN: 0 = attn_pp16_kernel,
+    // 1 = QB 2 always, 2 = QB 4 always, 3 (default) = by grid size
+    const int akern = moge_tune_get("ATTN_KERN", AP_KERN_DEFAULT);
+    if (akern >= 1) {
+        const long wgs4 = (long)((Ntok + 255) / 256) * B * nh;
+        const bool q4 = akern == 2 || (akern == 3 && wgs4 >= moge_tune_get("ATTN_Q4_MIN_WGS", 1536));
+        const int xr = moge_tune_get("ATTN_XCD", 1);
+        if (q4) {
+            if (int rc = set_dyn_lds<attn_pp16mq_kernel<4>>(smem)) return rc;
+            hipLaunchKernelGGL(attn_pp16mq_kernel<4>, dim3((Ntok + 255) / 256, B * nh), dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr);
+        } else {
+            if (int rc = set_dyn_lds<attn_pp16mq_kernel<2>>(smem)) return rc;
+            hipLaunchKernelGGL(attn_pp16mq_kernel<2>, grid, dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr);
+        }
         return (int)hipGetLastError();
     }
 #define AP_LAUNCH_VAR(V) do { if (int rc = set_dyn_lds<attn_pp16_kernel<V>>(smem)) return rc; \

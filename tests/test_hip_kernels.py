@@ -62,6 +62,29 @@ def test_attention(H, prec, B, nh, N):
     assert relmax(H.attention(prec, q, k, v), ref) < (2e-5 if prec == 0 else 1e-2)
 
 
+@pytest.mark.parametrize("B,nh,N", [(2, 3, 130), (1, 2, 300), (1, 6, 1370), (1, 2, 3601)])
+def test_attention_64_queries_per_wave_is_bit_identical(H, B, nh, N):
+    """attn_pp16mq_kernel<4> (64 queries per wave: what large grids run) against <2> (32 per wave): the overflow guard decides per 16-query
+    block, so a query's result does not depend on its wave-mates - bit-identical outputs, here with late dominant keys that force guard trips
+    in some blocks and not in their neighbours; both also against SDPA."""
+    from moge_amd import _lib as L
+    g = torch.Generator().manual_seed(N + 1)
+    q, k, v = (torch.randn(B, nh, N, 64, generator=g) for _ in range(3))
+    q = q * 1.5
+    k[:, :, N // 2 + 3] = q[:, :, 5] * 6.0          # one query (block 0) sees a huge late score; its neighbours in other blocks do not
+    k[:, 0, N - 2] = q[:, 0, min(70, N - 1)] * 5.0
+    ref = F.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda()).permute(0, 2, 1, 3).reshape(B, N, nh * 64)
+    outs = {}
+    for kern in (1, 2):
+        L.tune("ATTN_KERN", kern)
+        try:
+            outs[kern] = H.attention(1, q, k, v)
+        finally:
+            L.tune("ATTN_KERN", 3)
+        assert relmax(outs[kern], ref) < 1e-2, kern
+    assert torch.equal(outs[1], outs[2])
+
+
 def test_attention_online_softmax_rescale(H):
     """rule 26: force the running-max rescale branch - one key in a LATE tile dominates one query."""
     g = torch.Generator().manual_seed(7)

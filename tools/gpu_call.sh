@@ -30,6 +30,8 @@ print('conv forms $v: %.1f img/s  %.2f ms/step  conv %.2f ms  gemm_pp %.2f  attn
     corun_trace) rm -rf /tmp/ct; rocprofv3 --kernel-trace --output-format csv -d /tmp/ct -o ct -- ./tools/kbench corun fc2 4 > $out/${tag}_corun_trace.log 2>&1
                 f=$(find /tmp/ct -name "*kernel_trace.csv" | head -1); python3 tools/corun_overlap.py $f >> $out/${tag}_corun_trace.log 2>&1; tail -40 $out/${tag}_corun_trace.log ;;
     pcie)       timeout 600 python tools/pcie_check.py > $out/${tag}_pcie_check.log 2>&1; cat $out/${tag}_pcie_check.log ;;
+    attn_q4)    timeout 300 ./tools/kbench attn - 10 > $out/${tag}_kbench_attn.log 2>&1; cat $out/${tag}_kbench_attn.log
+                MOGE_ATTN_KERN=2 timeout 300 python -m pytest tests/test_hip_kernels.py -k attention -q -p no:cacheprovider 2>&1 | tail -3 ;;
     *) echo "unknown step $what" ;;
   esac
 done

@@ -338,11 +338,13 @@ __global__ void spike_k(f16* k, int Ntok, int bh, int key, float scale) {
     k[((size_t)bh * Ntok + key) * 64 + threadIdx.x] = (f16)((float)k[((size_t)bh * Ntok + key) * 64 + threadIdx.x] * scale);
 }
 
+__global__ void cmp_bits(const f16* a, const f16* b, size_t n, int* nbad);
 static int bench_attn(int iters) {
     hipStream_t st;
     CK(hipStreamCreate(&st));
     struct Case { const char* name; int B, nh, Ntok; };
-    const Case cases[] = {{"vitl b32 N3601", 32, 16, 3601}, {"small N130", 2, 3, 130}, {"N1370", 4, 16, 1370}};
+    const Case cases[] = {{"vitl b32 N3601", 32, 16, 3601}, {"vitl b16 N3601", 16, 16, 3601}, {"vitb b8 N3601", 8, 12, 3601}, {"vitl b4 N3601", 4, 16, 3601}, {"vitb b4 N3601", 4, 12, 3601},
+                          {"small N130", 2, 3, 130}, {"N1370", 4, 16, 1370}, {"vitl b32 518x1036", 32, 16, 3571}};
     int fails = 0;
     for (const Case& c : cases) {
         const size_t BH = (size_t)c.B * c.nh, n = BH * c.Ntok * 64;
@@ -371,7 +373,9 @@ static int bench_attn(int iters) {
         CK(hipStreamSynchronize(st));
         // exp: ATTN_EXP (32x32x16 kernels), var: ATTN_VAR bits of attn_pp16_kernel - both need a library built with --experiments
         struct Var { const char* name; int kind, exp, var; int kern = 0; };
-        std::vector<Var> vars = {{"pp16", 1, 0, 0, 0}, {"pp16m", 1, 0, 0, 1}};
+        std::vector<Var> vars = {{"pp16", 1, 0, 0, 0}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}};
+        f16* out_q2 = nullptr;                       // mq<2> result: mq<4> must reproduce it bit for bit (per-block guard decisions; spiked keys above force them)
+        CK(hipMalloc(&out_q2, n * 2));
         if (getenv("KB_EXP")) vars = {{"old(vT)", 0, 0, 0}, {"x:pp32 nw4", 1, 1, 0}, {"pp16", 1, 0, 0}, {"x:noexp", 1, 0, 1}, {"x:noguard", 1, 0, 2}, {"x:ks-outer", 1, 0, 4},
                                       {"x:ks+noguard", 1, 0, 6}, {"x:maxguard", 1, 0, 8}, {"x:ks+maxguard", 1, 0, 12}};
         if (getenv("KB_ABL")) vars = {{"pp16", 1, 0, 0}, {"x:noguard", 1, 0, 2}, {"x:nosum", 1, 0, 16}, {"x:nosum+noguard", 1, 0, 18}, {"x:nosum+ng+noexp", 1, 0, 19}, {"x:halfVreads", 1, 0, 32},
@@ -396,10 +400,21 @@ static int bench_attn(int iters) {
             CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
             const double tf = 4.0 * BH * (double)c.Ntok * c.Ntok * 64 / (ms * 1e-3) / 1e12;
-            printf("attn %-16s %-8s %8.3f ms %8.1f TF/s   check: max abs err %.2e, bad %d / %d %s\n", c.name, va.name, ms, tf, hmax, hbad, ns * 64, hbad ? "FAIL" : "ok");
+            int hdiff = -1;
+            if (va.kern == 1) CK(hipMemcpyAsync(out_q2, out, n * 2, hipMemcpyDeviceToDevice, st));
+            if (va.kern == 2) {
+                CK(hipMemsetAsync(dbad, 0, 4, st));
+                cmp_bits<<<2048, 256, 0, st>>>(out, out_q2, n, dbad);
+                CK(hipMemcpyAsync(&hdiff, dbad, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+                if (hdiff) fails++;
+            }
+            printf("attn %-18s %-8s %8.3f ms %8.1f TF/s   check: max abs err %.2e, bad %d / %d %s", c.name, va.name, ms, tf, hmax, hbad, ns * 64, hbad ? "FAIL" : "ok");
+            if (hdiff >= 0) printf("   vs mq<2>: %d values differ %s", hdiff, hdiff ? "FAIL" : "(bit-identical)");
+            printf("\n");
             fflush(stdout);
             if (hbad) fails++;
         }
+        CK(hipFree(out_q2));
         CK(hipFree(q)); CK(hipFree(k)); CK(hipFree(v)); CK(hipFree(vT)); CK(hipFree(out)); CK(hipFree(dbh)); CK(hipFree(dq)); CK(hipFree(ref)); CK(hipFree(dmax)); CK(hipFree(dbad));
     }
     return fails;
