@@ -50,6 +50,9 @@ __device__ __forceinline__ u32x4 rb_relu8(u32x4 v) {
     return v;
 }
 
+// VAR (tools/kbench A-B): bit 0 = no s_setprio around the MFMA segments, bit 1 = relu(x) applied at the head of the MFMA segment instead of
+// in the read segment (VALU in a read segment is starved while the partner wave of the SIMD issues MFMAs at priority 1)
+template <int VAR>
 __global__ __launch_bounds__(512, 2) void conv_rb_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -142,17 +145,24 @@ __global__ __launch_bounds__(512, 2) void conv_rb_kernel(const GemmArgs g) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);
     };
-    auto post_mfma = [&](bool last) {
-        __builtin_amdgcn_s_setprio(0);
+    // The hand-over barrier of an MFMA segment may sit E MFMAs BEFORE its end (VAR bits 2-3: E = 4 / 8 / 12): the partner group starts its
+    // MFMAs while this group's last ones are still issuing, so the matrix pipe does not idle for the barrier's release latency at every
+    // hand-over (measured ~190 clocks each, two per K-step).  No data hazard is attached to the position: MFMAs touch registers only.
+    constexpr int EARLY = ((VAR >> 2) & 3) * 4;
+    auto handover = [&](bool last) {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
         if (!(grp == 1 && last)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
-
+    auto post_mfma = [&](bool last) {
+        if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
+        if constexpr (EARLY == 0) handover(last);
+        else __builtin_amdgcn_sched_barrier(0);
+    };
     // optional s_memtime timeline of workgroup 0 (tools/kbench rb with KB_TS): wave 0 and wave 4, eight stamps per tile for the first six tiles
     unsigned long long* const ts = (g.dbg_ts && blockIdx.x == 0 && (wave & 3) == 0) ? g.dbg_ts + (wave >> 2) * 64 : nullptr;
     int ts_tile = 0;
@@ -194,23 +204,37 @@ __global__ __launch_bounds__(512, 2) void conv_rb_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) af[i][ks] = *reinterpret_cast<const u32x4*>(smem + (a0 ^ (ks * 64)));
             }
+            if (kt == 4 && ts && ts_tile == 3 && lane == 0) ts[48] = __builtin_readcyclecounter();
             read_w(kt);
             issue_w(kt + 3);                          // kt + 3 <= 11: conv2's first three steps are requested by conv1's last three
+            if (kt == 4 && ts && ts_tile == 3 && lane == 0) ts[49] = __builtin_readcyclecounter();
             // W(kt + 1) has landed (in order: everything older too); in flight stay W(kt + 2), W(kt + 3) and, on the first two steps of a
             // tile that follows another, the previous epilogue's stores
             if (kt < 2 && !first) rb_wait<2 + RB_NST>(); else rb_wait<2>();
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int ks = 0; ks < 2; ks++) af[i][ks] = rb_relu8(af[i][ks]);      // relu(x) (modules.py:52)
-            pre_mfma();
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++)
+            if constexpr (!(VAR & 2)) {
 #pragma unroll
                 for (int i = 0; i < 3; i++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) mma16<f16>(acc1[i][j], wf[j][ks], af[i][ks]);
+                    for (int ks = 0; ks < 2; ks++) af[i][ks] = rb_relu8(af[i][ks]);      // relu(x) (modules.py:52)
+            }
+            if (kt == 4 && ts && ts_tile == 3 && lane == 0) ts[50] = __builtin_readcyclecounter();
+            pre_mfma();
+            if (kt == 4 && ts && ts_tile == 3 && lane == 0) ts[51] = __builtin_readcyclecounter();
+            if constexpr ((VAR & 2) != 0) {
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) af[i][ks] = rb_relu8(af[i][ks]);
+            }
+#pragma unroll
+            for (int n = 0; n < 24; n++) {
+                const int ks = n / 12, i = (n % 12) / 4, j = n % 4;
+                if (EARLY > 0 && n == 24 - EARLY) handover(kt == 8);
+                mma16<f16>(acc1[i][j], wf[j][ks], af[i][ks]);
+            }
+            if (kt == 4 && ts && ts_tile == 3 && lane == 0) ts[52] = __builtin_readcyclecounter();
             post_mfma(kt == 8);
+            if (kt == 4 && ts && ts_tile == 3 && lane == 0) ts[53] = __builtin_readcyclecounter();
         }
         // ---- transition: every wave has read its last in-halo fragment (group 0's last barrier pairs with the one group 1 passes after its
         // step-8 reads): the in-halo buffer and weight slot 0 are free.  Next tile's coordinates, W(12), then the next in-halo image (after the
@@ -286,11 +310,11 @@ __global__ __launch_bounds__(512, 2) void conv_rb_kernel(const GemmArgs g) {
             else rb_wait<0>();
             pre_mfma();
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) mma16<f16>(acc2[i][j], wf[j][ks], af[i][ks]);
+            for (int n = 0; n < 16; n++) {
+                const int ks = n / 8, i = (n % 8) / 4, j = n % 4;
+                if (EARLY > 0 && n == 16 - EARLY) handover(kt == 17);
+                mma16<f16>(acc2[i][j], wf[j][ks], af[i][ks]);
+            }
             post_mfma(kt == 17);
         }
 
@@ -356,15 +380,28 @@ bool conv_rb_eligible(const GemmArgs& g) {
     return true;
 }
 
-int launch_conv_rb(const GemmArgs& g, hipStream_t st) {
-    if (!conv_rb_eligible(g)) return -1;
-    if (int rc = set_dyn_lds<conv_rb_kernel>(RB_SMEM)) return rc;
+template <int VAR>
+static int launch_conv_rb_var(const GemmArgs& g, hipStream_t st) {
+    if (int rc = set_dyn_lds<conv_rb_kernel<VAR>>(RB_SMEM)) return rc;
     const long B = (long)g.M / ((long)g.H * g.W);
     const long tiles = B * ((g.H + 15) / 16) * ((g.W + 15) / 16);
     long slots = pp_device_cus();
     const long cap = moge_tune_get("CONV_GRID", 0);      // tests: a small grid makes small problems walk many tiles per workgroup
     if (cap > 0) slots = cap;
     const long grid = tiles < slots ? tiles : slots;
-    hipLaunchKernelGGL(conv_rb_kernel, dim3((unsigned)grid), dim3(512), RB_SMEM, st, g);
+    hipLaunchKernelGGL(conv_rb_kernel<VAR>, dim3((unsigned)grid), dim3(512), RB_SMEM, st, g);
     return (int)hipGetLastError();
+}
+
+int launch_conv_rb(const GemmArgs& g, hipStream_t st) {
+    if (!conv_rb_eligible(g)) return -1;
+    switch (moge_tune_get("CONV_RB_VAR", 0)) {
+    case 1: return launch_conv_rb_var<1>(g, st);
+    case 2: return launch_conv_rb_var<2>(g, st);
+    case 3: return launch_conv_rb_var<3>(g, st);
+    case 4: return launch_conv_rb_var<4>(g, st);
+    case 8: return launch_conv_rb_var<8>(g, st);
+    case 12: return launch_conv_rb_var<12>(g, st);
+    default: return launch_conv_rb_var<0>(g, st);
+    }
 }

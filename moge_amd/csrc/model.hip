@@ -576,7 +576,10 @@ static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* 
     for (int j = 0; j < n; j++) {
         const T* w1 = P<T>(h, name + S(".res%d.%d.w1", l, j)); const T* w2 = P<T>(h, name + S(".res%d.%d.w2", l, j));
         const float* b1 = M(h, name + S(".res_blocks.%d.%d.layers.2.bias", l, j)); const float* b2 = M(h, name + S(".res_blocks.%d.%d.layers.5.bias", l, j));
-        if (std::is_same<T, f16>::value && moge_tune_get("CONV_RB", 1) && (may_swap || ((n - j) >= 2) || cur != x)) {
+        // CONV_RB (default OFF): measured on MI355X the fused launch is 5-10 % SLOWER than the two conv_pp launches at the bench's level-3 shape
+        // (1.44-1.46 vs 1.37-1.38 ms at batch 32, profiles/r03a_kbench_rb.log, timeline r03j: one 130 KiB workgroup per CU exposes every
+        // latency the two-per-CU conv_pp form hides, and the MFMA segments run at 21.7 clocks per MFMA beside the partner's read segment)
+        if (std::is_same<T, f16>::value && moge_tune_get("CONV_RB", 0) && (may_swap || ((n - j) >= 2) || cur != x)) {
             // (without may_swap the result must end in x: fuse blocks in pairs, or the last one when the data currently sits in tmp)
             GemmArgs g = gemm_args();
             g.a = cur; g.H = Hh; g.W = Ww; g.C = C; g.relu_in = 1; g.w = w1; g.ldw = 9 * C; g.M = B * Hh * Ww; g.N = C; g.K = 9 * C;

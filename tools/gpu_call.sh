@@ -32,6 +32,7 @@ print('conv forms $v: %.1f img/s  %.2f ms/step  conv %.2f ms  gemm_pp %.2f  attn
     pcie)       timeout 600 python tools/pcie_check.py > $out/${tag}_pcie_check.log 2>&1; cat $out/${tag}_pcie_check.log ;;
     attn_q4)    timeout 300 ./tools/kbench attn - 10 > $out/${tag}_kbench_attn.log 2>&1; cat $out/${tag}_kbench_attn.log
                 MOGE_ATTN_KERN=2 timeout 300 python -m pytest tests/test_hip_kernels.py -k attention -q -p no:cacheprovider 2>&1 | tail -3 ;;
+    kb_rb_var)  for v in ${RBVARS:-0 4 8 12}; do echo "== CONV_RB_VAR $v"; KB_RBVAR=$v KB_TS=1 KB_ROUNDS=2 timeout 300 ./tools/kbench rb - 10 2>&1 | grep -v "tile [0-2]:\|b16\|grid b8\|odd" ; done > $out/${tag}_kbench_rb_var.log 2>&1; cat $out/${tag}_kbench_rb_var.log ;;
     *) echo "unknown step $what" ;;
   esac
 done

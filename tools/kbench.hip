@@ -560,6 +560,7 @@ static int bench_rb(int iters) {
         GemmArgs gr = g1; gr.act = ACT_NONE; gr.out = y1; gr.add = x; gr.rb_w2 = w2; gr.rb_bias2 = b2;
         if (!conv_rb_eligible(gr)) { printf("rb %s: not eligible\n", c.name); fails++; continue; }
         auto two = [&]() { launch_gemm<f16>(g1, AMODE_CONV3, st); launch_gemm<f16>(g2, AMODE_CONV3, st); };
+        moge_tune_set("CONV_RB_VAR", getenv("KB_RBVAR") ? atoi(getenv("KB_RBVAR")) : 0);
         auto one = [&]() { launch_conv_rb(gr, st); };
         CK(hipMemsetAsync(y0, 0, n * 2, st)); CK(hipMemsetAsync(y1, 0xff, n * 2, st));
         two(); one();
@@ -588,6 +589,11 @@ static int bench_rb(int iters) {
                     printf("   ts wave %d tile %d: head-wait %5.2f  conv1 %6.2f  mid+transition %5.2f  conv2 %6.2f  epi-loads %5.2f  stage+stores %5.2f   (tile start +%.2f)  [x100 clocks]\n", w * 4, t,
                            (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01, (q[5] - q[4]) * 0.01, (q[6] - q[5]) * 0.01, (q[0] - hts[w * 64]) * 0.01);
                 }
+            for (int w = 0; w < 2; w++) {
+                const unsigned long long* q = hts + w * 64 + 48;
+                if (q[5]) printf("   ts wave %d conv1 step 4 of tile 3: reads issued %4llu  relu+wait %4llu  barrier-in %4llu  24 MFMAs %4llu  barrier-out %4llu   [clocks]\n", w * 4,
+                                 q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4]);
+            }
             CK(hipFree(dts));
         }
         const double fl = 2.0 * 2.0 * px * 64.0 * 576.0;          // algorithmic: the two convs
