@@ -248,6 +248,7 @@ int moge_test_conv3x3(int precision, const float* x, const float* w, const float
  *   y = [add +] act(conv3x3(relu_in ? relu(x) : x) + bias [+ side_w . side] [+ wu u(x) + wv v(y)])          modules.py:53-66, 148-181, 245
  *   up2: bilinear x2 + 3x3 as the 4-phase conv + pixel shuffle, y (B,2H,2W,Cout), uv at the OUTPUT resolution    modules.py:155-159
  *   w2 != NULL: the fused residual block  y = x + conv2(relu(conv1(relu(x)) + bias)) + bias2  in ONE launch       modules.py:47-68
+ *   dot_w != NULL (with up2): y[..., e] = sum_c dot_w[e][c] * fp16(up2 result[..., c]) - the level-4 output conv applied inside the resampler, modules.py:231
  * All pointers DEVICE fp32, NHWC maps, torch weight layouts (Cout,Cin,3,3) / side_w (Cout,Cin). */
 typedef struct moge_test_conv_args {
     int32_t precision, B, H, W, Cin, Cout;
@@ -258,6 +259,7 @@ typedef struct moge_test_conv_args {
     const float* wu; const float* wv; float u0, u1, v0, v1;
     const float* w2; const float* bias2;     /* fused residual block (fp16, Cin == Cout == 64) or NULL */
     float* y;
+    const float* dot_w; int32_t dot_rows;    /* up2 + fused 1x1 output conv (fp16, Cin 64, Cout 32): dot_w (dot_rows <= 4, 32) fp32; y is then (B,2H,2W,4) */
 } moge_test_conv_args;
 int moge_test_conv_ex(const moge_test_conv_args* args, void* stream);
 /* ConvTranspose2d k2 s2, NHWC: x (B,H,W,Cin), w (Cin,Cout,2,2) torch layout, y (B,2H,2W,Cout) */

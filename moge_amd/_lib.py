@@ -67,7 +67,7 @@ class TestConvArgs(C.Structure):
                 ("relu_in", C.c_int32), ("act", C.c_int32), ("up2", C.c_int32),
                 ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("add", C.c_void_p), ("side", C.c_void_p), ("side_w", C.c_void_p),
                 ("wu", C.c_void_p), ("wv", C.c_void_p), ("u0", C.c_float), ("u1", C.c_float), ("v0", C.c_float), ("v1", C.c_float),
-                ("w2", C.c_void_p), ("bias2", C.c_void_p), ("y", C.c_void_p)]
+                ("w2", C.c_void_p), ("bias2", C.c_void_p), ("y", C.c_void_p), ("dot_w", C.c_void_p), ("dot_rows", C.c_int32)]
 
 
 class MogeError(RuntimeError):

@@ -6,6 +6,7 @@
 
 typedef _Float16 f16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
@@ -224,6 +225,13 @@ struct GemmArgs {
     // conv_rb.hip (fused residual block, modules.py:47-68): out = add + conv2(relu(conv1(relu(a)) + bias)) + rb_bias2; w / rb_w2 = [C][9C]
     const void* rb_w2;
     const float* rb_bias2;
+    // conv_pp.hip EPI_CONVT with a fused 1x1 output conv (level 4 of the decoder, fp16 path): the 32 channels of every high-res pixel are
+    // rounded to fp16 and contracted with dot_nd groups of four output rows on the matrix pipe; the (B, 2H, 2W, Cout) map is NOT stored.
+    //   dot_out[((b*2H + Y)*2W + X) * 4*dot_nd + 4*gq + e] = sum_c dot_tab(gq, e, c) * fp16(x4[b, Y, X, c])        (fp32)
+    // dot_tab: f16 [dot_nd][64 lanes][8], the rows in MFMA A-operand lane layout (pack_dot_table in elementwise.hip)
+    const void* dot_tab;
+    float* dot_out;
+    int dot_nd;
 };
 
 // Opt a kernel into more than 64 KiB of dynamic LDS.  The attribute is per DEVICE and a process may drive several (one host thread per

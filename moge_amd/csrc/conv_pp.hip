@@ -63,6 +63,14 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     // the side conv is a tenth K-step on them.  Keeps the single-image form's 73 KiB of LDS = TWO workgroups per CU (the two-halo-buffer form
     // of round 2 fits one: 1176 us against ~600 us for the plain conv of the same shape).
     constexpr bool SIDE_REG = (EPI & 16) != 0;
+    // EPI bit 5 (with bit 1, BN = 128, Cout = 32): the pixel-shuffled 32-channel map is NOT stored; every high-res pixel's channels are rounded
+    // to fp16 (what the store would have kept) and contracted with up to 3 x 4 output-conv rows by ONE small MFMA per group, block and phase:
+    // the accumulator layout (lane = pixel, channels 16*jj + 4*g4 + e) is already a B operand whose K index is a permutation of the 32
+    // channels; the A operand (g.dot_tab) holds the weight rows in the same permutation, replicated over the four row groups so that every
+    // lane group receives the four outputs.  modules.py:231 (+ :245 pre-composed, see model.hip): the 960 x 960 x 32 maps of level 4 were
+    // 2 x 1.9 GB written and 4 x 1.9 GB read per step (head_final) for 3 + 1 useful channels.
+    constexpr bool DOT = (EPI & 32) != 0;
+    static_assert(!DOT || (CONVT && M16 && BN == 128), "fused output conv: the 64 -> 4 x 32 pixel-shuffle resampler");
     static_assert(!SIDE_REG || (M16 && BN == 64 && NH == 1), "register side input: single-image 64-channel form");
     constexpr int WN = BN / 64, WM = 8 / WN, TM = TW * 16 / 32 / WM, TN = 2;
     constexpr int HALO_W = Halo<TW>::W, HALO_PX = Halo<TW>::PX, HALO_PIECES = Halo<TW>::PIECES, HALO_BYTES = Halo<TW>::BYTES, HPW = Halo<TW>::HPW;
@@ -385,6 +393,12 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
         }
     };
     if constexpr (PERSIST) load_skip_rows();         // early: their latency passes under the arithmetic below (they must be in before the prefetch)
+    u32x4 dota[DOT ? 3 : 1], dotb[DOT ? 2 * TM : 1][2];
+    if constexpr (DOT) {
+#pragma unroll
+        for (int gq = 0; gq < 3; gq++)
+            dota[gq] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(g.dot_tab) + (gq < g.dot_nd ? gq : 0) * 1024 + lane * 16);
+    }
     if constexpr (M16) {
         // 16x16x32 accumulators: block i = tile row wm*2*TM + i, lane: pixel x0 + l15, channels nw + jj*16 + 4*g4 .. +3
         float u0[2 * TM], u1[2 * TM], v0[2 * TM], v1[2 * TM];
@@ -436,7 +450,37 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], lo);
                 const f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                *reinterpret_cast<f16x4*>(R + row * 128 + ((((jj * 2 + (g4 >> 1)) ^ (row & 7)) << 4) | ((g4 & 1) << 3))) = hv;
+                if constexpr (DOT) {
+                    // B operand of the output-conv MFMA of (block i, phase jj >> 1): halves 0-3 = channels 4*g4 + e (jj even), 4-7 = 16 + 4*g4 + e (jj odd)
+                    const u32x2 hw = __builtin_bit_cast(u32x2, hv);
+                    dotb[i][jj >> 1][(jj & 1) * 2] = hw[0];
+                    dotb[i][jj >> 1][(jj & 1) * 2 + 1] = hw[1];
+                } else {
+                    *reinterpret_cast<f16x4*>(R + row * 128 + ((((jj * 2 + (g4 >> 1)) ^ (row & 7)) << 4) | ((g4 & 1) << 3))) = hv;
+                }
+            }
+        }
+        if constexpr (DOT) {
+            // one small MFMA per (group, pixel block, phase); lane group g4 stores pixel block i = g4 (every group holds all four results):
+            // pixel (y0 + wm*2*TM + i, x0 + l15), phases (dy = wn, dx = p) = two adjacent high-res pixels, contiguous over the 16 lanes of a row.
+            // Stored at once (one result live at a time: the 3 x 4 x 2 results together do not fit beside the kernel's other registers)
+            float* const dout = g.dot_out;
+            const int nd4 = 4 * g.dot_nd;
+#pragma unroll
+            for (int i = 0; i < 2 * TM; i++) {
+                const int y = y0 + wm * 2 * TM + i, x = x0 + l15;
+                const bool mine = g4 == i && y < H && x < W;
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const size_t px = ((size_t)b * 2 * H + 2 * y + wn) * (2 * W) + 2 * x + p;
+#pragma unroll
+                    for (int gq = 0; gq < 3; gq++)
+                        if (gq < g.dot_nd) {
+                            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                            mma16<f16>(d, dota[gq], dotb[i][p]);
+                            if (mine) *reinterpret_cast<f32x4*>(dout + px * nd4 + 4 * gq) = d;
+                        }
+                }
             }
         }
     } else {
@@ -504,6 +548,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
         if (more) issue_halo(0);
         asm volatile("" ::: "memory");
     }
+    if constexpr (!DOT)
 #pragma unroll
     for (int it = 0; it < WROWS / 8; it++) {
         const int row = it * 8 + rr;
@@ -561,6 +606,7 @@ bool conv_pp_eligible(const GemmArgs& g) {
     if (g.relu_in && (g.uv.wu || g.epi != EPI_STORE)) return false;
     if (g.epi == EPI_STORE)        // (the residual add is applied after the activation here: never combined by the decoder)
         return (g.ldc & 7) == 0 && (!g.add || ((g.ldadd & 7) == 0 && g.act == ACT_NONE)) && (!g.uv.wu || g.bias) && g.act != ACT_GELU;
+    if (g.dot_tab && !(g.epi == EPI_CONVT && g.Cout == 32 && g.N == 128 && g.C == 64 && g.dot_out && g.dot_nd >= 1 && g.dot_nd <= 3 && !g.a2)) return false;
     if (g.epi == EPI_CONVT) return !g.add && g.act == ACT_NONE && (g.Cout == 32 || (g.Cout & 63) == 0) && g.N == 4 * g.Cout;
     return false;
 }
@@ -570,6 +616,13 @@ static int launch_conv_epi(const GemmArgs& g, hipStream_t st) {
     const int e = (g.uv.wu ? 1 : 0) | (g.epi == EPI_CONVT ? 2 : 0) | (g.relu_in ? 4 : 0);
     if constexpr (BN == 64 && TW == 16 && NH == 1) {
         if (g.a2) return e == 0 ? launch_conv_cfg<BN, TW, NH, 8 | 16>(g, st) : -1;      // register side input (plain store only: what the heads use)
+    }
+    if constexpr (BN == 128 && TW == 16 && NH == 1) {
+        if (g.dot_tab) {                                                                // fused output conv of level 4
+            if (e == 2) return launch_conv_cfg<BN, TW, NH, 8 | 2 | 32>(g, st);
+            if (e == 3) return launch_conv_cfg<BN, TW, NH, 8 | 2 | 1 | 32>(g, st);
+            return -1;
+        }
     }
 #ifdef MOGE_EXPERIMENTS
     if (TW == 32 || moge_tune_get("CONV_M16", 1) == 0) {       // the v_mfma_f32_32x32x16_f16 form (tools/kbench A-B only)

@@ -747,3 +747,24 @@ int launch_resize_bilinear_uv(const void* x, void* out, int B, int hs, int ws, i
 }
 template int launch_resize_bilinear_uv<f16>(const void*, void*, int, int, int, int, int, int, int, float, float, float, float, hipStream_t);
 template int launch_resize_bilinear_uv<float>(const void*, void*, int, int, int, int, int, int, int, float, float, float, float, hipStream_t);
+
+
+// --------------------------------------------------------------------------------------------
+// A-operand table of conv_pp.hip's fused output conv (GemmArgs::dot_tab): nd groups of four weight rows W[4*gq + e][0..31] (fp32, rows >=
+// `rows` are zero) as v_mfma_f32_16x16x32_f16 A fragments: lane (r = lane & 15, g4 = lane >> 4) holds row (r & 3) of its group - replicated
+// over the four row groups, so every lane group of the result holds the four outputs - at the K positions of its slots s = 0..7:
+// channel 4*g4 + s (s < 4), 16 + 4*g4 + s - 4 (s >= 4) = the channel order of the conv accumulators that form the B operand.
+// --------------------------------------------------------------------------------------------
+__global__ void pack_dot_table_kernel(const float* __restrict__ w, int rows, int nd, f16* __restrict__ tab) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // (gq, lane, s)
+    if (idx >= nd * 64 * 8) return;
+    const int s = idx & 7, lane = (idx >> 3) & 63, gq = idx >> 9;
+    const int row = 4 * gq + (lane & 3), g4 = lane >> 4;
+    const int c = s < 4 ? 4 * g4 + s : 16 + 4 * g4 + (s - 4);
+    tab[idx] = (f16)(row < rows ? w[row * 32 + c] : 0.f);
+}
+int launch_pack_dot_table(const float* w, int rows, int nd, void* tab, hipStream_t st) {
+    if (rows < 1 || nd < 1 || rows > 4 * nd) return -1;
+    hipLaunchKernelGGL(pack_dot_table_kernel, dim3((nd * 512 + 255) / 256), dim3(256), 0, st, w, rows, nd, (f16*)tab);
+    return (int)hipGetLastError();
+}

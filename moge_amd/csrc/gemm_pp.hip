@@ -45,7 +45,6 @@ template <int EPK> struct EpkBase { static constexpr int K = EPK == EPK_GELU_LN 
 // Addressing: raw buffer instructions over a descriptor of exactly M rows (wave-uniform, built from kernel arguments) + ONE 32-bit byte
 // offset per lane - no 64-bit per-lane address lives across the stages (with them the kernel spilled, and every scratch reload waited
 // vmcnt(0) = for all stores in flight); rows >= M are out of range of the descriptor: their loads return 0 and their stores are dropped.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 struct ResidBufs {
     __amdgpu_buffer_rsrc_t x, x16, part;
     unsigned ldc4, ldc2, npart8;        // row pitches in bytes: fp32 residual, fp16 copy, (sum, sum of squares) pairs

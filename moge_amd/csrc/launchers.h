@@ -28,6 +28,11 @@ int launch_repack(const float* src, void* dst, int n0, int n1, int n2, int n3, l
                   long ds2, hipStream_t st);
 
 template <typename T> int launch_pack_phase_conv(const float* w, void* dst, int Cout, int Cin, hipStream_t st);
+int launch_pack_dot_table(const float* w, int rows, int nd, void* tab, hipStream_t st);      // GemmArgs::dot_tab from fp32 rows [rows][32]
+// head_final on the fused output-conv maps (conv_pp.hip DOT): y (B,Hd,Wd,4) fp32 = Wo . x4, z (B,Hd,Wd,zld) fp32 with this head's group at
+// channel zoff (= (Wo . Win4) . neck4), or null; out = remap(resize(y + z) + bias)
+int launch_head_final_dot(int kind, const float* y, const float* z, int zld, int zoff, const float* bias, float* out, int B, int Hd, int Wd, int H, int W,
+                          int remap, hipStream_t st);
 
 template <typename T>
 int launch_head_final(int kind, const void* x4, const float* w, const float* bias, const void* n4, const float* w2, float* out, int B, int Hd,

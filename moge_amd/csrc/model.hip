@@ -213,6 +213,11 @@ static void build_tables_v2_decoder(moge_handle* h) {
             tadd(h, name + ".output_blocks.4.bias", cout);
             aadd(h, name + ".out4.w2", (int64_t)cout * c.dims[4]);      // output conv o level-4 input block (fp16 path, see head_final_kernel)
             aadd(h, name + ".out4.b2", cout);
+            aadd(h, name + ".dot.own", 256);                            // conv_pp fused output conv: one group of A-operand rows (512 halves), Wout
+        }
+        if (neck) {
+            aadd(h, "neck.dot.w2cat", 3 * 4 * 32);                      // the heads' (Wout . Win4) rows, four per head (zero padded), head order
+            aadd(h, "neck.dot", 3 * 256);                               // ... as up to three A-operand groups
         }
     };
     stack("neck", true, c.neck_res_blocks, 0);
@@ -292,6 +297,7 @@ static int build_aux(moge_handle* h, hipStream_t st) {
         return 0;
     };
     CHK(stack("neck"));
+    int ndot = 0;                                   // heads that have a group in the neck's fused-output-conv table
     for (int k = 0; k < 3; k++)
         if (c.heads & HEAD_BITS[k]) {
             CHK(stack(HEAD_NAMES[k]));
@@ -317,7 +323,18 @@ static int build_aux(moge_handle* h, hipStream_t st) {
             HIPCHK(hipMemcpyAsync(A(h, name + ".out4.w2"), w2.data(), w2.size() * 4, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(A(h, name + ".out4.b2"), b2.data(), b2.size() * 4, hipMemcpyHostToDevice, st));
             HIPCHK(hipStreamSynchronize(st));
+            // fused output conv of level 4 (conv_pp.hip DOT, fp16 path): this head's Wout as its own group, its W2 as group `ndot` of the neck's table
+            if (c4 == 32 && co <= 4) {
+                LCHK(launch_pack_dot_table(M(h, name + ".output_blocks.4.weight"), co, 1, A(h, name + ".dot.own"), st));
+                std::vector<float> rows4(4 * 32, 0.f);
+                for (int o = 0; o < co; o++)
+                    for (int j = 0; j < 32; j++) rows4[o * 32 + j] = w2[(size_t)o * c4 + j];
+                HIPCHK(hipMemcpyAsync(A(h, "neck.dot.w2cat") + ndot * 128, rows4.data(), 128 * 4, hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+                ndot++;
+            }
         }
+    if (ndot > 0) LCHK(launch_pack_dot_table(A(h, "neck.dot.w2cat"), 4 * ndot, ndot, A(h, "neck.dot"), st));
     h->aux_ready = true;
     return 0;
 }
@@ -500,7 +517,10 @@ static int run_gemm(moge_handle* h, const GemmArgs& g, int amode, int cls, hipSt
     switch (g.epi) {
     case EPI_RESID: bytes += (double)g.M * g.N * (8.0 + (g.x16 ? 2.0 : 0.0)) + (g.ln_part ? (double)g.M * (g.N / 32) * 8.0 : 0.0); break;   // fp32 x read + write, fp16 copy, LN partials
     case EPI_PATCH: bytes += (double)g.M * g.N * 8.0; break;                                  // + pos read, fp32 x write
-    default: bytes += (double)g.M * g.N * e * (g.add ? 2 : 1); break;                         // STORE / QKV / CONVT: the outputs (+ the added map)
+    default:
+        if (g.dot_tab) bytes += (double)g.M * 4 * (16.0 * g.dot_nd);                           // fused output conv: 4 phases x 4 nd floats per low-res pixel
+        else bytes += (double)g.M * g.N * e * (g.add ? 2 : 1);                                 // STORE / QKV / CONVT: the outputs (+ the added map)
+        break;
     }
     if (cls == MOGE_KC_GEMM && amode == AMODE_LINEAR && std::is_same<T, f16>::value && gemm_runs_pp(g)) cls = MOGE_KC_GEMM_PP;
     ProfScope ps(h, st, cls, flops, bytes);
@@ -535,13 +555,14 @@ static int conv3x3(moge_handle* h, const T* in, const T* w, const float* bias, T
 // bilinear x2 + 3x3 conv as a 4-phase 3x3 conv on the low-res map (Hl,Wl), output (B,2Hl,2Wl,Cout); uv given for the HIGH-res grid
 template <typename T>
 static int conv_up2_phase(moge_handle* h, const T* in, const T* w4, const float* bias4, T* out, int B, int Hl, int Wl, int Cin, int Cout,
-                          const UVTerm* uv, hipStream_t st) {
+                          const UVTerm* uv, hipStream_t st, const float* dot_tab = nullptr, int dot_nd = 0, float* dot_out = nullptr) {
     GemmArgs g = gemm_args();
     g.a = in; g.H = Hl; g.W = Wl; g.C = Cin;
     g.w = w4; g.ldw = 9 * Cin;
     g.M = B * Hl * Wl; g.N = 4 * Cout; g.K = 9 * Cin;
     g.epi = EPI_CONVT; g.bias = bias4; g.out = out; g.Cout = Cout; g.pixW = Wl; g.pixH = Hl;
     if (uv) g.uv = *uv;
+    if (dot_tab) { g.dot_tab = dot_tab; g.dot_nd = dot_nd; g.dot_out = dot_out; g.out = nullptr; }      // fused output conv: only (B,2H,2W,4 nd) fp32 leaves the kernel
     return run_gemm<T>(h, g, AMODE_CONV3, MOGE_KC_CONV, st);
 }
 
@@ -782,6 +803,12 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
         LCHK(launch_mlp_layer(m2, M(h, "scale_head.4.weight"), M(h, "scale_head.4.bias"), o_metric, B, c.scale_hidden, 1, 2, st));
     }
 
+    // fp16 path, level 4 (no residual blocks there, 32 channels): out_k(x4_k + in4_k(n4)) = Wout_k x4_k + (Wout_k Win4_k) n4 + b2_k is evaluated
+    // INSIDE the two 64 -> 4 x 32 resampler convs (conv_pp.hip, fused output conv); head_final only resizes and remaps 4 + 4 floats per tap
+    int nheads = 0;
+    for (int k = 0; k < 3; k++) nheads += (c.heads & HEAD_BITS[k]) ? 1 : 0;
+    const bool l4dot = std::is_same<T, f16>::value && c.head_res_blocks[MOGE_LEVELS - 1] == 0 && c.neck_res_blocks[MOGE_LEVELS - 1] == 0 && c.dims[4] == 32 &&
+                       c.dims[3] == 64 && moge_tune_get("FUSE_L4", 1) != 0 && moge_tune_get("L4DOT", 1) != 0 && moge_tune_get("CONV_PP", 1) != 0;
     // ---- neck (modules.py:242-254; level-0 uv concat folded into a rank-2 epilogue term, v2.py:154-160) -----------
     T* N[MOGE_LEVELS];
     for (int l = 0; l < MOGE_LEVELS; l++) N[l] = (T*)(ws + pl.neck[l]);
@@ -797,6 +824,11 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
                 CHK(convT2<T>(h, N[l - 1], P<T>(h, S("neck.rs%d.wT", l - 1)), A(h, S("neck.rs%d.biasT", l - 1)), Sc[0], B, Hh / 2, Ww / 2, ci, co, st));
                 CHK(conv3x3<T>(h, Sc[0], P<T>(h, S("neck.rs%d.w3", l - 1)), A(h, S("neck.rs%d.bias2", l - 1)), N[l], B, Hh, Ww, co, co, 0, ACT_NONE, nullptr,
                                &uvl, st));
+            } else if (l4dot) {
+                // the neck's level-4 map is only ever read through the heads' composed input block + output conv (no residual blocks at level
+                // 4): the resampler applies all of them per pixel and stores 4 floats per head instead of 32 halves
+                CHK(conv_up2_phase<T>(h, N[l - 1], P<T>(h, "neck.rs3.w3p"), A(h, "neck.rs3.bias4"), N[l], B, Hh / 2, Ww / 2, ci, co, &uvl, st, A(h, "neck.dot"), nheads,
+                                      (float*)N[l]));
             } else {
                 CHK(conv_up2_phase<T>(h, N[l - 1], P<T>(h, "neck.rs3.w3p"), A(h, "neck.rs3.bias4"), N[l], B, Hh / 2, Ww / 2, ci, co, &uvl, st));
             }
@@ -809,6 +841,8 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     for (int k = 0; k < 3; k++) {
         if (!(c.heads & HEAD_BITS[k]) || !outs[k]) continue;
         const std::string name = HEAD_NAMES[k];
+        int head_idx = 0;                  // this head's group in the neck's fused-output-conv table: its position among the model's heads
+        for (int k2 = 0; k2 < k; k2++) head_idx += (c.heads & HEAD_BITS[k2]) ? 1 : 0;
         int cur = 0;                       // Sc[cur] holds the running x
         CHK(conv1x1<T>(h, N[0], P<T>(h, name + ".in0.w"), M(h, name + ".input_blocks.0.bias"), Sc[cur], BP, c0, c0, nullptr, nullptr, cols, rows, st));
         CHK(res_blocks<T>(h, name, 0, c.head_res_blocks[0], Sc[cur], Sc[(cur + 1) % 3], B, rows, cols, c0, st));
@@ -836,6 +870,10 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
                     CHK(conv3x3<T>(h, Sc[a], P<T>(h, name + S(".rs%d.w3", l - 1)), M(h, name + S(".resamplers.%d.1.bias", l - 1)), Sc[b2], B, Hh, Ww, co, co, 0,
                                    ACT_NONE, nullptr, nullptr, st));
                 nxt = b2;
+            } else if (l4dot) {
+                CHK(conv_up2_phase<T>(h, Sc[cur], P<T>(h, name + ".rs3.w3p"), A(h, name + ".rs3.bias4"), Sc[a], B, Hh / 2, Ww / 2, ci, co, nullptr, st, A(h, name + ".dot.own"), 1,
+                                      (float*)Sc[a]));
+                nxt = a;
             } else {
                 CHK(conv_up2_phase<T>(h, Sc[cur], P<T>(h, name + ".rs3.w3p"), A(h, name + ".rs3.bias4"), Sc[a], B, Hh / 2, Ww / 2, ci, co, nullptr, st));
                 nxt = a;
@@ -854,7 +892,10 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
         }
         {
             ProfScope ps(h, st, MOGE_KC_POST, 0, (double)B * (rows << 4) * (cols << 4) * c.dims[4] * sizeof(T));
-            if (fuse_l4)
+            if (l4dot)
+                LCHK(launch_head_final_dot(k, (const float*)Sc[cur], (const float*)N[4], 4 * nheads, 4 * head_idx, A(h, name + ".out4.b2"), outs[k], B, rows << 4, cols << 4,
+                                           pl.H, pl.W, c.remap_output, st));
+            else if (fuse_l4)
                 LCHK(launch_head_final<T>(k, Sc[cur], M(h, name + ".output_blocks.4.weight"), A(h, name + ".out4.b2"), N[4], A(h, name + ".out4.w2"), outs[k], B,
                                           rows << 4, cols << 4, c.dims[4], pl.H, pl.W, c.remap_output, st));
             else
@@ -869,7 +910,9 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     h->last.bufs["tapcat"] = {pl.tapcat, {(int64_t)BP * c.n_taps * D, 1}};
     h->last.bufs["cls"] = {pl.cls, {(int64_t)B * D, 0}};
     h->last.bufs["features"] = {pl.feat, {(int64_t)BP * c0, 1}};
-    for (int l = 0; l < MOGE_LEVELS; l++) h->last.bufs[S("neck%d", l)] = {pl.neck[l], {(int64_t)BP * ((int64_t)1 << (2 * l)) * c.dims[l], 1}};
+    for (int l = 0; l < MOGE_LEVELS; l++)
+        if (!(l == MOGE_LEVELS - 1 && l4dot))       // (fused output conv: the level-4 map is never materialised)
+            h->last.bufs[S("neck%d", l)] = {pl.neck[l], {(int64_t)BP * ((int64_t)1 << (2 * l)) * c.dims[l], 1}};
     return 0;
 }
 

@@ -221,6 +221,66 @@ int launch_head_final(int kind, const void* x4, const float* w, const float* bia
 template int launch_head_final<f16>(int, const void*, const float*, const float*, const void*, const float*, float*, int, int, int, int, int, int, int, hipStream_t, int);
 template int launch_head_final<float>(int, const void*, const float*, const float*, const void*, const float*, float*, int, int, int, int, int, int, int, hipStream_t, int);
 
+// head_final on the maps of the fused output conv (conv_pp.hip, EPI bit 5): the 1x1 output conv (modules.py:231) and the pre-composed level-4
+// input block (modules.py:245) were applied per high-res pixel by the resampler kernels, so what is left is 4 + 4 floats per tap:
+// bilinear resize (v2.py:170; linear: it commutes with the convs), bias, remap (v2.py:173-180).  One thread per output pixel.
+template <int KIND>
+__global__ __launch_bounds__(256) void head_final_dot_kernel(const float* __restrict__ y, const float* __restrict__ z, int zld, int zoff,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int B, int Hd, int Wd, int H, int W, int remap) {
+    constexpr int CO = (KIND == 2 || KIND == 3) ? 1 : 3;
+    const long total = (long)B * H * W;
+    const float sy_scale = (float)Hd / (float)H, sx_scale = (float)Wd / (float)W;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ox = idx % W;
+        const long t = idx / W;
+        const int oy = t % H, b = t / H;
+        float sy = sy_scale * (oy + 0.5f) - 0.5f, sx = sx_scale * (ox + 0.5f) - 0.5f;
+        sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx;
+        int y0 = (int)sy, x0 = (int)sx;
+        y0 = y0 < Hd - 1 ? y0 : Hd - 1; x0 = x0 < Wd - 1 ? x0 : Wd - 1;
+        const int y1 = y0 + 1 < Hd ? y0 + 1 : Hd - 1, x1 = x0 + 1 < Wd ? x0 + 1 : Wd - 1;
+        float ly = sy - y0, lx = sx - x0;
+        ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
+        const float wt[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
+        const size_t pb = (size_t)b * Hd * Wd;
+        const size_t pix[4] = {pb + (size_t)y0 * Wd + x0, pb + (size_t)y0 * Wd + x1, pb + (size_t)y1 * Wd + x0, pb + (size_t)y1 * Wd + x1};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(y + pix[k] * 4);
+            if (z) v += *reinterpret_cast<const f32x4*>(z + pix[k] * zld + zoff);
+            acc += wt[k] * v;
+        }
+        float o[3];
+#pragma unroll
+        for (int j = 0; j < CO; j++) o[j] = acc[j] + bias[j];
+        if (KIND == 0) {
+            float x = o[0], yy = o[1], zz = o[2];
+            if (remap == MOGE_REMAP_EXP) { zz = expf(zz); x *= zz; yy *= zz; }
+            else if (remap == MOGE_REMAP_SINH) { x = sinhf(x); yy = sinhf(yy); zz = sinhf(zz); }
+            else if (remap == MOGE_REMAP_SINH_EXP) { x = sinhf(x); yy = sinhf(yy); zz = expf(zz); }
+            out[idx * 3] = x; out[idx * 3 + 1] = yy; out[idx * 3 + 2] = zz;
+        } else if (KIND == 1) {
+            const float nrm = fmaxf(sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]), 1e-12f);
+            out[idx * 3] = o[0] / nrm; out[idx * 3 + 1] = o[1] / nrm; out[idx * 3 + 2] = o[2] / nrm;
+        } else if (KIND == 3) {
+            out[idx] = o[0];
+        } else {
+            out[idx] = 1.f / (1.f + expf(-o[0]));
+        }
+    }
+}
+int launch_head_final_dot(int kind, const float* y, const float* z, int zld, int zoff, const float* bias, float* out, int B, int Hd, int Wd, int H, int W,
+                          int remap, hipStream_t st) {
+    const long total = (long)B * H * W;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65536) blocks = 65536;
+#define HFD(K) hipLaunchKernelGGL((head_final_dot_kernel<K>), dim3(blocks), dim3(256), 0, st, y, z, zld, zoff, bias, out, B, Hd, Wd, H, W, remap)
+    if (kind == 0) HFD(0); else if (kind == 1) HFD(1); else if (kind == 2) HFD(2); else HFD(3);
+#undef HFD
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // out[b][n] = f(sum_k in[b][k]*W[n][k] + bias[n]); one wave per output, fp32.  act: 0 none, 1 relu, 2 exp
 __global__ __launch_bounds__(256) void mlp_layer_kernel(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,

@@ -171,6 +171,13 @@ static int t_conv_ex(const moge_test_conv_args& a, hipStream_t st) {
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.a = xb.p; g.H = H; g.W = W; g.C = Cin; g.relu_in = a.relu_in;
     g.w = wb.p; g.ldw = 9 * Cin; g.M = B * H * W; g.K = 9 * Cin; g.out = yb.p; g.pixW = W; g.pixH = H; g.act = a.act;
+    DevBuf dtab, dout;
+    if (a.dot_w) {
+        if (!up2 || !std::is_same<T, f16>::value || Cin != 64 || Cout != 32 || a.dot_rows < 1 || a.dot_rows > 4) return MOGE_ERR_INVALID;
+        TCHK(dtab.alloc(1024)); TCHK(dout.alloc((size_t)B * Ho * Wo * 4 * sizeof(float)));
+        TL(launch_pack_dot_table(a.dot_w, a.dot_rows, 1, dtab.p, st));
+        g.dot_tab = dtab.p; g.dot_nd = 1; g.dot_out = (float*)dout.p;
+    }
     if (up2) {
         if (a.add || a.side || a.w2) return MOGE_ERR_INVALID;
         TL(launch_pack_phase_conv<T>(a.w, wb.p, Cout, Cin, st));
@@ -209,7 +216,12 @@ static int t_conv_ex(const moge_test_conv_args& a, hipStream_t st) {
     } else {
         TL(launch_gemm<T>(g, AMODE_CONV3, st));
     }
-    TL(from_t<T>(yb.p, a.y, (long)ny, st));
+    if (a.dot_w) {
+        if (!conv_pp_eligible(g)) return MOGE_ERR_INVALID;
+        TCHK(hipMemcpyAsync(a.y, dout.p, (size_t)B * Ho * Wo * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+        TL(from_t<T>(yb.p, a.y, (long)ny, st));
+    }
     TCHK(hipStreamSynchronize(st));
     return 0;
 }

@@ -153,7 +153,7 @@ def groupnorm_relu(prec, x_nhwc, gamma, beta, groups):
     return y
 
 
-def conv_ex(x_nhwc, w, bias, prec=1, relu_in=False, act=0, add=None, side=None, side_w=None, uv=None, up2=False, w2=None, bias2=None):
+def conv_ex(x_nhwc, w, bias, prec=1, relu_in=False, act=0, add=None, side=None, side_w=None, uv=None, up2=False, w2=None, bias2=None, dot_w=None):
     """One 3x3 conv through the pieces the decoder fuses into it (moge_test_conv_ex).  uv = (wu, wv, u0, u1, v0, v1) at the OUTPUT resolution;
     w2 / bias2 select the fused residual block (conv_rb.hip)."""
     import ctypes as C
@@ -170,7 +170,7 @@ def conv_ex(x_nhwc, w, bias, prec=1, relu_in=False, act=0, add=None, side=None, 
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
-    y = torch.empty((B, Ho, Wo, Cout), device="cuda", dtype=torch.float32)
+    y = torch.empty((B, Ho, Wo, 4 if dot_w is not None else Cout), device="cuda", dtype=torch.float32)
     a = L.TestConvArgs()
     a.precision, a.B, a.H, a.W, a.Cin, a.Cout = prec, B, H, W, Cin, Cout
     a.relu_in, a.act, a.up2 = int(bool(relu_in)), act, int(bool(up2))
@@ -180,6 +180,8 @@ def conv_ex(x_nhwc, w, bias, prec=1, relu_in=False, act=0, add=None, side=None, 
         wu, wv, u0, u1, v0, v1 = uv
         a.wu, a.wv, a.u0, a.u1, a.v0, a.v1 = dev(wu), dev(wv), u0, u1, v0, v1
     a.w2, a.bias2 = dev(w2), dev(bias2)
+    if dot_w is not None:
+        a.dot_w, a.dot_rows = dev(dot_w), int(dot_w.shape[0])
     a.y = y.data_ptr()
     L.check(L.lib.moge_test_conv_ex(C.byref(a), st()))
     return y

@@ -116,6 +116,26 @@ def test_conv_up2_pixel_shuffle(H, uv, B, Hh, Ww, Cin, Cout):
     assert float((out - ref).abs().mean()) <= 3e-4 * scale
 
 
+@pytest.mark.parametrize("uv", [False, True])
+@pytest.mark.parametrize("rows", [1, 3, 4])
+@pytest.mark.parametrize("B,Hh,Ww", [(2, 19, 33), (1, 16, 16), (1, 37, 50)])
+def test_conv_up2_with_fused_output_conv(H, uv, rows, B, Hh, Ww):
+    """The level-4 resampler with the head's 1x1 output conv (modules.py:231) applied inside it: (B, 2H, 2W, 4) fp32 = Wout . fp16(up2 result), the
+    32-channel map itself never stored.  Against the unfused kernel's own fp16 output contracted in fp32 with the fp16-rounded weights (exact up
+    to fp32 summation order) and against F.conv2d end to end."""
+    g, x, w, b = mk(B, Hh, Ww, 64, 32, 8)
+    wout = torch.randn(rows, 32, generator=g) / 32 ** 0.5
+    kw = {}
+    if uv:
+        kw["uv"] = (torch.randn(32, generator=g), torch.randn(32, generator=g), -0.7, 0.7, -0.6, 0.6)
+    x4 = H.conv_ex(x, w, b, up2=True, **kw)                                   # the unfused path's fp16 map
+    got = H.conv_ex(x, w, b, up2=True, dot_w=wout, **kw)
+    ref = torch.einsum("bhwc,oc->bhwo", x4.double(), r16(wout).double().cuda())
+    scale = float(ref.abs().max())
+    assert float((got[..., :rows].double() - ref).abs().max()) <= 2e-6 * scale + 1e-6
+    assert float(got[..., rows:].abs().max()) == 0.0 if rows < 4 else True
+
+
 def resblock_ref(x, w1, b1, w2, b2):
     h = r16(F.relu(conv_ref(x, w1, b1, True)))                       # the intermediate map is fp16 in both the fused and the two-launch path
     xc = h.permute(0, 3, 1, 2)

@@ -33,6 +33,16 @@ print('conv forms $v: %.1f img/s  %.2f ms/step  conv %.2f ms  gemm_pp %.2f  attn
     attn_q4)    timeout 300 ./tools/kbench attn - 10 > $out/${tag}_kbench_attn.log 2>&1; cat $out/${tag}_kbench_attn.log
                 MOGE_ATTN_KERN=2 timeout 300 python -m pytest tests/test_hip_kernels.py -k attention -q -p no:cacheprovider 2>&1 | tail -3 ;;
     kb_rb_var)  for v in ${RBVARS:-0 4 8 12}; do echo "== CONV_RB_VAR $v"; KB_RBVAR=$v KB_TS=1 KB_ROUNDS=2 timeout 300 ./tools/kbench rb - 10 2>&1 | grep -v "tile [0-2]:\|b16\|grid b8\|odd" ; done > $out/${tag}_kbench_rb_var.log 2>&1; cat $out/${tag}_kbench_rb_var.log ;;
+    ab)         # same box, alternating: MOGE_$AB_VAR = 0 / 1 (e.g. AB_VAR=L4DOT)
+                for r in 1 2; do
+                  for v in ${AB_VALS:-0 1}; do
+                    env MOGE_${AB_VAR}=$v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pcie 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline()); k = d['kernel_classes']
+print('$AB_VAR=$v: %.1f img/s  %.2f ms/step  conv %.2f ms  gemm_pp %.2f  attn %.2f  post %.2f  norm %.2f' % (d['value'], d['ms_per_step'], k['conv']['ms_per_step'], k['gemm_pp']['ms_per_step'], k['attn']['ms_per_step'], k['post']['ms_per_step'], k['norm']['ms_per_step']))"
+                  done
+                done > $out/${tag}_ab_${AB_VAR}.log 2>&1; cat $out/${tag}_ab_${AB_VAR}.log ;;
+    tests_conv) timeout 600 python -m pytest tests/test_hip_conv_ex.py tests/test_hip_parity.py -m gpu -q -p no:cacheprovider > $out/${tag}_pytest_conv.log 2>&1; tail -15 $out/${tag}_pytest_conv.log ;;
     *) echo "unknown step $what" ;;
   esac
 done
