@@ -38,7 +38,7 @@ typedef enum moge_status {
 
 typedef enum moge_precision {
     MOGE_FP32 = 0,   /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity mode */
-    MOGE_FP16 = 1    /* fp16 storage, fp32 accumulate (v_mfma_f32_32x32x16_f16): the throughput mode */
+    MOGE_FP16 = 1    /* fp16 storage, fp32 accumulate (v_mfma_f32_16x16x32_f16): the throughput mode */
 } moge_precision;
 
 typedef enum moge_remap { MOGE_REMAP_LINEAR = 0, MOGE_REMAP_SINH = 1, MOGE_REMAP_EXP = 2, MOGE_REMAP_SINH_EXP = 3 } moge_remap;
@@ -109,7 +109,7 @@ typedef struct moge_outputs {
 typedef struct moge_handle moge_handle;
 
 /* Kernel classes for the built-in HIP-event profiler (bench.py roofline). */
-/* MOGE_KC_GEMM_PP: launches of the ViT / out-projection linear layers that ran on the ping-pong throughput kernel (gemm_pp128m16_kernel) -
+/* MOGE_KC_GEMM_PP: launches of the ViT / out-projection linear layers that ran on the persistent ping-pong throughput kernel (gemm_pp128p_kernel; K < 192: its one-tile form gemm_pp128m16_kernel) -
  * the roofline object of bench.py; MOGE_KC_GEMM: the same layers on the latency-regime kernels + the patch-embed GEMM. */
 enum { MOGE_KC_GEMM = 0, MOGE_KC_ATTN = 1, MOGE_KC_CONV = 2, MOGE_KC_NORM = 3, MOGE_KC_PRE = 4, MOGE_KC_POST = 5,
        MOGE_KC_RECOVER = 6, MOGE_KC_GEMM_PP = 7, MOGE_KC_COUNT = 8 };
@@ -214,7 +214,7 @@ void moge_tune_set(const char* key, int value);
 int moge_test_gemm(int precision, const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
                    int act, void* stream);
 /* The same GEMM through every fused epilogue of the ViT / decoder linear layers (gemm.hip + gemm_pp.hip), so that the production fp16
- * throughput kernel (gemm_pp128m16_kernel: selected when N % 256 == 0, K % 64 == 0 and the problem has >= PP_MIN_TILES 256x256 tiles, or forced
+ * throughput kernel (gemm_pp128p_kernel, persistent; gemm_pp128m16_kernel for K < 192: selected when N % 256 == 0, K % 64 == 0 and the problem has >= PP_MIN_TILES 256x256 tiles, or forced
  * with moge_tune_set("PP_MIN_TILES", 0)) and the latency-regime kernels (moge_tune_set("GEMM_PP", 0)) can each be compared with a plain
  * fp32 reference and with each other.  All pointers are DEVICE fp32 unless noted; acc = A W^T.
  *   MOGE_TG_STORE  out[m][n]  = act(lnfold(acc) + bias[n] (+ wu[n] u(x) + wv[n] v(y)))            attention.py:72, mlp.py:35, modules.py:128-131

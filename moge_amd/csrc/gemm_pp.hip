@@ -622,7 +622,13 @@ __device__ __forceinline__ void pp_epi_run(const GemmArgs& g, f32x4 (&acc)[8][4]
 // Queue order of a tile's DMA: A0 W0 W1 | epilogue loads, stores | A1 A2lo | A2hi W2 A3lo ... : the steady-state vmcnt(10) of the ring
 // (leaves A(t+2)lo A(t+2)hi W(t+2) A(t+3)lo) holds from t = 0 on; the tile-head wait is vmcnt(6) (A1 A2lo stay in flight).
 // ------------------------------------------------------------------------------------------------------------------------
-template <int EPK, int SROWS>
+// MRG (round 3 experiment, instantiated in --experiments builds only; measured 10-17 % SLOWER, see launch_pp_any): ONE MFMA segment of 64 per
+// K-tile and wave group instead of two of 32 - half the hand-overs between the two wave groups of a SIMD (each costs ~90 clocks of barrier +
+// restart, conv_rb.hip's step timeline: profiles/r03j_kbench_rb_step_timeline.log) - at the price of a W ring that is only 0.75 K-tiles ahead.  The A rows
+// 64-127 of the wave ("hi") are read from LDS INSIDE the segment, into the registers of the "lo" fragments as those die, so the register
+// count does not change.  The DMA schedule is then tied to the global intervals (both groups issue at the start of an even interval - group 0
+// is in its read segment, group 1 in its MFMA segment - and wait at the interval ends), see the loop.
+template <int EPK, int SROWS, bool MRG>
 __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
     constexpr int WN = 4, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * 32 KiB (A ring) + 2 * 32 KiB (W ring)
@@ -726,13 +732,122 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(POST + PP_TRAIL) : "memory");
         first = false;
         __builtin_amdgcn_s_barrier();
-        if (grp == 1) __builtin_amdgcn_s_barrier();
+        if (!MRG && grp == 1) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         PP_STAMP(1);
 
         u32x4 af[4][2], wf[4][2];
         int sa = 0;
+        if constexpr (MRG) {
+            // Interval 2t:   group 0 reads the fragments of K-tile t (W, A rows 0-63), group 1 runs the 64 MFMAs of K-tile t - 1;
+            // interval 2t+1: group 0 runs the 64 MFMAs of K-tile t, group 1 reads the fragments of K-tile t.  One barrier ends every interval.
+            // DMA (every wave, whatever its group is doing): at the START of interval 2t  W(t+1) A_hi(t+1) A_lo(t+2)  [their buffers: W(t-1) and
+            // A_lo(t-1) were last read in interval 2t-1, A_hi(t-2) in interval 2t-2];  at the END of interval 2t: A_hi(t) has landed (vmcnt: it
+            // leaves A_lo(t+1) and this interval's pieces in flight);  at the END of interval 2t+1: W(t+1) and A_lo(t+1) have landed (A_hi(t+1),
+            // A_lo(t+2) stay in flight).  The tile head has requested A_lo(1) A_hi(1) A_lo(2) (and W(1) landed with W(0)).
+            auto read_frags = [&](int t, int slot) {
+                const char* sl = smem + slot * 32768;
+                const char* slw = smem + 98304 + (t & 1) * 32768;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) wf[j][ks] = *reinterpret_cast<const u32x4*>(slw + (w_off ^ (ks * 64)) + j * 2048);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 64)) + i * 2048);
+            };
+            auto mfma64 = [&](int slot, bool last = false) {    // K-tile whose A tile sits in `slot`; W and A-lo fragments are in wf / af
+                const char* sl = smem + slot * 32768;
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                u32x4 ah[4][2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) mma16<f16>(acc[i][j], wf[j][ks], af[i][ks]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) ah[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 64)) + (4 + i) * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (last) {
+                    // group 1's last K-tile runs while group 0 is already in its epilogue, which stages through A slots 1 and 2: group 0 waits
+                    // (behind its epilogue's loads) for this barrier = group 1's last LDS read of the ring
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) mma16<f16>(acc[4 + i][j], wf[j][ks], ah[i][ks]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto end_interval = [&]() {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // (one straight-line loop PER GROUP: with the group test inside the loop the accumulators meet in 128 phi nodes at every join and
+            //  the allocator spills hundreds of registers - scratch traffic that would also break the counted vmcnt waits)
+            auto dma_even = [&](int t, int sa1, int sa2) {      // start of interval 2t
+                if (t + 1 < nkt) { issue_w(t + 1); issue_a(t + 1, sa1, 1); }
+                if (t + 2 < nkt) issue_a(t + 2, sa2, 0);
+            };
+            auto wait_even = [&](int t) {                       // end of interval 2t (t >= 1): A_hi(t) has landed
+                if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+                else if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            };
+            auto wait_odd = [&](int t) {                        // end of interval 2t+1: W(t+1), A_lo(t+1) have landed
+                if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                else if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            };
+            if (grp == 0) {
+                for (int t = 0; t < nkt; t++) {
+                    const int sa1 = sa == 2 ? 0 : sa + 1, sa2 = sa == 0 ? 2 : sa - 1;        // slots of K-tiles t+1 and t+2 (= t-1)
+                    if (t >= 1) dma_even(t, sa1, sa2);
+                    read_frags(t, sa);
+                    if (t >= 1) wait_even(t);
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    end_interval();
+                    mfma64(sa);
+                    wait_odd(t);
+                    end_interval();
+                    sa = sa1;
+                }
+            } else {
+                // t = 0: nothing to compute in the even interval
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                end_interval();
+                read_frags(0, 0);
+                wait_odd(0);
+                end_interval();
+                sa = 1;
+                for (int t = 1; t < nkt; t++) {
+                    const int sa1 = sa == 2 ? 0 : sa + 1, sa2 = sa == 0 ? 2 : sa - 1;
+                    dma_even(t, sa1, sa2);
+                    mfma64(sa2);                               // K-tile t - 1
+                    wait_even(t);
+                    end_interval();
+                    read_frags(t, sa);
+                    wait_odd(t);
+                    end_interval();
+                    sa = sa1;
+                }
+                mfma64(sa == 0 ? 2 : sa - 1, true);            // the last K-tile (group 0 is in its epilogue)
+            }
+        } else
         for (int t = 0; t < nkt; t++) {
             const char* sl = smem + sa * 32768;
             const char* slw = smem + 98304 + (t & 1) * 32768;
@@ -787,6 +902,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
         PP_STAMP(2);
         PpEpiPre<EPK, SROWS> pre;
         pp_epi_pre<EPK, SROWS>(g, pre, lane, m0 + wm * 128, n0 + wn * 64);
+        if constexpr (MRG) {
+            if (grp == 0) {                                  // pairs with the barrier inside group 1's last MFMA segment (see mfma64)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         li += wgs_x;
         const bool more = li < cnt;
         PP_STAMP(3);
@@ -829,10 +952,10 @@ static bool pp_persistent_ok(const GemmArgs& g) {
     }
 }
 
-template <int EPK, int SROWS>
+template <int EPK, int SROWS, bool MRG = false>
 static int launch_pp128p(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = 163840;
-    constexpr auto kern = gemm_pp128p_kernel<EPK, SROWS>;
+    constexpr auto kern = gemm_pp128p_kernel<EPK, SROWS, MRG>;
     if (int rc = set_dyn_lds<kern>(smem)) return rc;
     const long ntiles = (long)((g.M + 255) / 256) * (g.N / 256);
     long cap = moge_tune_get("PP_GRID", 0);                  // tests: a small grid makes small problems walk many tiles per workgroup
@@ -883,8 +1006,9 @@ static int launch_pp_cfg(const GemmArgs& g, hipStream_t st) {
 }
 #endif
 
-// Shapes / epilogues the ping-pong kernels take (f16, LINEAR mode only): 256 x 256 tiles of full 128-byte K rows.  Both product kernels
-// (gemm_pp128m16_kernel: 8 waves; gemm_pp4w16_kernel: 4 waves) and the latency-regime kernels of gemm.hip issue v_mfma_f32_16x16x32_f16 over the
+// Shapes / epilogues the ping-pong kernels take (f16, LINEAR mode only): 256 x 256 tiles of full 128-byte K rows.  The product kernels
+// (gemm_pp128p_kernel, persistent, and its one-tile-per-workgroup form gemm_pp128m16_kernel for K < 192: 8 waves each; the 4-wave
+// gemm_pp4w16_kernel is an --experiments build only) and the latency-regime kernels of gemm.hip issue v_mfma_f32_16x16x32_f16 over the
 // same K grouping and share the epilogue arithmetic, so a GEMM's result does not depend on which of them its size selects
 // (tests/test_hip_gemm_pp.py compares them bit for bit, every epilogue flavour).
 bool gemm_pp_eligible(const GemmArgs& g) {
@@ -937,6 +1061,11 @@ static int launch_pp_any(const GemmArgs& g, hipStream_t st) {
     int kern = moge_tune_get("PP_KERN", -1);
     if (kern < 0) kern = 2;
     if (kern == 2 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64>(g, st);
+#ifdef MOGE_EXPERIMENTS
+    // merged MFMA segments (see the kernel): bit-identical, 10-17 % SLOWER on every hot-path shape (profiles/r03r_kbench_gemm_merged_segments.log:
+    // fc2 1117 -> 941, fc1 1023 -> 916, out-proj 1243 -> 1025 TF/s) - tools/kbench A-B builds only
+    if (kern == 3 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64, true>(g, st);
+#endif
 #ifdef MOGE_EXPERIMENTS
     if (kern == 1) return launch_pp4w16<EPK>(g, st);
 #endif

@@ -43,6 +43,15 @@ print('$AB_VAR=$v: %.1f img/s  %.2f ms/step  conv %.2f ms  gemm_pp %.2f  attn %.
                   done
                 done > $out/${tag}_ab_${AB_VAR}.log 2>&1; cat $out/${tag}_ab_${AB_VAR}.log ;;
     tests_conv) timeout 600 python -m pytest tests/test_hip_conv_ex.py tests/test_hip_parity.py -m gpu -q -p no:cacheprovider > $out/${tag}_pytest_conv.log 2>&1; tail -15 $out/${tag}_pytest_conv.log ;;
+    other_cfgs) for a in "--config moge-2-vitb-normal --batch 8" "--config moge-2-vitl-normal" "--shape mixed --config moge-2-vitl-normal" "--num-tokens 1369" "--config moge-2-vits-normal --batch 8"; do
+                  timeout 400 python bench.py $a --steps 10 --warmup 3 --no-cpu-baseline --no-pcie 2>/dev/null | tail -1
+                done > $out/${tag}_bench_other_configs.jsonl; python -c "
+import json
+for l in open('$out/${tag}_bench_other_configs.jsonl'):
+    d = json.loads(l); k = d['kernel_classes']
+    print(d['metric'][:70], '| %.1f img/s %.2f ms/step p50 %.2f | conv %.2f gemm_pp %.2f gemm %.2f attn %.2f post %.2f' % (d['value'], d['ms_per_step'], d['p50_latency_ms_batch1'], k['conv']['ms_per_step'], k['gemm_pp']['ms_per_step'], k['gemm']['ms_per_step'], k['attn']['ms_per_step'], k['post']['ms_per_step']))" ;;
+    kb_gemm_mrg) for f in qkv proj fc1 fc2 outproj tailM; do KB_PP=1 KB_ROUNDS=3 timeout 300 ./tools/kbench gemm $f 10; done > $out/${tag}_kbench_gemm_mrg.log 2>&1; grep -v "^   ts" $out/${tag}_kbench_gemm_mrg.log | grep -v "b1\.\|b4\.\|vits" ;;
+    tests_gemm) MOGE_PP_KERN=${PPK:-3} timeout 600 python -m pytest tests/test_hip_gemm_pp.py -m gpu -q -p no:cacheprovider 2>&1 | tail -5 ;;
     *) echo "unknown step $what" ;;
   esac
 done

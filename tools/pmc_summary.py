@@ -8,7 +8,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 seen = set()
 for r in rows:
-    k = (re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))[:70], int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1))
+    # (template arguments contain ", ": written with ";" so that the summary stays a plain comma-separated table)
+    k = (re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace(", ", ";")[:70], int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1))
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if (r["Dispatch_Id"], ) not in seen:
         seen.add((r["Dispatch_Id"], ))
