@@ -215,6 +215,20 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     // and reloads them from scratch in every K-step - behind vmcnt(0).  l15t is made opaque once per tile so they are recomputed per tap
     // (6 VALU) as in the one-tile-per-workgroup kernel.
     int l15t = l15;
+    // 16x16x32 form: the fragment address of (pixel block i, tap (dy, dx), K-step ks) = abase[dx + 1][ks] + (i + 1 + dy) * HALO_W * 128: three
+    // column shifts x two K-steps per lane, refreshed once per tile; the row part is a compile-time ds_read offset.  (Round 3: the per-tap
+    // recomputation was ~20 VALU in every read segment - issued beside the partner wave's priority-1 MFMAs they cost ~10-20 clocks each and
+    // made the READ segment the longer one: 128-channel K-steps 1780 clocks for 2 x 32 MFMAs.)
+    int abase[3][2];
+    auto set_abase = [&]() {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const int hx = l15t + d;                                       // halo column of tap dx = d - 1
+            const int a = wm * (2 * TM * HALO_W * 128) + hx * 128 + ((g4 ^ (hx & 7)) << 4);
+            abase[d][0] = a; abase[d][1] = a ^ 64;
+        }
+    };
+    if constexpr (M16) set_abase();
     u32x4 sidef[SIDE_REG ? 2 * TM : 1][2];      // SIDE_REG: B fragments of the side map (pixel block i, K-step ks)
     auto kstep = [&](const char* halo, int dy, int dx, bool first_of_image, int image, bool relu, bool from_regs = false) {
         const char* wsl = smem + LDS_W + (kt & 3) * WSLOT;
@@ -230,11 +244,9 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
             } else {
 #pragma unroll
             for (int i = 0; i < 2 * TM; i++) {
-                const int hx = l15t + 1 + dx;
-                const int hp = (wm * 2 * TM + i + 1 + dy) * HALO_W + hx;
-                const int a0 = hp * 128 + ((g4 ^ (hx & 7)) << 4);
 #pragma unroll
-                for (int ks = 0; ks < 2; ks++) af[i >> 1][(i & 1) * 2 + ks] = *reinterpret_cast<const u32x4*>(halo + (a0 ^ (ks * 64)));
+                for (int ks = 0; ks < 2; ks++)
+                    af[i >> 1][(i & 1) * 2 + ks] = *reinterpret_cast<const u32x4*>(halo + abase[dx + 1][ks] + (i + 1 + dy) * (HALO_W * 128));
             }
             }
 #pragma unroll
@@ -326,7 +338,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     bool first = true;
     for (;;) {                                      // ======== one tile per iteration ========
     b = sb; y0 = sy0; x0 = sx0; n0 = sn0;
-    if constexpr (PERSIST) asm volatile("" : "+v"(l15t));
+    if constexpr (PERSIST) { asm volatile("" : "+v"(l15t)); if constexpr (M16) set_abase(); }
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
