@@ -628,8 +628,10 @@ __device__ __forceinline__ void pp_epi_run(const GemmArgs& g, f32x4 (&acc)[8][4]
 // 64-127 of the wave ("hi") are read from LDS INSIDE the segment, into the registers of the "lo" fragments as those die, so the register
 // count does not change.  The DMA schedule is then tied to the global intervals (both groups issue at the start of an even interval - group 0
 // is in its read segment, group 1 in its MFMA segment - and wait at the interval ends), see the loop.
-template <int EPK, int SROWS, bool MRG>
+template <int EPK, int SROWS, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
+    constexpr bool MRG = MODE == 1;
+    constexpr bool WDMA_M = MODE == 2;         // W(t+2) requested at the head of the SECOND MFMA segment of K-tile t instead of in the read segment in front of it
     constexpr int WN = 4, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * 32 KiB (A ring) + 2 * 32 KiB (W ring)
 
@@ -868,6 +870,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
                     if (t + 2 < nkt) issue_a(t + 2, sa2, 1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 } else {
+                    if constexpr (WDMA_M) {
+                        // queue (oldest first): A_lo(t+2) | W(t+1) [head of M_b(t-1)] | A_hi(t+2) [L_a(t)] | A_lo(t+3) [here]: W(t+1) must have landed
+                        if (t + 3 < nkt) { issue_a(t + 3, sa, 0); asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
+                        else if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    } else
                     if (t + 3 < nkt) {
                         issue_w(t + 2);
                         issue_a(t + 3, sa, 0);
@@ -883,6 +891,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
+                if constexpr (WDMA_M) {
+                    if (half == 1 && t + 2 < nkt) issue_w(t + 2);          // W(t)'s slot: read by both groups in their L_a(t), two barriers ago at the latest
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++)
 #pragma unroll
@@ -952,10 +964,10 @@ static bool pp_persistent_ok(const GemmArgs& g) {
     }
 }
 
-template <int EPK, int SROWS, bool MRG = false>
+template <int EPK, int SROWS, int MODE = 0>
 static int launch_pp128p(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = 163840;
-    constexpr auto kern = gemm_pp128p_kernel<EPK, SROWS, MRG>;
+    constexpr auto kern = gemm_pp128p_kernel<EPK, SROWS, MODE>;
     if (int rc = set_dyn_lds<kern>(smem)) return rc;
     const long ntiles = (long)((g.M + 255) / 256) * (g.N / 256);
     long cap = moge_tune_get("PP_GRID", 0);                  // tests: a small grid makes small problems walk many tiles per workgroup
@@ -1064,7 +1076,10 @@ static int launch_pp_any(const GemmArgs& g, hipStream_t st) {
 #ifdef MOGE_EXPERIMENTS
     // merged MFMA segments (see the kernel): bit-identical, 10-17 % SLOWER on every hot-path shape (profiles/r03r_kbench_gemm_merged_segments.log:
     // fc2 1117 -> 941, fc1 1023 -> 916, out-proj 1243 -> 1025 TF/s) - tools/kbench A-B builds only
-    if (kern == 3 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64, true>(g, st);
+    if (kern == 3 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64, 1>(g, st);
+    // W(t+2) requested at the head of the second MFMA segment instead of in the read segment (LDS-DMA issue is cheaper among MFMAs, cdna guide
+    // constants): bit-identical, 0.5-3 % slower (profiles/r03u_kbench_gemm_wdma_in_mfma_segment.log: out-proj 1270 -> 1217, fc1 1043 -> 1028 TF/s)
+    if (kern == 4 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64, 2>(g, st);
 #endif
 #ifdef MOGE_EXPERIMENTS
     if (kern == 1) return launch_pp4w16<EPK>(g, st);
