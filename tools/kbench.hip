@@ -163,7 +163,8 @@ static int bench_gemm(const char* filter, int iters) {
     if (getenv("KB_EXP")) variants = {{"pp128-m16", 1, 2, 0, 0, 0}, {"pp4w-16", 1, 2, 0, 1, 0}, {"x:pp128-a3", 1, 2, 0, 0, 1}, {"x:pp128-a3c", 1, 2, 0, 0, 2}, {"x:pp128-2buf", 1, 2, 0, 0, 3},
                                       {"x:pp4w-32", 1, 2, 0, 0, 4}, {"x:pp64", 1, 2, 0, 0, 5}, {"x:pp64-2wg", 1, 2, 0, 0, 6}};
     if (getenv("KB_GC")) variants = {{"pp128p", 1, 2, 0, 2, 0}, {"pp128p gc2", 1, 2, 2, 2, 0}, {"pp128p gc8", 1, 2, 8, 2, 0}, {"pp128p gc16", 1, 2, 16, 2, 0}};
-    if (getenv("KB_PP")) variants = {{"pp128-m16", 1, 2, 0, 0, 0}, {"pp128p", 1, 2, 0, 2, 0}, {"pp128p-wm", 1, 2, 0, 4, 0}};
+    if (getenv("KB_PP")) variants = {{"pp128-m16", 1, 2, 0, 0, 0}, {"pp128p", 1, 2, 0, 2, 0}};
+    if (getenv("KB_PPX")) variants = {{"pp128p", 1, 2, 0, 2, 0}, {"x:pp128p-mrg", 1, 2, 0, 3, 0}, {"x:pp128p-wm", 1, 2, 0, 4, 0}};      // --experiments builds
     int fails = 0;
     for (const Shape& s : shapes) {
         if (filter && !strstr(s.name, filter)) continue;
