@@ -104,3 +104,40 @@ def test_master_blob_file_header_roundtrip_and_rejects_foreign_files(tmp_path):
     q.write_bytes(b"not a blob at all")
     with pytest.raises(ValueError):
         MoGeModel.from_blob(q)
+
+
+def test_master_blob_records_the_model_version(tmp_path):
+    """A MoGe-1 blob (same container, moge_amd/model/v1.py) must not load as MoGe-2 and vice versa: read_blob_header raises ValueError, which
+    from_pretrained's sidecar path turns into a fall-back to the checkpoint.  Blobs written before the field existed are MoGe-2 blobs."""
+    import json
+    import numpy as np
+    from moge_amd.model.v1 import MoGeModel as V1
+    from moge_amd.model.v2 import MoGeModel as V2
+    from oracle import moge_oracle as O
+
+    def write(path, header):
+        hb = json.dumps(header).encode()
+        with open(path, "wb") as f:
+            f.write(V2.BLOB_MAGIC)
+            f.write(len(hb).to_bytes(8, "little"))
+            f.write(hb)
+            f.write(b"\0" * ((-f.tell()) % 4096))
+            np.zeros(16, dtype=np.float32).tofile(f)
+
+    cfg = O.named_configs()["tiny-vits-normal"]
+    p2, p1, p0 = tmp_path / "v2.blob", tmp_path / "v1.blob", tmp_path / "old.blob"
+    write(p2, {"model_version": "v2", "model_config": cfg, "nbytes": 64})
+    write(p1, {"model_version": "v1", "model_config": {"encoder": "dinov2_vits14"}, "nbytes": 64})
+    write(p0, {"model_config": cfg, "nbytes": 64})
+    assert V2.read_blob_header(p2)[0]["model_version"] == "v2" and V1.read_blob_header(p1)[0]["model_version"] == "v1"
+    V2.read_blob_header(p0)                                   # legacy header = MoGe-2
+    for cls, path in ((V2, p1), (V1, p2), (V1, p0)):
+        with pytest.raises(ValueError):
+            cls.read_blob_header(path)
+
+
+def test_v1_rejects_upsample_widths_the_groupnorm_kernels_cannot_run():
+    """dim_upsample entries must be 32 / 64 / 128 / 256 / 512 (gn_partial's slabs): rejected at construction, not at the first forward."""
+    from moge_amd.model.v1 import MoGeModel as V1
+    with pytest.raises(NotImplementedError):
+        V1(encoder="dinov2_vits14", dim_upsample=[256, 96, 128])
