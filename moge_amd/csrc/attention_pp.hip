@@ -549,6 +549,14 @@ __global__ __launch_bounds__(256, QB > 2 ? 2 : 3) void attn_pp16mq_kernel(const 
     for (int i = 0; i < 4; i++) ones[i] = 0x3c003c00u;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    // A wave whose queries all lie beyond the sequence (the last workgroup of a head: N = 3601 leaves 17 queries for it, i.e. one wave of four)
+    // only keeps the workgroup's DMA ring and barriers going - exactly one barrier per tile, like every other path - and leaves: the wave
+    // with the real queries has its SIMD to itself and the workgroup frees its slot sooner (its three idle waves used to redo a clamped
+    // copy of query N - 1 at full cost).
+    if (__builtin_amdgcn_readfirstlane(q0) >= Ntok) {
+        for (int tt = 0; tt < ntiles; tt++) tile_head(tt);
+        return;
+    }
     tile_head(0);
 #pragma unroll
     for (int qb = 0; qb < QB; qb++) exact_block(0, ntiles == 1, qb);
