@@ -27,9 +27,11 @@ def _worker(rank, world, port, ckpt, q):
     mine = list(shard_batch(6, world, rank))
     model.half()
     out = model.infer(x[mine], num_tokens=108)
-    res = {k: v.cpu() for k, v in out.items()}
+    # numpy arrays travel through the queue BY VALUE; torch tensors would be handed over as file descriptors that the parent can only
+    # fetch while this process is still alive (a worker that finishes first made the test fail with EOFError in rebuild_storage_fd)
+    res = {k: v.cpu().numpy() for k, v in out.items()}
     if rank == 0:
-        full = {k: v.cpu() for k, v in model.infer(x, num_tokens=108).items()}      # what one process computes for the whole batch
+        full = {k: v.cpu().numpy() for k, v in model.infer(x, num_tokens=108).items()}      # what one process computes for the whole batch
         q.put(("full", full))
     q.put((rank, mine, res))
     dist.barrier()
@@ -54,8 +56,8 @@ def test_real_model_blob_broadcast_and_sharded_infer_world2(tmp_path):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    full = next(g[1] for g in got if g[0] == "full")
-    shards = [g for g in got if g[0] != "full"]
+    full = {k: torch.from_numpy(v) for k, v in next(g[1] for g in got if g[0] == "full").items()}
+    shards = [(g[0], g[1], {k: torch.from_numpy(v) for k, v in g[2].items()}) for g in got if g[0] != "full"]
     assert sorted(i for _, mine, _ in shards for i in mine) == list(range(6))
     for rank, mine, res in shards:
         for k, v in res.items():
