@@ -52,6 +52,12 @@ for l in open('$out/${tag}_bench_other_configs.jsonl'):
     print(d['metric'][:70], '| %.1f img/s %.2f ms/step p50 %.2f | conv %.2f gemm_pp %.2f gemm %.2f attn %.2f post %.2f' % (d['value'], d['ms_per_step'], d['p50_latency_ms_batch1'], k['conv']['ms_per_step'], k['gemm_pp']['ms_per_step'], k['gemm']['ms_per_step'], k['attn']['ms_per_step'], k['post']['ms_per_step']))" ;;
     kb_gemm_mrg) for f in qkv proj fc1 fc2 outproj tailM; do KB_PP=1 KB_ROUNDS=3 timeout 300 ./tools/kbench gemm $f 10; done > $out/${tag}_kbench_gemm_mrg.log 2>&1; grep -v "^   ts" $out/${tag}_kbench_gemm_mrg.log | grep -v "b1\.\|b4\.\|vits" ;;
     tests_gemm) MOGE_PP_KERN=${PPK:-3} timeout 600 python -m pytest tests/test_hip_gemm_pp.py -m gpu -q -p no:cacheprovider 2>&1 | tail -5 ;;
+    batch_sweep) for r in 1 2; do for b in ${BATCHES:-32 36 18 27}; do
+                  timeout 400 python bench.py --batch $b --steps 8 --warmup 3 --no-cpu-baseline --no-pcie 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline()); k = d['kernel_classes']
+print('batch $b: %.1f img/s  %.2f ms/step  (kernel sum single-stream %.2f ms: gemm_pp %.2f attn %.2f conv %.2f)' % (d['value'], d['ms_per_step'], d['whole_path']['kernel_ms_per_step'], k['gemm_pp']['ms_per_step'], k['attn']['ms_per_step'], k['conv']['ms_per_step']))"
+                done; done > $out/${tag}_batch_sweep.log 2>&1; cat $out/${tag}_batch_sweep.log ;;
     *) echo "unknown step $what" ;;
   esac
 done
