@@ -644,7 +644,7 @@ static int launch_attn_pp16(const void* q, const void* k, const void* v, void* o
     const int akern = moge_tune_get("ATTN_KERN", AP_KERN_DEFAULT);
     if (akern >= 1) {
         const long wgs4 = (long)((Ntok + 255) / 256) * B * nh;
-        const bool q4 = akern == 2 || (akern == 3 && wgs4 >= moge_tune_get("ATTN_Q4_MIN_WGS", 1536));
+        const bool q4 = akern == 2 || (akern == 3 && wgs4 >= moge_tune_get("ATTN_Q4_MIN_WGS", 640));
         const int xr = moge_tune_get("ATTN_XCD", 1);
         if (q4) {
             if (int rc = set_dyn_lds<attn_pp16mq_kernel<4>>(smem)) return rc;

@@ -36,12 +36,12 @@ print('conv forms $v: %.1f img/s  %.2f ms/step  conv %.2f ms  gemm_pp %.2f  attn
     ab)         # same box, alternating: MOGE_$AB_VAR = 0 / 1 (e.g. AB_VAR=L4DOT)
                 for r in 1 2; do
                   for v in ${AB_VALS:-0 1}; do
-                    env MOGE_${AB_VAR}=$v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pcie 2>/dev/null | python -c "
+                    env MOGE_${AB_VAR}=$v timeout 300 python bench.py ${BENCH_ARGS} --steps 10 --warmup 3 --no-cpu-baseline --no-pcie 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline()); k = d['kernel_classes']
 print('$AB_VAR=$v: %.1f img/s  %.2f ms/step  conv %.2f ms  gemm_pp %.2f  attn %.2f  post %.2f  norm %.2f' % (d['value'], d['ms_per_step'], k['conv']['ms_per_step'], k['gemm_pp']['ms_per_step'], k['attn']['ms_per_step'], k['post']['ms_per_step'], k['norm']['ms_per_step']))"
                   done
-                done > $out/${tag}_ab_${AB_VAR}.log 2>&1; cat $out/${tag}_ab_${AB_VAR}.log ;;
+                done > $out/${tag}_ab_${AB_VAR}${AB_SUFFIX}.log 2>&1; cat $out/${tag}_ab_${AB_VAR}${AB_SUFFIX}.log ;;
     tests_conv) timeout 600 python -m pytest tests/test_hip_conv_ex.py tests/test_hip_parity.py -m gpu -q -p no:cacheprovider > $out/${tag}_pytest_conv.log 2>&1; tail -15 $out/${tag}_pytest_conv.log ;;
     other_cfgs) for a in "--config moge-2-vitb-normal --batch 8" "--config moge-2-vitl-normal" "--shape mixed --config moge-2-vitl-normal" "--num-tokens 1369" "--config moge-2-vits-normal --batch 8"; do
                   timeout 400 python bench.py $a --steps 10 --warmup 3 --no-cpu-baseline --no-pcie 2>/dev/null | tail -1
@@ -58,6 +58,9 @@ import sys, json
 d = json.loads(sys.stdin.readline()); k = d['kernel_classes']
 print('batch $b: %.1f img/s  %.2f ms/step  (kernel sum single-stream %.2f ms: gemm_pp %.2f attn %.2f conv %.2f)' % (d['value'], d['ms_per_step'], d['whole_path']['kernel_ms_per_step'], k['gemm_pp']['ms_per_step'], k['attn']['ms_per_step'], k['conv']['ms_per_step']))"
                 done; done > $out/${tag}_batch_sweep.log 2>&1; cat $out/${tag}_batch_sweep.log ;;
+    tests_mp)   timeout 600 python -m pytest tests/test_hip_multiproc.py -m gpu -q -p no:cacheprovider 2>&1 | tail -5 ;;
+    ab_q4)      for cfg in "vitb8:--config moge-2-vitb-normal --batch 8" "vitl8:--batch 8" "vitl4:--batch 4" "vitl16:--batch 16"; do
+                  echo "== ${cfg%%:*}"; AB_SUFFIX=_${cfg%%:*} BENCH_ARGS="${cfg#*:}" AB_VAR=ATTN_Q4_MIN_WGS AB_VALS="640 1536" bash tools/gpu_call.sh $tag ab; done ;;
     *) echo "unknown step $what" ;;
   esac
 done
