@@ -499,19 +499,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
             __syncthreads();          // drains the DMA (vmcnt(0)) and orders it against the next slab's reads
         }
     } else {
-        // 3-slab ring, DMA two slabs ahead, ONE raw barrier per slab and a COUNTED vmcnt so the newest slab's loads stay in
+        // NSTAGE-slab ring, DMA NSTAGE - 1 slabs ahead, ONE raw barrier per slab and a COUNTED vmcnt so the younger slabs' loads stay in
         // flight across the barrier (a __syncthreads() here would drain them: LDS-DMA counts as a pending LDS write).
         constexpr int G = A_IT + W_IT;           // DMA instructions per thread per slab
-        issue(0, 0);
-        if (nkt > 1) issue(1, 1);
-        int cur = 0;
+        constexpr int AHEAD = NSTAGE - 1;
+        static_assert(G * (AHEAD - 1) <= 63, "vmcnt field");
+#pragma unroll
+        for (int s = 0; s < AHEAD; s++)
+            if (s < nkt) issue(s, s);
+        int cur = 0, nxt = AHEAD;                // slab kt lives in buffer kt % NSTAGE
         for (int kt = 0; kt < nkt; kt++) {
-            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+            const int younger = nkt - 1 - kt;    // slabs issued after slab kt (capped at AHEAD - 1)
+            if (younger >= AHEAD - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (AHEAD - 1)) : "memory");
+            else if (AHEAD > 2 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * 2) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();        // slab kt landed for every wave; every wave is done reading slab kt-1
-            if (kt + 2 < nkt) issue(kt + 2, cur == 0 ? 2 : cur - 1);
+            if (kt + AHEAD < nkt) issue(kt + AHEAD, nxt);
             compute(cur);
-            cur = cur == 2 ? 0 : cur + 1;
+            cur = cur == NSTAGE - 1 ? 0 : cur + 1;
+            nxt = nxt == NSTAGE - 1 ? 0 : nxt + 1;
         }
     }
     if constexpr (M16) {
@@ -619,11 +626,18 @@ int launch_gemm(const GemmArgs& g, int amode, hipStream_t st) {
             // latency regime: when 128x128 tiles do not even give every CU two workgroups, halve the tile rows (64x128, 48 KiB LDS: up to three
             // co-resident workgroups per CU hide each other's DMA / LDS latency).  Same MFMA and K order: results are bit-identical.
             const long blocks128 = ((long)(g.M + 127) / 128) * ((g.N + 127) / 128);
-            if (blocks128 < moge_tune_get("GLDS_SMALL_BLOCKS", 512) && moge_tune_get("GLDS_VARIANT", 2) == 2) return launch_glds<T, 2, 2, 1, 2, 2>(g, st);
+            if (blocks128 < moge_tune_get("GLDS_SMALL_BLOCKS", 512) && moge_tune_get("GLDS_VARIANT", 2) == 2) {
+                switch (moge_tune_get("GLDS_SMALL_NS", 2)) {            // ring depth of the 64x128 kernel (bit-identical results)
+                case 3: return launch_glds<T, 2, 2, 1, 2, 3>(g, st);
+                case 4: return launch_glds<T, 2, 2, 1, 2, 4>(g, st);
+                default: return launch_glds<T, 2, 2, 1, 2, 2>(g, st);
+                }
+            }
             switch (moge_tune_get("GLDS_VARIANT", 2)) {
             case 1: return launch_glds<T, 2, 2, 2, 2, 1>(g, st);       // 128x128, single buffer
             case 2: return launch_glds<T, 2, 2, 2, 2, 2>(g, st);       // 128x128, double buffer
             case 4: return launch_glds<T, 2, 2, 2, 2, 3>(g, st);       // 128x128, 3-slab ring
+            case 5: return launch_glds<T, 2, 2, 2, 2, 4>(g, st);       // 128x128, 4-slab ring
             default: return launch_glds<T, 4, 2, 2, 2, 3>(g, st);      // 256x128, 8 waves, 3-slab ring
             }
         }

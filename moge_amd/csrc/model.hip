@@ -84,6 +84,10 @@ struct moge_handle {
     static constexpr int MAX_SPLIT = 4;
     hipStream_t split_st[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
+    // head streams (small batches): after the neck the decoder heads are independent and their launches do not fill the chip; heads 1, 2
+    // of (sub-)batch `slot` run on head_st[slot][0 / 1] with their own scratch buffers, head 0 stays on the (sub-)batch's stream
+    hipStream_t head_st[MAX_SPLIT][2] = {};
+    hipEvent_t ev_neck[MAX_SPLIT] = {}, ev_head[MAX_SPLIT][2] = {};
     float img_mean[3] = {0.485f, 0.456f, 0.406f}, img_std[3] = {0.229f, 0.224f, 0.225f};   // refreshed from the checkpoint buffers
     // profiler
     bool prof_on = false;
@@ -409,7 +413,9 @@ static int pack_weights(moge_handle* h, hipStream_t st) {
 struct Plan {
     size_t total = 0;
     size_t base = 0;          // byte offset of this plan inside the workspace arena (batch-split mode places two plans side by side)
-    size_t patches, x, xn, q, k, vT, attn, hidden, tapcat, cls, mlp1, mlp2, metric, feat, neck[MOGE_LEVELS], scratch[3];
+    size_t patches, x, xn, q, k, vT, attn, hidden, tapcat, cls, mlp1, mlp2, metric, feat, neck[MOGE_LEVELS], scratch[9];
+    int head_sets = 1;        // scratch triples: one per decoder head when the heads run on their own streams (small batches), else 1
+    int slot = 0;             // index of this (sub-)batch among the batch-split parts (selects the head streams)
     size_t ln_part, ln_mr;    // LN fold: (sum, sum of squares) per row and 32-column group; (mean, rstd) per row
     size_t maskprob, focal, shift, intr, pts_tmp, nrm_tmp, post_end;
     int B, H, W, rows, cols, Np, Ntok, Npad;
@@ -459,7 +465,10 @@ static Plan make_plan(const moge_config& c, int prec, int B, int H, int W, int r
         if (e > mx) mx = e;
     }
     p.scratch_elems = mx;
-    for (int i = 0; i < 3; i++) p.scratch[i] = take(p, mx * s);
+    int nheads = 0;
+    for (int k = 0; k < 3; k++) nheads += (c.heads & HEAD_BITS[k]) ? 1 : 0;
+    p.head_sets = (nheads > 1 && moge_tune_get("HEAD_STREAMS", 1) != 0 && B <= moge_tune_get("HEAD_STREAMS_MAX_B", 1)) ? nheads : 1;
+    for (int i = 0; i < 3 * p.head_sets; i++) p.scratch[i] = take(p, mx * s);
     return p;
 }
 static size_t forward_ws_bytes(moge_handle* h, const Plan& pl);
@@ -838,11 +847,34 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     // ---- heads -------------------------------------------------------------------------------------------------------
     float* outs[3] = {o_points, o_normal, o_maskprob};
     const bool fuse_l4 = std::is_same<T, f16>::value && c.head_res_blocks[MOGE_LEVELS - 1] == 0 && moge_tune_get("FUSE_L4", 1) != 0;
+    // small batches: every head after the first on its own stream and scratch triple (same kernels: bit-identical); not under the profiler,
+    // whose events bracket launches on ONE stream
+    const bool par_heads = pl.head_sets > 1 && !h->prof_on;
+    hipStream_t st_main = st;
+    int forked = 0;
+    if (par_heads) {
+        if (!h->ev_neck[pl.slot]) HIPCHK(hipEventCreateWithFlags(&h->ev_neck[pl.slot], hipEventDisableTiming));
+        HIPCHK(hipEventRecord(h->ev_neck[pl.slot], st_main));
+    }
     for (int k = 0; k < 3; k++) {
         if (!(c.heads & HEAD_BITS[k]) || !outs[k]) continue;
         const std::string name = HEAD_NAMES[k];
         int head_idx = 0;                  // this head's group in the neck's fused-output-conv table: its position among the model's heads
         for (int k2 = 0; k2 < k; k2++) head_idx += (c.heads & HEAD_BITS[k2]) ? 1 : 0;
+        if (par_heads && head_idx > 0) {
+            hipStream_t& hs = h->head_st[pl.slot][head_idx - 1];
+            if (!hs) {
+                HIPCHK(hipStreamCreateWithFlags(&hs, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&h->ev_head[pl.slot][head_idx - 1], hipEventDisableTiming));
+            }
+            HIPCHK(hipStreamWaitEvent(hs, h->ev_neck[pl.slot], 0));
+            st = hs;
+            for (int i = 0; i < 3; i++) Sc[i] = (T*)(ws + pl.scratch[3 * head_idx + i]);
+            forked |= 1 << (head_idx - 1);
+        } else {
+            st = st_main;
+            for (int i = 0; i < 3; i++) Sc[i] = (T*)(ws + pl.scratch[i]);
+        }
         int cur = 0;                       // Sc[cur] holds the running x
         CHK(conv1x1<T>(h, N[0], P<T>(h, name + ".in0.w"), M(h, name + ".input_blocks.0.bias"), Sc[cur], BP, c0, c0, nullptr, nullptr, cols, rows, st));
         CHK(res_blocks<T>(h, name, 0, c.head_res_blocks[0], Sc[cur], Sc[(cur + 1) % 3], B, rows, cols, c0, st));
@@ -903,6 +935,12 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
                                           rows << 4, cols << 4, c.dims[4], pl.H, pl.W, c.remap_output, st));
         }
     }
+    st = st_main;
+    for (int i = 0; i < 2; i++)
+        if (forked & (1 << i)) {
+            HIPCHK(hipEventRecord(h->ev_head[pl.slot][i], h->head_st[pl.slot][i]));
+            HIPCHK(hipStreamWaitEvent(st_main, h->ev_head[pl.slot][i], 0));
+        }
     // remember buffers for debug taps
     h->last.valid = true; h->last.prec = TT<T>::PREC; h->last.B = B; h->last.rows = rows; h->last.cols = cols;
     h->last.bufs.clear();
@@ -1208,6 +1246,10 @@ void moge_destroy(moge_handle* h) {
     if (h->d_status) hipFree(h->d_status);
     for (int i = 0; i < moge_handle::MAX_SPLIT; i++) { if (h->split_st[i]) hipStreamDestroy(h->split_st[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    for (int i = 0; i < moge_handle::MAX_SPLIT; i++) {
+        if (h->ev_neck[i]) hipEventDestroy(h->ev_neck[i]);
+        for (int k = 0; k < 2; k++) { if (h->head_st[i][k]) hipStreamDestroy(h->head_st[i][k]); if (h->ev_head[i][k]) hipEventDestroy(h->ev_head[i][k]); }
+    }
     for (auto& r : h->prof_pending) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (auto e : h->ev_pool) hipEventDestroy(e);
     delete h;
@@ -1339,6 +1381,7 @@ static int forward_dispatch(moge_handle* h, const void* image, int img_dtype, co
         const int b1 = (int)((long)B * (i + 1) / n);
         sub[i] = make_plan(h->cfg, h->prec, b1 - b0s[i], pl.H, pl.W, pl.rows, pl.cols);
         sub[i].base = off;
+        sub[i].slot = i;
         off += sub[i].total;
     }
     CHK(ensure_ws(h, off));

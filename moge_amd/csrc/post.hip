@@ -314,10 +314,13 @@ int launch_mlp_layer(const float* in, const float* W, const float* bias, float* 
 // ------------------------------------------------------------------------------------------------------------
 // recovery
 // ------------------------------------------------------------------------------------------------------------
-#define REC_PTS 16      // 4096 sample points / 256 threads
+#define REC_THREADS 1024
+#define REC_PTS 4       // 4096 sample points / 1024 threads (batch-1 latency: the solver is a chain of ~30 block reductions over fp64 divisions;
+                        // 16 waves shorten every link 4 x against the 4-wave form: 168 -> ~50 us)
 
 template <int NV>
 __device__ __forceinline__ void block_sum(double* v, double* sh) {
+    constexpr int NW = REC_THREADS / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < NV; j++) {
@@ -328,7 +331,16 @@ __device__ __forceinline__ void block_sum(double* v, double* sh) {
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NV; j++) v[j] = ((sh[j] + sh[NV + j]) + sh[2 * NV + j]) + sh[3 * NV + j];
+    for (int j = 0; j < NV; j++) {
+        double t[4];                       // fixed tree: four chains of NW / 4 waves, then ((t0 + t1) + t2) + t3
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            t[q] = sh[(q * (NW / 4)) * NV + j];
+#pragma unroll
+            for (int w = 1; w < NW / 4; w++) t[q] += sh[(q * (NW / 4) + w) * NV + j];
+        }
+        v[j] = ((t[0] + t[1]) + t[2]) + t[3];
+    }
     __syncthreads();
 }
 
@@ -404,16 +416,17 @@ __device__ void lmpar1(double r, double diag, double qtb, double delta, double& 
 //   points (B,H,W,3) fp32; validity from mask_prob (>0.5f) or mask_u8 (!=0) or all-valid if both null
 //   fov_deg: null -> solve focal and shift; else focal fixed from fov_x (v2.py:261-263)
 //   focal_in: optional explicit focal (test entry point)
-__global__ __launch_bounds__(256) void recover_kernel(const float* __restrict__ points, const float* __restrict__ mask_prob,
+__global__ __launch_bounds__(REC_THREADS) void recover_kernel(const float* __restrict__ points, const float* __restrict__ mask_prob,
                                                       const uint8_t* __restrict__ mask_u8, const float* __restrict__ fov_deg,
                                                       const float* __restrict__ focal_in, int H, int W,
                                                       float u0, float u1, float ustep, float v0, float v1, float vstep,
                                                       float fov_c, float fx_mul, float fx_div, float fy_mul, float mask_thr,
                                                       float* __restrict__ focal_out, float* __restrict__ shift_out,
                                                       float* __restrict__ intrinsics, int* __restrict__ status) {
-    __shared__ double sh[4 * 8];
+    constexpr int NW = REC_THREADS / 64;
+    __shared__ double sh[NW * 2];
     __shared__ double sh0[2];
-    __shared__ int shi[4];
+    __shared__ int shi[NW];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* pts = points + (size_t)b * H * W * 3;
     RecPts P;
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(256) void recover_kernel(const float* __restrict__ 
     int first = 1 << 30, count = 0;
 #pragma unroll
     for (int i = 0; i < REC_PTS; i++) {
-        const int s = tid + 256 * i;                   // raster index in the 64x64 grid
+        const int s = tid + REC_THREADS * i;           // raster index in the 64x64 grid
         const int gy = s >> 6, gx = s & 63;
         const int sy = (int)(((long)gy * H) >> 6), sx = (int)(((long)gx * W) >> 6);   // nearest: floor(dst*in/64)
         const size_t pix = (size_t)sy * W + sx;
@@ -437,19 +450,22 @@ __global__ __launch_bounds__(256) void recover_kernel(const float* __restrict__ 
     for (int off = 32; off > 0; off >>= 1) { count += __shfl_xor(count, off); const int o = __shfl_xor(first, off); first = o < first ? o : first; }
     if ((tid & 63) == 0) { shi[tid >> 6] = count; }
     __syncthreads();
-    count = shi[0] + shi[1] + shi[2] + shi[3];
+    count = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) count += shi[w];
     __syncthreads();
     if ((tid & 63) == 0) shi[tid >> 6] = first;
     __syncthreads();
-    first = min(min(shi[0], shi[1]), min(shi[2], shi[3]));
+#pragma unroll
+    for (int w = 0; w < NW; w++) first = min(first, shi[w]);
     __syncthreads();
     const bool fixed = (fov_deg != nullptr) || (focal_in != nullptr);
     float focal_f = 1.f;
     if (focal_in) focal_f = focal_in[b];
     else if (fov_deg) focal_f = fov_c / tanf((fov_deg[b] / 2.f) * 0.017453292519943295f);
     const double focal_fixed = (double)focal_f;
-    const bool own_first = (first & 255) == tid;
-    const int first_slot = first >> 8;
+    const bool own_first = (first % REC_THREADS) == tid;
+    const int first_slot = first / REC_THREADS;
 
     float shift_res = 0.f, focal_res = fixed ? focal_f : 1.f;
     int st = 0;
@@ -485,6 +501,7 @@ __global__ __launch_bounds__(256) void recover_kernel(const float* __restrict__ 
             nfev++;
             const double xh = x + h;
             red[0] = 0.0;
+            double c_rx[REC_PTS], c_ry[REC_PTS], c_jx[REC_PTS], c_jy[REC_PTS];     // residuals and Jacobian column of this thread's points: reused by the Householder pass below
 #pragma unroll
             for (int i = 0; i < REC_PTS; i++)
                 if (P.valid >> i & 1) {
@@ -492,6 +509,7 @@ __global__ __launch_bounds__(256) void recover_kernel(const float* __restrict__ 
                     const double rx = f_cur * ((double)P.x[i] / d) - (double)P.u[i], ry = f_cur * ((double)P.y[i] / d) - (double)P.v[i];
                     const double hx = f_h * ((double)P.x[i] / dh) - (double)P.u[i], hy = f_h * ((double)P.y[i] / dh) - (double)P.v[i];
                     const double jx = (hx - rx) / h, jy = (hy - ry) / h;
+                    c_rx[i] = rx; c_ry[i] = ry; c_jx[i] = jx; c_jy[i] = jy;
                     red[0] += jx * jx + jy * jy;
                     if (own_first && i == first_slot) { sh0[0] = jx; sh0[1] = rx; }
                 }
@@ -505,12 +523,9 @@ __global__ __launch_bounds__(256) void recover_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int i = 0; i < REC_PTS; i++)
                     if (P.valid >> i & 1) {
-                        const double d = (double)P.z[i] + x, dh = (double)P.z[i] + xh;
-                        const double rx = f_cur * ((double)P.x[i] / d) - (double)P.u[i], ry = f_cur * ((double)P.y[i] / d) - (double)P.v[i];
-                        const double hx = f_h * ((double)P.x[i] / dh) - (double)P.u[i], hy = f_h * ((double)P.y[i] / dh) - (double)P.v[i];
-                        double vx = ((hx - rx) / h) / ajnorm;
+                        double vx = c_jx[i] / ajnorm;
                         if (own_first && i == first_slot) vx += 1.0;
-                        red[0] += vx * rx + (((hy - ry) / h) / ajnorm) * ry;
+                        red[0] += vx * c_rx[i] + (c_jy[i] / ajnorm) * c_ry[i];
                     }
                 block_sum<1>(red, sh);
                 r = -ajnorm;
@@ -614,7 +629,7 @@ int launch_recover(const float* points, const float* mask_prob, const uint8_t* m
     const float ustep = W > 1 ? (u1 - u0) / (float)(W - 1) : 0.f, vstep = H > 1 ? (v1 - v0) / (float)(H - 1) : 0.f;
     const float fov_c = (float)(a / sqrt(1 + a * a));
     const float diag = (float)sqrt(1 + a * a);
-    hipLaunchKernelGGL(recover_kernel, dim3(B), dim3(256), 0, st, points, mask_prob, mask_u8, fov_deg, focal_in, H, W, u0, u1, ustep, v0, v1,
+    hipLaunchKernelGGL(recover_kernel, dim3(B), dim3(REC_THREADS), 0, st, points, mask_prob, mask_u8, fov_deg, focal_in, H, W, u0, u1, ustep, v0, v1,
                        vstep, fov_c, diag, (float)a, diag, mask_thr, focal, shift, intrinsics, status);
     return (int)hipGetLastError();
 }

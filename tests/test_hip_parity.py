@@ -247,6 +247,33 @@ def test_batch_split_streams_are_bit_identical(MoGeModel, tmp_path_factory):
         model.float()
 
 
+def test_head_streams_are_bit_identical(MoGeModel, tmp_path_factory):
+    """Small batches run the decoder heads after the first on their own streams and scratch buffers (model.hip forward_impl,
+    HEAD_STREAMS); same kernels on the same inputs: the result must equal the one-stream result, alone and inside a split batch."""
+    from moge_amd import _lib as L
+    model, cfg, sd = get_model(MoGeModel, "tiny-vits-normal", 0, True, tmp_path_factory)
+    try:
+        for B in (1, 3, 9):
+            x = torch.rand(B, 3, 84, 112, generator=torch.Generator().manual_seed(11 + B))
+            for half in (False, True):
+                model.half() if half else model.float()
+                L.tune("HEAD_STREAMS", 0)
+                ref = model.infer(x, num_tokens=108)
+                L.tune("HEAD_STREAMS", 1)
+                for _ in range(2):                      # twice: the second call reuses streams, events and scratch of the first
+                    out = model.infer(x, num_tokens=108)
+                    for k in ref:
+                        a, b = out[k], ref[k]
+                        if a.dtype == torch.bool:
+                            assert torch.equal(a, b), k
+                        else:
+                            fin = torch.isfinite(b)
+                            assert torch.equal(fin, torch.isfinite(a)) and torch.equal(a[fin], b[fin]), f"{k}: head streams != one stream (B={B}, half={half})"
+    finally:
+        L.tune("HEAD_STREAMS", 1)
+        model.float()
+
+
 def test_eval_plugin_runs_through_the_click_loader(tmp_path_factory):
     """the reference's harness does `Baseline.load.main(args, standalone_mode=False)` then
     `infer_for_evaluation(image, intrinsics)` (moge/scripts/eval_baseline.py:40-42,65-71)."""

@@ -39,7 +39,7 @@ print('conv forms $v: %.1f img/s  %.2f ms/step  conv %.2f ms  gemm_pp %.2f  attn
                     env MOGE_${AB_VAR}=$v timeout 300 python bench.py ${BENCH_ARGS} --steps 10 --warmup 3 --no-cpu-baseline --no-pcie 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline()); k = d['kernel_classes']
-print('$AB_VAR=$v: %.1f img/s  %.2f ms/step  conv %.2f ms  gemm_pp %.2f  attn %.2f  post %.2f  norm %.2f' % (d['value'], d['ms_per_step'], k['conv']['ms_per_step'], k['gemm_pp']['ms_per_step'], k['attn']['ms_per_step'], k['post']['ms_per_step'], k['norm']['ms_per_step']))"
+print('$AB_VAR=$v: %.1f img/s  %.2f ms/step  p50(B=1) %.2f  conv %.2f ms  gemm_pp %.2f  attn %.2f  post %.2f  norm %.2f' % (d['value'], d['ms_per_step'], d['p50_latency_ms_batch1'], k['conv']['ms_per_step'], k['gemm_pp']['ms_per_step'], k['attn']['ms_per_step'], k['post']['ms_per_step'], k['norm']['ms_per_step']))"
                   done
                 done > $out/${tag}_ab_${AB_VAR}${AB_SUFFIX}.log 2>&1; cat $out/${tag}_ab_${AB_VAR}${AB_SUFFIX}.log ;;
     tests_conv) timeout 600 python -m pytest tests/test_hip_conv_ex.py tests/test_hip_parity.py -m gpu -q -p no:cacheprovider > $out/${tag}_pytest_conv.log 2>&1; tail -15 $out/${tag}_pytest_conv.log ;;
@@ -61,6 +61,21 @@ print('batch $b: %.1f img/s  %.2f ms/step  (kernel sum single-stream %.2f ms: ge
     tests_mp)   timeout 600 python -m pytest tests/test_hip_multiproc.py -m gpu -q -p no:cacheprovider 2>&1 | tail -5 ;;
     ab_q4)      for cfg in "vitb8:--config moge-2-vitb-normal --batch 8" "vitl8:--batch 8" "vitl4:--batch 4" "vitl16:--batch 16"; do
                   echo "== ${cfg%%:*}"; AB_SUFFIX=_${cfg%%:*} BENCH_ARGS="${cfg#*:}" AB_VAR=ATTN_Q4_MIN_WGS AB_VALS="640 1536" bash tools/gpu_call.sh $tag ab; done ;;
+    lat)        # batch-1 anatomy: kernel classes from the HIP-event profiler + a rocprofv3 kernel trace of the same command
+                timeout 300 python bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --no-pcie > $out/${tag}_bench_b1.json 2>/dev/null
+                python -c "
+import json
+d = json.loads(open('$out/${tag}_bench_b1.json').read().strip().splitlines()[-1]); k = d['kernel_classes']
+print('B=1: %.1f img/s %.3f ms/step p50 %.3f | ' % (d['value'], d['ms_per_step'], d['p50_latency_ms_batch1']) + ' '.join('%s %.3f' % (n, v['ms_per_step']) for n, v in k.items()))"
+                rm -rf /tmp/lt; rocprofv3 --kernel-trace --output-format csv -d /tmp/lt -o lt -- python bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --no-pcie --no-profile > /dev/null 2>&1
+                python3 tools/trace_summary.py /tmp/lt/lt_kernel_trace.csv 80 > $out/${tag}_b1_kernels_by_grid.csv; head -60 $out/${tag}_b1_kernels_by_grid.csv ;;
+    kb_lat)     for f in b1. b4.; do KB_LAT=1 KB_ROUNDS=3 timeout 300 ./tools/kbench gemm $f 20; done > $out/${tag}_kbench_gemm_latency.log 2>&1; grep -v "^   ts" $out/${tag}_kbench_gemm_latency.log ;;
+    ab_heads)   for cfg in "vitl1:--batch 1" "vitl4:--batch 4" "vitb8:--config moge-2-vitb-normal --batch 8" "vitln1:--config moge-2-vitl-normal --batch 1" "vitln4:--config moge-2-vitl-normal --batch 4"; do
+                  echo "== ${cfg%%:*}"; AB_SUFFIX=_${cfg%%:*} BENCH_ARGS="${cfg#*:}" AB_VAR=HEAD_STREAMS AB_VALS="0 1" bash tools/gpu_call.sh $tag ab; done
+                echo "== vitl32 (HEAD_STREAMS_MAX_B 7 / 16)"; AB_SUFFIX=_vitl32 BENCH_ARGS="" AB_VAR=HEAD_STREAMS_MAX_B AB_VALS="7 16" bash tools/gpu_call.sh $tag ab ;;
+    tests_par)  timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -5 ;;
+    tests_rec)  timeout 900 python -m pytest tests/test_hip_kernels.py tests/test_hip_parity.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -5 ;;
+    tests_cv)   timeout 900 python -m pytest tests/test_hip_kernels.py tests/test_hip_conv_ex.py tests/test_hip_parity.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -5 ;;
     *) echo "unknown step $what" ;;
   esac
 done

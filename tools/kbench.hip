@@ -154,15 +154,18 @@ static int bench_gemm(const char* filter, int iters) {
     };
     // kern: PP_KERN (0 = gemm_pp128m16_kernel, 2 = gemm_pp128p_kernel (persistent), 1 = gemm_pp4w16_kernel (--experiments));  exp: PP_EXP (library built with --experiments only: 1/2/3 = gemm_pp128
     // 32x32x16 form with A3 = 1/2/0, 4 = gemm_pp4w 32x32x16, 5 = 64-byte-row 256x256, 6 = 64-byte-row 256x128 two workgroups per CU)
-    struct Variant { const char* name; int pp, glds, dbg, kern, exp; };
+    struct Variant { const char* name; int pp, glds, dbg, kern, exp; int small_ns = 2, small_blocks = 512; };
     auto apply = [](const Variant& v) {
         moge_tune_set("GEMM_PP", v.pp); moge_tune_set("PP_MIN_TILES", 0); moge_tune_set("GLDS_VARIANT", v.glds); moge_tune_set("PP_DBG", v.dbg);
         moge_tune_set("PP_KERN", v.kern); moge_tune_set("PP_EXP", v.exp);
+        moge_tune_set("GLDS_SMALL_NS", v.small_ns); moge_tune_set("GLDS_SMALL_BLOCKS", v.small_blocks);
     };
     std::vector<Variant> variants = {{"glds2-m16", 0, 2, 0, 0, 0}, {"pp128-m16", 1, 2, 0, 0, 0}, {"pp128p", 1, 2, 0, 2, 0}};
     if (getenv("KB_EXP")) variants = {{"pp128-m16", 1, 2, 0, 0, 0}, {"pp4w-16", 1, 2, 0, 1, 0}, {"x:pp128-a3", 1, 2, 0, 0, 1}, {"x:pp128-a3c", 1, 2, 0, 0, 2}, {"x:pp128-2buf", 1, 2, 0, 0, 3},
                                       {"x:pp4w-32", 1, 2, 0, 0, 4}, {"x:pp64", 1, 2, 0, 0, 5}, {"x:pp64-2wg", 1, 2, 0, 0, 6}};
     if (getenv("KB_GC")) variants = {{"pp128p", 1, 2, 0, 2, 0}, {"pp128p gc2", 1, 2, 2, 2, 0}, {"pp128p gc8", 1, 2, 8, 2, 0}, {"pp128p gc16", 1, 2, 16, 2, 0}};
+    if (getenv("KB_LAT")) variants = {{"64x128 ns2", 0, 2, 0, 0, 0, 2, 512}, {"64x128 ns3", 0, 2, 0, 0, 0, 3, 512}, {"64x128 ns4", 0, 2, 0, 0, 0, 4, 512},      // latency-regime kernels
+                                      {"128x128 ns2", 0, 2, 0, 0, 0, 2, 0}, {"128x128 ns3", 0, 4, 0, 0, 0, 2, 0}, {"128x128 ns4", 0, 5, 0, 0, 0, 2, 0}, {"pp128p", 1, 2, 0, 2, 0}};
     if (getenv("KB_PP")) variants = {{"pp128-m16", 1, 2, 0, 0, 0}, {"pp128p", 1, 2, 0, 2, 0}};
     if (getenv("KB_PPX")) variants = {{"pp128p", 1, 2, 0, 2, 0}, {"x:pp128p-mrg", 1, 2, 0, 3, 0}, {"x:pp128p-wm", 1, 2, 0, 4, 0}};      // --experiments builds
     int fails = 0;

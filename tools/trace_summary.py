@@ -7,8 +7,11 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
     name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
     name = re.sub(r"^void ", "", name)[:60]
-    gs = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
-    wg = int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", 1)) or 1)
+    def dims(key):                                   # rocprofv3 7.x: per-dimension columns; older: one total
+        if key + "_X" in r:
+            return int(r[key + "_X"] or 1) * int(r.get(key + "_Y") or 1) * int(r.get(key + "_Z") or 1)
+        return int(r.get(key) or 1)
+    gs, wg = dims("Grid_Size"), dims("Workgroup_Size")
     k = (name, gs // max(wg, 1), wg)
     agg[k][0] += 1
     agg[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
