@@ -643,8 +643,11 @@ static int launch_attn_pp16(const void* q, const void* k, const void* v, void* o
     // 1 = QB 2 always, 2 = QB 4 always, 3 (default) = by grid size
     const int akern = moge_tune_get("ATTN_KERN", AP_KERN_DEFAULT);
     if (akern >= 1) {
-        const long wgs4 = (long)((Ntok + 255) / 256) * B * nh;
-        const bool q4 = akern == 2 || (akern == 3 && wgs4 >= moge_tune_get("ATTN_Q4_MIN_WGS", 640));
+        // QB = 2 while its grid fits ONE round of the chip (3 workgroups per CU): a lone round is a latency chain per workgroup and the 32-query
+        // form's is the shorter one (N = 3601, one image: 464 workgroups, 720 vs 680 TF/s; N = 1370 x 4: 760 vs 631); from two images on the
+        // 64-query form wins (928 workgroups = 1.2 rounds against 480 = 0.94: 745-797 vs 845-879 TF/s; r03zd_kbench_attn_b1.log)
+        const long wgs2 = (long)((Ntok + 127) / 128) * B * nh;
+        const bool q4 = akern == 2 || (akern == 3 && wgs2 > moge_tune_get("ATTN_Q2_MAX_WGS", 3 * pp_device_cus()));
         const int xr = moge_tune_get("ATTN_XCD", 1);
         if (q4) {
             if (int rc = set_dyn_lds<attn_pp16mq_kernel<4>>(smem)) return rc;

@@ -627,7 +627,7 @@ int launch_gemm(const GemmArgs& g, int amode, hipStream_t st) {
             // co-resident workgroups per CU hide each other's DMA / LDS latency).  Same MFMA and K order: results are bit-identical.
             const long blocks128 = ((long)(g.M + 127) / 128) * ((g.N + 127) / 128);
             if (blocks128 < moge_tune_get("GLDS_SMALL_BLOCKS", 512) && moge_tune_get("GLDS_VARIANT", 2) == 2) {
-                switch (moge_tune_get("GLDS_SMALL_NS", 2)) {            // ring depth of the 64x128 kernel (bit-identical results)
+                switch (moge_tune_get("GLDS_SMALL_NS", 3)) {            // ring depth of the 64x128 kernel (bit-identical results)
                 case 3: return launch_glds<T, 2, 2, 1, 2, 3>(g, st);
                 case 4: return launch_glds<T, 2, 2, 1, 2, 4>(g, st);
                 default: return launch_glds<T, 2, 2, 1, 2, 2>(g, st);

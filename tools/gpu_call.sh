@@ -60,7 +60,7 @@ print('batch $b: %.1f img/s  %.2f ms/step  (kernel sum single-stream %.2f ms: ge
                 done; done > $out/${tag}_batch_sweep.log 2>&1; cat $out/${tag}_batch_sweep.log ;;
     tests_mp)   timeout 600 python -m pytest tests/test_hip_multiproc.py -m gpu -q -p no:cacheprovider 2>&1 | tail -5 ;;
     ab_q4)      for cfg in "vitb8:--config moge-2-vitb-normal --batch 8" "vitl8:--batch 8" "vitl4:--batch 4" "vitl16:--batch 16"; do
-                  echo "== ${cfg%%:*}"; AB_SUFFIX=_${cfg%%:*} BENCH_ARGS="${cfg#*:}" AB_VAR=ATTN_Q4_MIN_WGS AB_VALS="640 1536" bash tools/gpu_call.sh $tag ab; done ;;
+                  echo "== ${cfg%%:*}"; AB_SUFFIX=_${cfg%%:*} BENCH_ARGS="${cfg#*:}" AB_VAR=ATTN_Q2_MAX_WGS AB_VALS="768 2900" bash tools/gpu_call.sh $tag ab; done ;;
     lat)        # batch-1 anatomy: kernel classes from the HIP-event profiler + a rocprofv3 kernel trace of the same command
                 timeout 300 python bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --no-pcie > $out/${tag}_bench_b1.json 2>/dev/null
                 python -c "
@@ -76,6 +76,10 @@ print('B=1: %.1f img/s %.3f ms/step p50 %.3f | ' % (d['value'], d['ms_per_step']
     tests_par)  timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -5 ;;
     tests_rec)  timeout 900 python -m pytest tests/test_hip_kernels.py tests/test_hip_parity.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -5 ;;
     tests_cv)   timeout 900 python -m pytest tests/test_hip_kernels.py tests/test_hip_conv_ex.py tests/test_hip_parity.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -5 ;;
+    kb_attn_b1) for f in "b1 N" "b2 N"; do timeout 300 ./tools/kbench attn "$f" 20; done > $out/${tag}_kbench_attn_b1.log 2>&1; cat $out/${tag}_kbench_attn_b1.log ;;
+    ab1)        # batch-1 A/B of MOGE_$AB_VAR over $AB_VALS
+                AB_SUFFIX=_b1 BENCH_ARGS="--batch 1" bash tools/gpu_call.sh $tag ab ;;
+    ab2)        AB_SUFFIX=_b2 BENCH_ARGS="--batch 2" bash tools/gpu_call.sh $tag ab ;;
     *) echo "unknown step $what" ;;
   esac
 done

@@ -343,14 +343,16 @@ __global__ void spike_k(f16* k, int Ntok, int bh, int key, float scale) {
 }
 
 __global__ void cmp_bits(const f16* a, const f16* b, size_t n, int* nbad);
-static int bench_attn(int iters) {
+static int bench_attn(const char* filter, int iters) {
     hipStream_t st;
     CK(hipStreamCreate(&st));
     struct Case { const char* name; int B, nh, Ntok; };
     const Case cases[] = {{"vitl b32 N3601", 32, 16, 3601}, {"vitl b16 N3601", 16, 16, 3601}, {"vitb b8 N3601", 8, 12, 3601}, {"vitl b4 N3601", 4, 16, 3601}, {"vitb b4 N3601", 4, 12, 3601},
-                          {"small N130", 2, 3, 130}, {"N1370", 4, 16, 1370}, {"vitl b32 518x1036", 32, 16, 3571}};
+                          {"small N130", 2, 3, 130}, {"N1370", 4, 16, 1370}, {"vitl b32 518x1036", 32, 16, 3571},
+                          {"vitl b1 N3601", 1, 16, 3601}, {"vitl b2 N3601", 2, 16, 3601}, {"vitb b1 N3601", 1, 12, 3601}, {"vitl b1 N1370", 1, 16, 1370}};
     int fails = 0;
     for (const Case& c : cases) {
+        if (filter && !strstr(c.name, filter)) continue;
         const size_t BH = (size_t)c.B * c.nh, n = BH * c.Ntok * 64;
         const int Npad = (c.Ntok + 63) / 64 * 64;
         f16 *q, *k, *v, *vT, *out;
@@ -683,7 +685,7 @@ int main(int argc, char** argv) {
     const char* filter = argc > 2 && strcmp(argv[2], "-") ? argv[2] : nullptr;
     const int iters = argc > 3 ? atoi(argv[3]) : 10;
     if (!strcmp(argv[1], "gemm")) return bench_gemm(filter, iters) ? 4 : 0;
-    if (!strcmp(argv[1], "attn")) return bench_attn(iters) ? 4 : 0;
+    if (!strcmp(argv[1], "attn")) return bench_attn(filter, iters) ? 4 : 0;
     if (!strcmp(argv[1], "conv")) return bench_conv(filter, iters) ? 4 : 0;
     if (!strcmp(argv[1], "rb")) return bench_rb(iters) ? 4 : 0;
     if (!strcmp(argv[1], "corun")) return bench_corun(filter, iters);
