@@ -270,3 +270,27 @@ def test_fast_gelu_matches_erf_gelu(H, kern):
     err = (out - ref).abs()
     bound = 1e-5 + ref.abs() * 2.0 ** -11 * 1.01            # 3.7e-6 (fit) + one fp16 rounding of the result
     assert bool((err <= bound).all()), float((err - bound).max())
+
+
+@pytest.mark.parametrize("M,N,K", [(3601, 1024, 64), (3601, 1024, 128), (700, 768, 192), (3601, 1024, 1024), (2 * 3601, 1024, 4096), (517, 384, 1536)])
+def test_latency_kernel_ring_depths_are_bit_identical(H, M, N, K):
+    """gemm_glds_kernel 64 x 128 (batch <= 2): the 3-slab LDS ring the library ships (DMA two slabs ahead, counted vmcnt), the double buffer of
+    round 2 and a 4-slab ring run the same MFMAs in the same order - same bits, including K of 1, 2 and 3 slabs (the ring's prologue / tail
+    cases) and the RESID epilogue; and the 3-slab form against torch."""
+    from moge_amd import _lib as L
+    A, W, b = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23)
+    gamma, x0 = rnd(N, seed=24), rnd(M, N, seed=25, scale=3.0)
+    outs = {}
+    try:
+        for ns in (2, 3, 4):
+            L.tune("GLDS_SMALL_NS", ns)
+            with Force("latency"):
+                outs[ns] = (H.gemm_ex(H.TG_STORE, A, W, b, act=2)["out"], H.gemm_ex(H.TG_RESID, A, W, b, xres=x0, gamma=gamma, want_x16=True))
+    finally:
+        L.tune("GLDS_SMALL_NS", 3)
+    close(outs[3][0], h16(F.gelu(acc_ref(A, W) + b)), what="gelu store")
+    close(outs[3][1]["xres"], x0 + gamma * (acc_ref(A, W) + b), tol=2e-6, what="resid x")
+    for ns in (2, 4):
+        assert torch.equal(outs[ns][0], outs[3][0]), f"ring depth {ns} != 3 (store)"
+        for k in ("xres", "x16", "ln_part"):
+            assert torch.equal(outs[ns][1][k], outs[3][1][k]), f"ring depth {ns} != 3 ({k})"
