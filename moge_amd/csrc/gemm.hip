@@ -623,8 +623,9 @@ int launch_gemm(const GemmArgs& g, int amode, hipStream_t st) {
             if (gemm_runs_pp(g)) return launch_gemm_pp(g, st);
         }
         if (g.N > 64 && !g.relu_in && (g.K % (8 * TT<T>::CH)) == 0 && !g_disable_glds) {
-            // latency regime: when 128x128 tiles do not even give every CU two workgroups, halve the tile rows (64x128, 48 KiB LDS: up to three
-            // co-resident workgroups per CU hide each other's DMA / LDS latency).  Same MFMA and K order: results are bit-identical.
+            // latency regime: when 128x128 tiles do not even give every CU two workgroups, halve the tile rows (64x128; a 3-slab
+            // ring = 72 KiB LDS, two co-resident workgroups per CU: at batch 1-2 the weights arrive cold from HBM and the second slab in flight is worth
+            // more than a third workgroup - 7.3 -> 6.85 ms per image against the double buffer).  Same MFMA and K order: results are bit-identical.
             const long blocks128 = ((long)(g.M + 127) / 128) * ((g.N + 127) / 128);
             if (blocks128 < moge_tune_get("GLDS_SMALL_BLOCKS", 512) && moge_tune_get("GLDS_VARIANT", 2) == 2) {
                 switch (moge_tune_get("GLDS_SMALL_NS", 3)) {            // ring depth of the 64x128 kernel (bit-identical results)
