@@ -192,6 +192,10 @@ int moge_postprocess(moge_handle* h, const float* points_in, const float* normal
 int moge_depth_edge_mask(moge_handle* h, const float* depth, const unsigned char* mask, int B, int H, int W, float rtol,
                          unsigned char* out, void* stream);
 
+/* replaces the per-key `.half()` of MoGeModel.forward on a half model (moge/model/v2.py:386-387): n fp32 values -> fp16
+ * (round to nearest even, as torch), so that forward() too returns without a torch op between the kernels and the caller. */
+int moge_cast_f16(const float* src, void* dst_f16, int64_t n, void* stream);      /* stateless: runs on the current device */
+
 /* Synchronise `stream` and report the sticky device-side status of the calls since the last sync
  * (MOGE_ERR_NONFINITE if a recovery solve saw non-finite residuals). */
 int moge_sync(moge_handle* h, void* stream);

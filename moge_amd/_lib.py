@@ -99,6 +99,7 @@ def _load() -> C.CDLL:
         "moge_infer": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, C.POINTER(Outputs), vp]),
         "moge_postprocess": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, C.POINTER(Outputs), vp]),
         "moge_depth_edge_mask": (C.c_int, [vp, vp, vp, i32, i32, i32, C.c_float, vp, vp]),
+        "moge_cast_f16": (C.c_int, [vp, vp, C.c_int64, vp]),
         "moge_sync": (C.c_int, [vp, vp]),
         "moge_profile_enable": (C.c_int, [vp, i32]),
         "moge_profile_read": (C.c_int, [vp, C.POINTER(Profile), i32]),
@@ -133,7 +134,7 @@ def _load() -> C.CDLL:
 lib = _load()
 EXPORTS = ["moge_abi_version", "moge_last_error", "moge_create", "moge_create_v1", "moge_v1_forward", "moge_v1_infer", "moge_destroy", "moge_load_weights", "moge_alloc_master",
            "moge_master_blob", "moge_master_ready", "moge_set_precision", "moge_set_onnx_compatible_mode", "moge_workspace_bytes", "moge_forward", "moge_infer",
-           "moge_postprocess", "moge_depth_edge_mask", "moge_sync", "moge_profile_enable", "moge_profile_read", "moge_debug_tap", "moge_tune_set", "moge_test_gemm",
+           "moge_postprocess", "moge_depth_edge_mask", "moge_cast_f16", "moge_sync", "moge_profile_enable", "moge_profile_read", "moge_debug_tap", "moge_tune_set", "moge_test_gemm",
            "moge_test_gemm_ex", "moge_test_layernorm", "moge_test_attention", "moge_test_conv3x3", "moge_test_conv_ex", "moge_test_convt2x2", "moge_test_preprocess",
            "moge_test_resize_bicubic_aa", "moge_test_groupnorm_relu", "moge_test_posembed", "moge_test_recover",
            "moge_align_l1", "moge_align_l1_anchored", "moge_align_select", "moge_align_lstsq"]

@@ -1533,6 +1533,13 @@ int moge_depth_edge_mask(moge_handle* h, const float* depth, const unsigned char
     return 0;
 }
 
+int moge_cast_f16(const float* src, void* dst_f16, int64_t n, void* stream) {
+    if (!src || !dst_f16 || n < 0) return fail(MOGE_ERR_INVALID, "moge_cast_f16: null argument or negative count");
+    if (n == 0) return 0;
+    LCHK((launch_convert<float, f16>(src, dst_f16, (long)n, (hipStream_t)stream)));
+    return 0;
+}
+
 int moge_sync(moge_handle* h, void* stream) {
     if (!h) return fail(MOGE_ERR_INVALID, "null handle");
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));

@@ -389,7 +389,12 @@ class MoGeModel:
             L.check(L.lib.moge_forward(self._handle, image.data_ptr(), self._img_dtype(image), B, H, W, rows, cols,
                                        C.byref(o), L.stream_ptr(dev)))
         if self._dtype == torch.float16:
-            res = {k: v.half() for k, v in res.items()}
+            # a half model returns half tensors (v2.py:386-387): converted by the library, on the same stream
+            with torch.cuda.device(dev):
+                half = {k: torch.empty_like(v, dtype=torch.float16) for k, v in res.items()}
+                for k, v in res.items():
+                    L.check(L.lib.moge_cast_f16(v.data_ptr(), half[k].data_ptr(), v.numel(), L.stream_ptr(dev)))
+            res = half
         return res
 
     __call__ = forward

@@ -256,3 +256,19 @@ def test_groupnorm_relu(H, prec, B, Hh, Ww, Cc, G):
     ref = F.relu(F.group_norm(xin.cuda(), G, w.cuda(), b.cuda(), 1e-5)).permute(0, 2, 3, 1)
     out = H.groupnorm_relu(prec, x.permute(0, 2, 3, 1), w, b, G)
     assert relmax(out, ref) < (2e-5 if prec == 0 else 2e-3)
+
+
+def test_cast_f16_matches_torch_half_bit_for_bit(H):
+    """moge_cast_f16 (what MoGeModel.forward of a half model returns through, v2.py:386-387): round-to-nearest-even like `.half()`, including
+    ties, overflow to inf, subnormal halves, signed zeros, inf and NaN."""
+    from moge_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([torch.randn(100003, generator=g) * 10.0 ** torch.randint(-9, 6, (100003,), generator=g).float(),
+                   torch.tensor([0.0, -0.0, 65504.0, 65519.9, 65520.0, -70000.0, 1e-8, 5.96e-8, 2.98e-8, 2.9802322e-8, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11,
+                                 float("inf"), float("-inf"), float("nan")])]).cuda()
+    out = torch.empty(x.shape, dtype=torch.float16, device="cuda")
+    L.check(L.lib.moge_cast_f16(x.data_ptr(), out.data_ptr(), x.numel(), L.stream_ptr(x.device)))
+    torch.cuda.synchronize()
+    ref = x.half()
+    assert torch.equal(out.view(torch.int16)[~torch.isnan(ref)], ref.view(torch.int16)[~torch.isnan(ref)])
+    assert torch.isnan(out[torch.isnan(ref)]).all()

@@ -178,6 +178,26 @@ def test_stage_taps_match_oracle(MoGeModel, tmp_path_factory):
         assert rel_err(fwd[k].cpu().numpy(), ref[k].numpy()) < 5e-4, k
 
 
+def test_forward_of_a_half_model_returns_half_tensors(MoGeModel, tmp_path_factory):
+    """v2.py:386-387: forward() of a `.half()` model returns fp16 tensors of the same shapes; they come from moge_cast_f16 on the launch
+    stream (no torch op on the path) and stay within the fp16 band of the fp32 forward."""
+    model, cfg, sd = get_model(MoGeModel, "tiny-vits-normal", 0, True, tmp_path_factory)
+    x = torch.rand(2, 3, 84, 112, generator=torch.Generator().manual_seed(21))
+    try:
+        model.float()
+        f32 = model.forward(x, 108)
+        model.half()
+        f16 = model.forward(x, 108)
+        again = model.forward(x, 108)
+    finally:
+        model.float()
+    assert set(f16) == set(f32)
+    for k in f32:
+        assert f16[k].dtype == torch.float16 and f16[k].shape == f32[k].shape and f16[k].is_cuda, k
+        assert torch.equal(f16[k], again[k]), k
+        assert rel_err(f16[k].float().cpu().numpy(), f32[k].cpu().numpy()) < 2e-2, k
+
+
 def test_error_behaviour_matches_reference(MoGeModel, tmp_path_factory):
     """scipy raises ValueError('Residuals are not finite in the initial point.') when the point map overflows."""
     from oracle import moge_oracle as O
