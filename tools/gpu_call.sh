@@ -80,6 +80,7 @@ print('B=1: %.1f img/s %.3f ms/step p50 %.3f | ' % (d['value'], d['ms_per_step']
     ab1)        # batch-1 A/B of MOGE_$AB_VAR over $AB_VALS
                 AB_SUFFIX=_b1 BENCH_ARGS="--batch 1" bash tools/gpu_call.sh $tag ab ;;
     ab2)        AB_SUFFIX=_b2 BENCH_ARGS="--batch 2" bash tools/gpu_call.sh $tag ab ;;
+    tests_new2) timeout 600 python -m pytest tests/test_hip_kernels.py tests/test_hip_parity.py -m gpu -q -p no:cacheprovider -k "cast or half_model" 2>&1 | tail -3 ;;
     *) echo "unknown step $what" ;;
   esac
 done

@@ -149,12 +149,14 @@ static int bench_gemm(const char* filter, int iters) {
         {"b1.proj", Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"b1.fc1", Ntok, 4096, 1024, EPI_STORE, ACT_GELU, 0, 0, 0, 0, 0, 0, 0},
         {"b1.fc2", Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
+        {"vitb1.proj", Ntok, 768, 768, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
+        {"vitb1.fc2", Ntok, 768, 3072, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"b4.proj", 4 * Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"b4.fc2", 4 * Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
     };
     // kern: PP_KERN (0 = gemm_pp128m16_kernel, 2 = gemm_pp128p_kernel (persistent), 1 = gemm_pp4w16_kernel (--experiments));  exp: PP_EXP (library built with --experiments only: 1/2/3 = gemm_pp128
     // 32x32x16 form with A3 = 1/2/0, 4 = gemm_pp4w 32x32x16, 5 = 64-byte-row 256x256, 6 = 64-byte-row 256x128 two workgroups per CU)
-    struct Variant { const char* name; int pp, glds, dbg, kern, exp; int small_ns = 2, small_blocks = 512; };
+    struct Variant { const char* name; int pp, glds, dbg, kern, exp; int small_ns = 3, small_blocks = 512; };
     auto apply = [](const Variant& v) {
         moge_tune_set("GEMM_PP", v.pp); moge_tune_set("PP_MIN_TILES", 0); moge_tune_set("GLDS_VARIANT", v.glds); moge_tune_set("PP_DBG", v.dbg);
         moge_tune_set("PP_KERN", v.kern); moge_tune_set("PP_EXP", v.exp);
