@@ -1337,12 +1337,13 @@ static int check_call(moge_handle* h, const void* image, int B, int H, int W, in
 }
 
 // number of sub-batches a batch of B runs as (each on its own internal stream): BATCH_SPLIT = 0/1 off, n >= 2 -> n parts (default 2) when
-// every part keeps at least 4 images
+// every part keeps at least BATCH_SPLIT_MIN = 3 images (batch 6 = 3 + 3: 211 -> 222 img/s; batch 4 = 2 + 2 falls into the latency-regime kernels: 215 -> 184)
 static int split_parts(moge_handle* h, int B) {
     if (h->prof_on) return 1;
     int n = moge_tune_get("BATCH_SPLIT", 2);
     if (n > moge_handle::MAX_SPLIT) n = moge_handle::MAX_SPLIT;
-    while (n > 1 && B / n < 4) n--;
+    const int min_part = moge_tune_get("BATCH_SPLIT_MIN", 3);
+    while (n > 1 && B / n < min_part) n--;
     return n < 2 ? 1 : n;
 }
 // workspace bytes a forward over plan pl needs (callers size the arena BEFORE taking pointers into it)
