@@ -608,7 +608,9 @@ static int launch_by_n(const GemmArgs& g, hipStream_t st) {
 bool gemm_runs_pp(const GemmArgs& g) {
     if (!moge_tune_get("GEMM_PP", 1) || !gemm_pp_eligible(g)) return false;
     const long tiles = ((long)(g.M + 255) / 256) * ((g.N + 255) / 256);
-    return tiles >= moge_tune_get("PP_MIN_TILES", 128);
+    // crossover (M = 3601 per image, N = 1024): the 64 x 128 kernel takes 47 / 18 us per image (fc2 / proj), a 256 x 256 tile 74 / 28 us however few of
+    // them there are - from ~94 tiles (two images: 116) the throughput kernel wins (batch 2: 169.3 -> 173.4 img/s)
+    return tiles >= moge_tune_get("PP_MIN_TILES", 96);
 }
 
 template <typename T>

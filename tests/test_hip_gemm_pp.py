@@ -2,7 +2,7 @@
 PyTorch fp32 reference of the same op, and bit-for-bit against the latency-regime kernels of gemm.hip.
 
 Dispatch (gemm.hip launch_gemm): a GEMM goes to the ping-pong kernel when N % 256 == 0, K % 64 == 0 and it has at least PP_MIN_TILES
-(128) tiles of 256x256; everything smaller runs gemm_glds_kernel / gemm_kernel.  The tests pin the kernel under test explicitly:
+(96) tiles of 256x256; everything smaller runs gemm_glds_kernel / gemm_kernel.  The tests pin the kernel under test explicitly:
   force = "pp"      moge_tune_set("PP_MIN_TILES", 0)   -> the ping-pong kernel for every eligible shape; PP_KERN picks which of the two
                     product kernels (gemm_pp128p_kernel: persistent, the default; gemm_pp128m16_kernel: one tile per workgroup) - each test runs both
   force = "latency" moge_tune_set("GEMM_PP", 0)        -> gemm.hip only
@@ -55,7 +55,7 @@ class Force:
 
     def __exit__(self, *exc):
         from moge_amd import _lib as L
-        L.tune("PP_MIN_TILES", 128)
+        L.tune("PP_MIN_TILES", 96)
         L.tune("GEMM_PP", 1)
         L.tune("PP_KERN", -1)
         L.tune("PP_GRID", 0)

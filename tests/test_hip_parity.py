@@ -125,11 +125,11 @@ def test_fp16_throughput_kernels_in_the_model_match_reference_golden(MoGeModel, 
         base = model.infer(x, **kw)
         L.tune("PP_MIN_TILES", 0)
         forced = model.infer(x, **kw)
-        L.tune("PP_MIN_TILES", 128)
+        L.tune("PP_MIN_TILES", 96)
         xb = x.expand(9, *x.shape[1:]).contiguous()        # 9 x 3601 rows = 127 row tiles x >= 3 column tiles: ping-pong regime, two half-batch streams
         batch = model.infer(xb, **kw)
     finally:
-        L.tune("PP_MIN_TILES", 128)
+        L.tune("PP_MIN_TILES", 96)
         model.float()
     check_fp16(sub(forced, st), g, band)
     for k in base:
