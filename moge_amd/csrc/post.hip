@@ -314,11 +314,11 @@ int launch_mlp_layer(const float* in, const float* W, const float* bias, float* 
 // ------------------------------------------------------------------------------------------------------------
 // recovery
 // ------------------------------------------------------------------------------------------------------------
-#define REC_THREADS 1024
-#define REC_PTS 4       // 4096 sample points / 1024 threads (batch-1 latency: the solver is a chain of ~30 block reductions over fp64 divisions;
-                        // 16 waves shorten every link 4 x against the 4-wave form: 168 -> ~50 us)
+// REC_THREADS threads x REC_PTS sample points = the 64 x 64 grid.  Batch-1 latency: the solver is a chain of ~35 block reductions over fp64 divisions; more
+// waves shorten every link (4 waves: 168 us; 16 waves: 82-91 us with 300 B per lane of scratch under its 128-register budget; 8 waves, REC_THREADS = 512, no
+// scratch: 89-90 us - level, the 16-wave form is the one the golden suite ran with)
 
-template <int NV>
+template <int NV, int REC_THREADS>
 __device__ __forceinline__ void block_sum(double* v, double* sh) {
     constexpr int NW = REC_THREADS / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -344,13 +344,15 @@ __device__ __forceinline__ void block_sum(double* v, double* sh) {
     __syncthreads();
 }
 
+template <int REC_PTS>
 struct RecPts {
     float x[REC_PTS], y[REC_PTS], z[REC_PTS], u[REC_PTS], v[REC_PTS];
     unsigned valid;     // bit i: sample i of this thread is inside the mask
 };
 
 // closed-form focal for a given shift (geometry_numpy.py:85-86), fp64
-__device__ __forceinline__ void focal_sums(const RecPts& P, double s, double& num, double& den) {
+template <int REC_PTS>
+__device__ __forceinline__ void focal_sums(const RecPts<REC_PTS>& P, double s, double& num, double& den) {
     num = 0.0; den = 0.0;
 #pragma unroll
     for (int i = 0; i < REC_PTS; i++)
@@ -416,6 +418,7 @@ __device__ void lmpar1(double r, double diag, double qtb, double delta, double& 
 //   points (B,H,W,3) fp32; validity from mask_prob (>0.5f) or mask_u8 (!=0) or all-valid if both null
 //   fov_deg: null -> solve focal and shift; else focal fixed from fov_x (v2.py:261-263)
 //   focal_in: optional explicit focal (test entry point)
+template <int REC_THREADS>
 __global__ __launch_bounds__(REC_THREADS) void recover_kernel(const float* __restrict__ points, const float* __restrict__ mask_prob,
                                                       const uint8_t* __restrict__ mask_u8, const float* __restrict__ fov_deg,
                                                       const float* __restrict__ focal_in, int H, int W,
@@ -423,13 +426,13 @@ __global__ __launch_bounds__(REC_THREADS) void recover_kernel(const float* __res
                                                       float fov_c, float fx_mul, float fx_div, float fy_mul, float mask_thr,
                                                       float* __restrict__ focal_out, float* __restrict__ shift_out,
                                                       float* __restrict__ intrinsics, int* __restrict__ status) {
-    constexpr int NW = REC_THREADS / 64;
+    constexpr int NW = REC_THREADS / 64, REC_PTS = 4096 / REC_THREADS;
     __shared__ double sh[NW * 2];
     __shared__ double sh0[2];
     __shared__ int shi[NW];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* pts = points + (size_t)b * H * W * 3;
-    RecPts P;
+    RecPts<REC_PTS> P;
     P.valid = 0;
     int first = 1 << 30, count = 0;
 #pragma unroll
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(REC_THREADS) void recover_kernel(const float* __res
         // f(x0): focal + |fvec|
         double red[8];
         double f_cur = focal_fixed;
-        if (!fixed) { focal_sums(P, x, red[0], red[1]); block_sum<2>(red, sh); f_cur = red[0] / red[1]; }
+        if (!fixed) { focal_sums(P, x, red[0], red[1]); block_sum<2, REC_THREADS>(red, sh); f_cur = red[0] / red[1]; }
         red[0] = 0.0; red[1] = 0.0;
 #pragma unroll
         for (int i = 0; i < REC_PTS; i++)
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(REC_THREADS) void recover_kernel(const float* __res
                 red[0] += rx * rx + ry * ry;
                 if (!(isfinite(rx) && isfinite(ry))) red[1] += 1.0;
             }
-        block_sum<2>(red, sh);
+        block_sum<2, REC_THREADS>(red, sh);
         double fnorm = sqrt(red[0]);
         if (red[1] > 0.0 || !isfinite(fnorm)) { st = MOGE_ERR_NONFINITE; info = -1; }
         while (info == 0) {
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(REC_THREADS) void recover_kernel(const float* __res
             double h = eps * fabs(x);
             if (h == 0.0) h = eps;
             double f_h = focal_fixed;
-            if (!fixed) { focal_sums(P, x + h, red[0], red[1]); block_sum<2>(red, sh); f_h = red[0] / red[1]; }
+            if (!fixed) { focal_sums(P, x + h, red[0], red[1]); block_sum<2, REC_THREADS>(red, sh); f_h = red[0] / red[1]; }
             nfev++;
             const double xh = x + h;
             red[0] = 0.0;
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(REC_THREADS) void recover_kernel(const float* __res
                     red[0] += jx * jx + jy * jy;
                     if (own_first && i == first_slot) { sh0[0] = jx; sh0[1] = rx; }
                 }
-            block_sum<1>(red, sh);          // (contains the barriers that publish sh0)
+            block_sum<1, REC_THREADS>(red, sh);          // (contains the barriers that publish sh0)
             const double j0 = sh0[0], fv0 = sh0[1];
             const double acnorm = sqrt(red[0]);
             double r = 0.0, qtf = fv0;
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(REC_THREADS) void recover_kernel(const float* __res
                         if (own_first && i == first_slot) vx += 1.0;
                         red[0] += vx * c_rx[i] + (c_jy[i] / ajnorm) * c_ry[i];
                     }
-                block_sum<1>(red, sh);
+                block_sum<1, REC_THREADS>(red, sh);
                 r = -ajnorm;
                 const double v0 = j0 / ajnorm + 1.0;
                 qtf = v0 != 0.0 ? fv0 - red[0] : fv0;
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(REC_THREADS) void recover_kernel(const float* __res
                 const double pnorm = fabs(diag * p);
                 if (iter == 1) delta = fmin(delta, pnorm);
                 double f2 = focal_fixed;
-                if (!fixed) { focal_sums(P, x2, red[0], red[1]); block_sum<2>(red, sh); f2 = red[0] / red[1]; }
+                if (!fixed) { focal_sums(P, x2, red[0], red[1]); block_sum<2, REC_THREADS>(red, sh); f2 = red[0] / red[1]; }
                 red[0] = 0.0;
 #pragma unroll
                 for (int i = 0; i < REC_PTS; i++)
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(REC_THREADS) void recover_kernel(const float* __res
                         const double rx = f2 * ((double)P.x[i] / d) - (double)P.u[i], ry = f2 * ((double)P.y[i] / d) - (double)P.v[i];
                         red[0] += rx * rx + ry * ry;
                     }
-                block_sum<1>(red, sh);
+                block_sum<1, REC_THREADS>(red, sh);
                 nfev++;
                 const double fnorm1 = sqrt(red[0]);
                 double actred = -1.0;
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(REC_THREADS) void recover_kernel(const float* __res
                         den += (double)(px * px) + (double)(py * py);
                     }
                 red[0] = num; red[1] = den;
-                block_sum<2>(red, sh);
+                block_sum<2, REC_THREADS>(red, sh);
                 focal_res = (float)((float)red[0] / (float)red[1]);
             }
         } else {
@@ -629,8 +632,12 @@ int launch_recover(const float* points, const float* mask_prob, const uint8_t* m
     const float ustep = W > 1 ? (u1 - u0) / (float)(W - 1) : 0.f, vstep = H > 1 ? (v1 - v0) / (float)(H - 1) : 0.f;
     const float fov_c = (float)(a / sqrt(1 + a * a));
     const float diag = (float)sqrt(1 + a * a);
-    hipLaunchKernelGGL(recover_kernel, dim3(B), dim3(REC_THREADS), 0, st, points, mask_prob, mask_u8, fov_deg, focal_in, H, W, u0, u1, ustep, v0, v1,
-                       vstep, fov_c, diag, (float)a, diag, mask_thr, focal, shift, intrinsics, status);
+    if (moge_tune_get("REC_THREADS", 1024) == 512)
+        hipLaunchKernelGGL(recover_kernel<512>, dim3(B), dim3(512), 0, st, points, mask_prob, mask_u8, fov_deg, focal_in, H, W, u0, u1, ustep, v0, v1,
+                           vstep, fov_c, diag, (float)a, diag, mask_thr, focal, shift, intrinsics, status);
+    else
+        hipLaunchKernelGGL(recover_kernel<1024>, dim3(B), dim3(1024), 0, st, points, mask_prob, mask_u8, fov_deg, focal_in, H, W, u0, u1, ustep, v0, v1,
+                           vstep, fov_c, diag, (float)a, diag, mask_thr, focal, shift, intrinsics, status);
     return (int)hipGetLastError();
 }
 
