@@ -130,6 +130,10 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="disable the per-kernel HIP-event profiler")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="run only the cpu_baseline leg (no GPU needed) and print it")
     ap.add_argument("--print-launch", action="store_true", help="print the torch.distributed.run command --gpus N would re-execute as, and exit")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 (nccl = RCCL over xGMI: production; gloo: "
+                                                                               "host-staged weight broadcast, for ranks that must share a device)")
+    ap.add_argument("--single-device", action="store_true", help="every rank drives cuda:0 (start-up / host-feeding test of the N-process path on a 1-GPU box; "
+                                                                 "needs --backend gloo: RCCL refuses two ranks on one device).  The line says so; it is not a scaling number")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         # no GPU needed: the CPU leg alone (in the build container this times the unmodified reference: kind "reference")
@@ -155,12 +159,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
+    if args.single_device and args.backend != "gloo":
+        raise SystemExit("--single-device needs --backend gloo (RCCL refuses two ranks on one device)")
+    dev_index = 0 if args.single_device else local_rank
+    t_start = time.perf_counter()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     from moge_amd.model import import_model_class_by_version
@@ -186,15 +197,17 @@ def main():
         broadcast_weights(model, src=0)                  # one-time RCCL broadcast of the master blob
         dist.barrier()
         tb = time.perf_counter() - tb
-        ones = torch.ones(1, device=dev)
+        ones = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(ones)                            # how many ranks RCCL actually joined
         rccl = {"rccl_ranks": int(ones.item()), "backend": dist.get_backend(), "weight_broadcast_bytes": int(model.master_blob().numel()),
                 "weight_broadcast_seconds": round(tb, 4)}
+        if args.single_device:
+            rccl["single_device"] = True
     model.half()
 
     B = args.batch
     default_workload = (args.batch == BATCH_PER_GPU and args.config == WORKLOAD_CONFIG and args.num_tokens is None and args.shape == f"{IMG}x{IMG}")
-    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    g = torch.Generator(device="cpu").manual_seed(rank)            # rank 0: torch.rand(32, 3, 518, 518, manual_seed(0)) as SURVEY.md 8(d) config 3 draws it
     if args.shape == "mixed":
         xs = [torch.rand(B // 2, 3, 518, 1036, generator=g).to(dev), torch.rand(B - B // 2, 3, 1036, 518, generator=g).to(dev)]
     else:
@@ -205,6 +218,7 @@ def main():
     num_tokens = args.num_tokens or int(model.num_tokens_range[0] + (9 / 9) * (model.num_tokens_range[1] - model.num_tokens_range[0]))
 
     def barrier():
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -218,6 +232,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    startup_s = time.perf_counter() - t_start           # process-group init + checkpoint / broadcast + packing + warm-up, this rank
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -242,9 +257,12 @@ def main():
         prof = model.profile_read(reset=True)
         model.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        cdev = dev if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed, startup_s], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, startup_max = float(t[0].item()), float(t[1].item())
+        if rccl is not None:
+            rccl["startup_seconds_max_over_ranks"] = round(startup_max, 2)
     assert bool(torch.isfinite(out["intrinsics"]).all())
 
     if rank == 0:
@@ -288,10 +306,29 @@ def main():
                 res["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
                 res["roofline"]["traffic_unit"] = "bytes per launch (fabric reads x2-corrected + writes)"
                 res["roofline"]["traffic_source"] = tj["source"]
+                # the PMC passes cannot run inside this process: say which kernel source they were taken at, and flag the number when
+                # csrc/gemm_pp.hip has changed since (tools/pmc_traffic.py records the hash)
+                import hashlib
+                kpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "moge_amd", "csrc", "gemm_pp.hip")
+                cur = hashlib.sha256(open(kpath, "rb").read()).hexdigest()[:16]
+                res["roofline"]["traffic_taken_at"] = {"git": tj.get("git_commit"), "gemm_pp_hip_sha256_16": tj.get("gemm_pp_sha256_16")}
+                if tj.get("gemm_pp_sha256_16") != cur:
+                    res["roofline"]["traffic_stale"] = True
+                    print(f"[bench] WARNING: moge_amd/pmc_traffic.json was measured on gemm_pp.hip {tj.get('gemm_pp_sha256_16')}, the tree has {cur}: "
+                          "roofline.traffic is stale - rerun tools/profile_round.sh + tools/pmc_traffic.py", file=sys.stderr)
                 if tj.get("clock_ghz"):
                     # shader clock the kernel actually held in the PMC pass (the chip clocks to its power budget: 2.4 GHz is what `peak` assumes)
                     res["roofline"]["clock_ghz"] = tj["clock_ghz"]
                     res["roofline"]["mfma_busy_at_that_clock"] = tj.get("mfma_busy_at_that_clock")
+            # second ceiling: what a bare chain of the same MFMA instruction sustains on this chip under its power limit (tools/mfma_power,
+            # no data movement at all) - `frac` stays against the datasheet peak
+            spath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "moge_amd", "mfma_sustained.json")
+            if os.path.exists(spath):
+                with open(spath) as f:
+                    sj = json.load(f)
+                res["roofline"]["sustained_peak"] = sj["tflops"]
+                res["roofline"]["frac_of_sustained"] = round(ach / sj["tflops"], 4)
+                res["roofline"]["sustained_source"] = sj["source"]
             tot_ms = sum(v["ms"] for v in prof.values())
             tot_fl = sum(v["flops"] for v in prof.values())
             res["kernel_classes"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),

@@ -142,6 +142,12 @@ int moge_load_weights(moge_handle* h, const moge_tensor_desc* descs, int n, void
 int moge_alloc_master(moge_handle* h);
 int moge_master_blob(moge_handle* h, void** dev_ptr, size_t* bytes);
 int moge_master_ready(moge_handle* h);
+/* The same distribution for a host WITHOUT torch: `nccl_comm` is an ncclComm_t of the calling process (one rank per GPU,
+ * created by the host with ncclCommInitRank), passed as void* so that this header needs no RCCL include.  Rank `root` must hold loaded
+ * weights; every rank calls this once: ncclBroadcast of the fp32 master blob over xGMI on `stream`, then (non-root ranks) moge_master_ready.
+ * RCCL is bound at call time (dlopen of the librccl.so.1 already in the process, else the system one): no link-time dependency.
+ * The reference has no counterpart - it is a single-process PyTorch module (moge/model/v2.py:76-107 loads one checkpoint per process). */
+int moge_broadcast_weights(moge_handle* h, void* nccl_comm, int root, void* stream);
 
 /* replaces nn.Module.half()/.float() (scripts/infer.py:82-84): select the compute precision.  Packs the
  * kernel-layout weight set for that precision on first use (both sets may stay resident). */
@@ -166,7 +172,10 @@ int moge_forward(moge_handle* h, const void* image, int img_dtype, int B, int H,
 
 /* replaces MoGeModel.infer (v2.py:194-303) after the host has resolved num_tokens: forward + focal/shift
  * recovery (geometry_torch.py:115-170; MINPACK lmdif in fp64 on device) + intrinsics + re-projection +
- * metric scale + masking.  fov_x_deg: NULL, or device pointer to B floats (degrees). */
+ * metric scale + masking.  fov_x_deg: NULL, or device pointer to B floats (degrees).
+ * Every head is optional (v2.py:46-56): a model without a points head returns the validity mask (probability > 0.5, no `depth > 0` term)
+ * and the masked normal only (v2.py:251-298) - points / depth / intrinsics buffers are then ignored; without a mask head nothing is masked;
+ * without a scale head nothing is scaled. */
 int moge_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, int W, int token_rows, int token_cols,
                const float* fov_x_deg, int flags, const moge_outputs* out, void* stream);
 

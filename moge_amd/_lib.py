@@ -92,6 +92,7 @@ def _load() -> C.CDLL:
         "moge_alloc_master": (C.c_int, [vp]),
         "moge_master_blob": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "moge_master_ready": (C.c_int, [vp]),
+        "moge_broadcast_weights": (C.c_int, [vp, vp, i32, vp]),
         "moge_set_precision": (C.c_int, [vp, i32, vp]),
         "moge_set_onnx_compatible_mode": (C.c_int, [vp, i32]),
         "moge_workspace_bytes": (C.c_int, [vp, i32, i32, i32, i32, i32, C.POINTER(C.c_size_t)]),
@@ -133,7 +134,7 @@ def _load() -> C.CDLL:
 
 lib = _load()
 EXPORTS = ["moge_abi_version", "moge_last_error", "moge_create", "moge_create_v1", "moge_v1_forward", "moge_v1_infer", "moge_destroy", "moge_load_weights", "moge_alloc_master",
-           "moge_master_blob", "moge_master_ready", "moge_set_precision", "moge_set_onnx_compatible_mode", "moge_workspace_bytes", "moge_forward", "moge_infer",
+           "moge_master_blob", "moge_master_ready", "moge_broadcast_weights", "moge_set_precision", "moge_set_onnx_compatible_mode", "moge_workspace_bytes", "moge_forward", "moge_infer",
            "moge_postprocess", "moge_depth_edge_mask", "moge_cast_f16", "moge_sync", "moge_profile_enable", "moge_profile_read", "moge_debug_tap", "moge_tune_set", "moge_test_gemm",
            "moge_test_gemm_ex", "moge_test_layernorm", "moge_test_attention", "moge_test_conv3x3", "moge_test_conv_ex", "moge_test_convt2x2", "moge_test_preprocess",
            "moge_test_resize_bicubic_aa", "moge_test_groupnorm_relu", "moge_test_posembed", "moge_test_recover",

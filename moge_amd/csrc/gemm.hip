@@ -649,6 +649,9 @@ int launch_gemm(const GemmArgs& g, int amode, hipStream_t st) {
         if constexpr (std::is_same<T, f16>::value) {
             if (moge_tune_get("CONV_PP", 1) && conv_pp_eligible(g)) return launch_conv_pp(g, st);
         }
+        // the fused output conv (GemmArgs::dot_tab, g.out == nullptr) exists in the halo kernel only: any other kernel would store the full
+        // map through a null pointer.  Unsupported shape, not a launch.
+        if (g.dot_tab) return -1;
         return launch_by_n<T, AMODE_CONV3>(g, st);
     }
     return -1;

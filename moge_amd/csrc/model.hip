@@ -7,6 +7,7 @@
 #include "launchers.h"
 #include "../../include/moge_hip.h"
 
+#include <dlfcn.h>
 #include <cmath>
 #include <type_traits>
 #include <cstdarg>
@@ -852,6 +853,19 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     const bool par_heads = pl.head_sets > 1 && !h->prof_on;
     hipStream_t st_main = st;
     int forked = 0;
+    // Whatever way this function is left (a failed launch in the middle of a head included), the caller's stream must be ordered behind every
+    // head stream that was forked: their kernels use the shared workspace and the caller's output buffers, which a later ensure_ws() / hipFree
+    // or the caller itself may touch as soon as `st_main` looks idle.
+    struct HeadJoin {
+        moge_handle* h; int slot; hipStream_t main; int* forked;
+        ~HeadJoin() {
+            for (int i = 0; i < 2; i++)
+                if (*forked & (1 << i)) {
+                    if (hipEventRecord(h->ev_head[slot][i], h->head_st[slot][i]) == hipSuccess) hipStreamWaitEvent(main, h->ev_head[slot][i], 0);
+                }
+            *forked = 0;
+        }
+    } head_join{h, pl.slot, st_main, &forked};
     if (par_heads) {
         if (!h->ev_neck[pl.slot]) HIPCHK(hipEventCreateWithFlags(&h->ev_neck[pl.slot], hipEventDisableTiming));
         HIPCHK(hipEventRecord(h->ev_neck[pl.slot], st_main));
@@ -940,6 +954,7 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
         if (forked & (1 << i)) {
             HIPCHK(hipEventRecord(h->ev_head[pl.slot][i], h->head_st[pl.slot][i]));
             HIPCHK(hipStreamWaitEvent(st_main, h->ev_head[pl.slot][i], 0));
+            forked &= ~(1 << i);
         }
     // remember buffers for debug taps
     h->last.valid = true; h->last.prec = TT<T>::PREC; h->last.B = B; h->last.rows = rows; h->last.cols = cols;
@@ -1283,6 +1298,57 @@ int moge_master_ready(moge_handle* h) {
     return 0;
 }
 
+// ---- one-time weight distribution over RCCL ------------------------------------------------------------------
+// RCCL is resolved at CALL time with dlopen / dlsym - libmoge_hip.so has no link-time dependency on it (a single-GPU deployment needs no RCCL
+// at all) - and from the library instance that is ALREADY loaded in the process when there is one (SONAME librccl.so.1: torch's bundled copy
+// inside a PyTorch host), because the communicator handed in belongs to that instance.
+namespace {
+struct RcclApi {
+    int (*bcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;      // ncclBroadcast(sendbuff, recvbuff, count, datatype, root, comm, stream)
+    int (*user_rank)(void*, int*) = nullptr;                                               // ncclCommUserRank
+    int (*count)(void*, int*) = nullptr;                                                   // ncclCommCount
+    const char* (*errstr)(int) = nullptr;                                                  // ncclGetErrorString
+    bool ok = false;
+};
+RcclApi& rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api;
+    tried = true;
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return api;
+    api.bcast = reinterpret_cast<decltype(api.bcast)>(dlsym(lib, "ncclBroadcast"));
+    api.user_rank = reinterpret_cast<decltype(api.user_rank)>(dlsym(lib, "ncclCommUserRank"));
+    api.count = reinterpret_cast<decltype(api.count)>(dlsym(lib, "ncclCommCount"));
+    api.errstr = reinterpret_cast<decltype(api.errstr)>(dlsym(lib, "ncclGetErrorString"));
+    api.ok = api.bcast && api.user_rank && api.count;
+    return api;
+}
+}  // namespace
+
+int moge_broadcast_weights(moge_handle* h, void* nccl_comm, int root, void* stream) {
+    if (!h || !nccl_comm) return fail(MOGE_ERR_INVALID, "null argument");
+    RcclApi& api = rccl_api();
+    if (!api.ok) return fail(MOGE_ERR_INVALID, "RCCL not available: librccl.so.1 could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+    HIPCHK(hipSetDevice(h->device));
+    int rank = -1, n = 0;
+    int rc = api.user_rank(nccl_comm, &rank);
+    if (rc == 0) rc = api.count(nccl_comm, &n);
+    if (rc != 0) return fail(MOGE_ERR_INVALID, "RCCL communicator query failed: %s", api.errstr ? api.errstr(rc) : "?");
+    if (root < 0 || root >= n) return fail(MOGE_ERR_INVALID, "root %d is not a rank of a %d-rank communicator", root, n);
+    if (rank == root && !h->master_ready) return fail(MOGE_ERR_NOT_LOADED, "the root rank has no weights to broadcast (moge_load_weights first)");
+    CHK(moge_alloc_master(h));
+    hipStream_t st = (hipStream_t)stream;
+    const int NCCL_FLOAT32 = 7;                                  // ncclFloat (rccl.h ncclDataType_t)
+    rc = api.bcast(h->master, h->master, h->master_floats, NCCL_FLOAT32, root, nccl_comm, st);
+    if (rc != 0) return fail(MOGE_ERR_HIP, "ncclBroadcast failed: %s", api.errstr ? api.errstr(rc) : "?");
+    HIPCHK(hipStreamSynchronize(st));
+    if (rank != root) return moge_master_ready(h);               // kernel layouts are re-packed from the received master copy on next use
+    return 0;
+}
+
 int moge_load_weights(moge_handle* h, const moge_tensor_desc* descs, int n, void* stream) {
     if (!h || !descs) return fail(MOGE_ERR_INVALID, "null argument");
     hipStream_t st = (hipStream_t)stream;
@@ -1342,7 +1408,8 @@ static int split_parts(moge_handle* h, int B) {
     if (h->prof_on) return 1;
     int n = moge_tune_get("BATCH_SPLIT", 2);
     if (n > moge_handle::MAX_SPLIT) n = moge_handle::MAX_SPLIT;
-    const int min_part = moge_tune_get("BATCH_SPLIT_MIN", 3);
+    int min_part = moge_tune_get("BATCH_SPLIT_MIN", 3);
+    if (min_part < 1) min_part = 1;                 // (a part of 0 images is not a batch)
     while (n > 1 && B / n < min_part) n--;
     return n < 2 ? 1 : n;
 }
@@ -1449,7 +1516,7 @@ static int post_impl(moge_handle* h, const Plan& pl, const float* pts_in, const 
     float* focal = out->focal ? out->focal : (float*)(h->ws + pl.focal);
     float* shift = out->shift ? out->shift : (float*)(h->ws + pl.shift);
     float* intr = out->intrinsics ? out->intrinsics : (float*)(h->ws + pl.intr);
-    {
+    if (pts_in) {                   // (no points head, v2.py:251-281: nothing to recover - mask and masked normal only)
         ProfScope ps(h, st, MOGE_KC_RECOVER, 0, (double)B * 4096 * 16);
         LCHK(launch_recover(pts_in, mp, nullptr, fov, nullptr, B, H, W, focal, shift, intr, h->d_status, st, h->mask_thr));
     }
@@ -1467,8 +1534,10 @@ int moge_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, i
     CHK(check_call(h, image, B, H, W, rows, cols));
     if (!out) return fail(MOGE_ERR_INVALID, "null outputs");
     const moge_config& c = h->cfg;
-    if (!(c.heads & MOGE_HEAD_POINTS)) return fail(MOGE_ERR_INVALID, "infer needs a points head");
-    if (!out->points || !out->depth) return fail(MOGE_ERR_INVALID, "points and depth output buffers are required");
+    // every head is optional (v2.py:46-56): without a points head infer() returns the mask (no `depth > 0` term) and the masked normal (v2.py:251-298)
+    const bool has_pts = (c.heads & MOGE_HEAD_POINTS) != 0;
+    if (has_pts && (!out->points || !out->depth)) return fail(MOGE_ERR_INVALID, "points and depth output buffers are required");
+    if (!has_pts && !(c.heads & (MOGE_HEAD_MASK | MOGE_HEAD_NORMAL))) return fail(MOGE_ERR_INVALID, "the model has no points, mask or normal head: infer() has nothing to return");
     hipStream_t st = (hipStream_t)stream;
     CHK(ingest_image(h, image, img_dtype, B, H, W, st));
     Plan pl = make_plan(c, h->prec, B, H, W, rows, cols);
@@ -1476,8 +1545,8 @@ int moge_infer(moge_handle* h, const void* image, int img_dtype, int B, int H, i
     float* mp = (c.heads & MOGE_HEAD_MASK) ? (out->mask_prob ? out->mask_prob : (float*)(h->ws + pl.maskprob)) : nullptr;
     float* nrm = (c.heads & MOGE_HEAD_NORMAL) ? out->normal : nullptr;
     float* metric = (c.heads & MOGE_HEAD_SCALE) ? (out->metric_scale ? out->metric_scale : (float*)(h->ws + pl.metric)) : nullptr;
-    CHK(forward_dispatch(h, image, img_dtype, pl, out->points, nrm, mp, metric, st));
-    return post_impl(h, pl, out->points, nrm, mp, metric, fov_x_deg, flags, out, st);
+    CHK(forward_dispatch(h, image, img_dtype, pl, has_pts ? out->points : nullptr, nrm, mp, metric, st));
+    return post_impl(h, pl, has_pts ? out->points : nullptr, nrm, mp, metric, fov_x_deg, flags, out, st);
 }
 
 static int v1_check(moge_handle* h, const void* image, int B, int H, int W, int rh, int rw, void* stream) {

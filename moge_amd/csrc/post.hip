@@ -655,23 +655,25 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* points_in, c
         const int ox = idx % W;
         const long t = idx / W;
         const int oy = t % H, b = t / H;
-        float x = points_in[idx * 3], y = points_in[idx * 3 + 1], z = points_in[idx * 3 + 2];
-        z += shift[b];
+        // a model without a points head (v2.py:251-281, `points is None`): no depth, no intrinsics, no `depth > 0` term in the mask;
+        // only the mask and the masked normal leave the kernel
+        float x = 0.f, y = 0.f, z = 1.f;
+        if (points_in) { x = points_in[idx * 3]; y = points_in[idx * 3 + 1]; z = points_in[idx * 3 + 2] + shift[b]; }
         bool m = true;
         if (mask_prob) m = (mask_prob[idx] > mask_thr) && ((flags & 0x100) || z > 0.f);
         float depth = z;
-        if (flags & MOGE_FORCE_PROJECTION) {
+        if (points_in && (flags & MOGE_FORCE_PROJECTION)) {
             const float fx = intr[b * 9], fy = intr[b * 9 + 4], cx = intr[b * 9 + 2], cy = intr[b * 9 + 5];
             const float u = ((float)ox + 0.5f) / (float)W, v = ((float)oy + 0.5f) / (float)H;
             x = (u - cx) / fx * depth;
             y = (v - cy) / fy * depth;
         }
-        if (metric) { const float s = metric[b]; x *= s; y *= s; z *= s; depth *= s; }
+        if (metric && points_in) { const float s = metric[b]; x *= s; y *= s; z *= s; depth *= s; }
         float nx = 0.f, ny = 0.f, nz = 0.f;
         if (normal_in) { nx = normal_in[idx * 3]; ny = normal_in[idx * 3 + 1]; nz = normal_in[idx * 3 + 2]; }
         if ((flags & MOGE_APPLY_MASK) && mask_prob && !m) { x = INF; y = INF; z = INF; depth = INF; nx = 0.f; ny = 0.f; nz = 0.f; }
-        if (points_out) { points_out[idx * 3] = x; points_out[idx * 3 + 1] = y; points_out[idx * 3 + 2] = z; }
-        if (depth_out) depth_out[idx] = depth;
+        if (points_out && points_in) { points_out[idx * 3] = x; points_out[idx * 3 + 1] = y; points_out[idx * 3 + 2] = z; }
+        if (depth_out && points_in) depth_out[idx] = depth;
         if (normal_out && normal_in) { normal_out[idx * 3] = nx; normal_out[idx * 3 + 1] = ny; normal_out[idx * 3 + 2] = nz; }
         if (mask_out && mask_prob) mask_out[idx] = m ? 1 : 0;
     }

@@ -264,8 +264,9 @@ class MoGeModel:
             n = int.from_bytes(f.read(8), "little")
             header = json.loads(f.read(n).decode())
             off = f.tell()
-        # (blobs written before the field existed are MoGe-2 blobs)
-        if header.get("model_version", "v2") != cls.MODEL_VERSION:
+        # blobs written before the field existed carry no version: accept them for either class (the byte size is checked against the
+        # config when the blob is uploaded, _upload_blob) instead of treating a MoGe-1 blob as foreign on every load
+        if header.get("model_version", cls.MODEL_VERSION) != cls.MODEL_VERSION:
             raise ValueError(f"{path}: master blob of model version {header.get('model_version')!r}, this class is {cls.MODEL_VERSION!r}")
         off += (-off) % 4096
         if os.path.getsize(path) != off + header["nbytes"]:
@@ -279,7 +280,10 @@ class MoGeModel:
         cfg = header["model_config"]
         if model_kwargs is not None:
             cfg.update(model_kwargs)
-        model = cls(**cfg)
+        try:
+            model = cls(**cfg)
+        except TypeError as e:              # an un-versioned (legacy) blob of the other model family: its config keywords do not fit this class
+            raise ValueError(f"{path}: the blob's model_config does not describe a {cls.MODEL_VERSION} model ({e})") from e
         model._blob_path, model._blob_offset = str(path), off
         return model
 
@@ -458,12 +462,10 @@ class MoGeModel:
             self._set_precision(self._precision(use_fp16))
             o = L.Outputs()
             res: Dict[str, torch.Tensor] = {}
-            has_points = bool(self._bits & L.HEAD_POINTS)
-            if not has_points:
-                raise NotImplementedError("infer() without a points head is not implemented")
-            res["points"] = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev); o.points = res["points"].data_ptr()
-            res["intrinsics"] = torch.empty((B, 3, 3), dtype=torch.float32, device=dev); o.intrinsics = res["intrinsics"].data_ptr()
-            res["depth"] = torch.empty((B, H, W), dtype=torch.float32, device=dev); o.depth = res["depth"].data_ptr()
+            if self._bits & L.HEAD_POINTS:      # every head is optional (v2.py:46-56); absent heads => absent keys (v2.py:291-298)
+                res["points"] = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev); o.points = res["points"].data_ptr()
+                res["intrinsics"] = torch.empty((B, 3, 3), dtype=torch.float32, device=dev); o.intrinsics = res["intrinsics"].data_ptr()
+                res["depth"] = torch.empty((B, H, W), dtype=torch.float32, device=dev); o.depth = res["depth"].data_ptr()
             if self._bits & L.HEAD_MASK:
                 res["mask"] = torch.empty((B, H, W), dtype=torch.bool, device=dev); o.mask = res["mask"].data_ptr()
             if self._bits & L.HEAD_NORMAL:

@@ -12,6 +12,13 @@ pinned at 3fab839f in the reference's pyproject.toml:23).
 
 Every fixture records: the model config name, checkpoint seed, the input recipe, the infer() kwargs, the
 reference outputs, a checksum of the synthetic weights and the torch/scipy versions that produced it.
+
+Three reference runs per case: fp32 (`infer.*`), fp32 weights + use_fp16=True = torch.autocast(float16) (`infer16.*`) and `model.half()`
+(`infer16half.*`, scripts/infer.py:83-84).  The last one needs ONE more documented stub on CPU: ATen has no Half kernel for the
+antialiased resize (`_upsample_bilinear2d_aa` / `_upsample_bicubic2d_aa`: "compute_index_ranges_weights" not implemented for 'Half'),
+so `install_half_stub()` routes `F.interpolate(half tensor, antialias=True)` through fp32 and rounds the result back to fp16 - what the
+GPU kernel of the same op does (its accumulation type for Half is float, one rounding on store).  Every other op of the half model runs
+ATen's own Half kernels unmodified.
 """
 from __future__ import annotations
 
@@ -67,6 +74,40 @@ def install_stubs():
     u.pt, u.np = pt, npm
     sys.modules["utils3d"], sys.modules["utils3d.pt"], sys.modules["utils3d.np"] = u, pt, npm
     sys.path.insert(0, REFERENCE_ROOT)
+
+
+_half_stub_installed = False
+
+
+def install_half_stub():
+    """`model.half()` on CPU: the ONE op without a Half kernel is the antialiased resize (modules.py:121; v1.py:274,279).  Compute it in
+    fp32 and round once to fp16 - the arithmetic of the GPU kernel (accscalar_t = float for Half).  Everything else stays ATen's."""
+    global _half_stub_installed
+    if _half_stub_installed:
+        return
+    import torch.nn.functional as F
+    orig = F.interpolate
+
+    def interpolate(input, *a, **k):
+        if input.dtype == torch.float16 and k.get("antialias"):
+            return orig(input.float(), *a, **k).half()
+        return orig(input, *a, **k)
+
+    F.interpolate = interpolate          # moge.model.modules / v1 call `F.interpolate` through the module object
+    _half_stub_installed = True
+
+
+def case_config(case: dict) -> dict:
+    """model_config of a case: the named config, optionally with `remap_output` replaced (v2.py:122-136) and heads removed
+    (v2.py:46-56: every head is optional; infer() then returns the remaining keys, v2.py:251-298)."""
+    import copy
+    cfg = copy.deepcopy(oracle_module(case).named_configs()[case["config"]])
+    ov = case.get("cfg_override") or {}
+    if "remap_output" in ov:
+        cfg["remap_output"] = ov["remap_output"]
+    for h in ov.get("drop", []):
+        cfg.pop(h, None)
+    return cfg
 
 
 def weights_digest(sd) -> str:
@@ -128,6 +169,24 @@ CASES = [
     # and a common offset of 3 from block 2 on, all other channels O(1)): what the fp16 LayerNorm fold does when |x| / sigma is large
     dict(name="vitl_518_t3600_massive", config="moge-2-vitl", seed=0, sane=True, massive=True, input="rand", input_seed=0, shape=[1, 3, 518, 518],
          kwargs=dict(use_fp16=False), stride=7),
+    # BASELINE configs[3] at its own size: moge-2-vitl-normal (all three heads) on 518x518, default tokens (60x60 grid)
+    dict(name="vitl_normal_518_t3600", config="moge-2-vitl-normal", seed=0, sane=True, input="rand", input_seed=0, shape=[1, 3, 518, 518],
+         kwargs=dict(use_fp16=False), stride=7),
+    # the other remap_output modes (v2.py:122-136; every released model uses 'exp').  fov_x is given: the synthetic point head is pinhole-like only
+    # under 'exp' (xy * z needs the product); with the other remaps z is nearly constant and the FREE-focal solve is a one-parameter family
+    # (reference vs oracle differ by 0.3 there, like tiny_illposed) - with the focal known the shift is well determined; z_bias keeps the un-exponentiated depth away from 0
+    dict(name="tiny_remap_linear", config="tiny-vits-normal", cfg_override=dict(remap_output="linear"), z_bias=2.0, seed=0, sane=True, input_seed=21, shape=[2, 3, 98, 126],
+         kwargs=dict(num_tokens=120, use_fp16=False, fov_x=50.0)),
+    dict(name="tiny_remap_sinh", config="tiny-vits-normal", cfg_override=dict(remap_output="sinh"), z_bias=1.5, seed=0, sane=True, input_seed=22, shape=[2, 3, 84, 112],
+         kwargs=dict(num_tokens=108, use_fp16=False, fov_x=65.0)),
+    dict(name="tiny_remap_sinh_exp", config="tiny-vits-normal", cfg_override=dict(remap_output="sinh_exp"), seed=0, sane=True, input_seed=23, shape=[1, 3, 140, 150],
+         kwargs=dict(num_tokens=56, use_fp16=False, fov_x=40.0)),
+    # optional heads (v2.py:46-56, 251-298): no points head -> infer() returns mask (no depth > 0 term) and the masked normal only;
+    # points only -> no mask, no metric scale, no normal
+    dict(name="tiny_no_points_head", config="tiny-vits-normal", cfg_override=dict(drop=["points_head"]), seed=0, sane=True, input_seed=24, shape=[2, 3, 84, 112],
+         kwargs=dict(num_tokens=108, use_fp16=False)),
+    dict(name="tiny_points_head_only", config="tiny-vits-normal", cfg_override=dict(drop=["mask_head", "normal_head", "scale_head"]), seed=0, sane=True, input_seed=25,
+         shape=[2, 3, 84, 112], kwargs=dict(num_tokens=108, use_fp16=False)),
 ]
 CASES += [
     # MoGe-1 (moge/model/v1.py): real v1 class on synthetic checkpoints
@@ -151,19 +210,23 @@ def case_state_dict(case: dict, cfg: dict):
     sd = oracle_module(case).synth_state_dict(cfg, case["seed"], case["sane"])
     if case.get("massive"):
         O.add_massive_activations(sd, cfg)
+    if case.get("z_bias") is not None:              # raw z of the point head = z_bias + O(0.3) noise: keeps a 'linear' / 'sinh' depth away from 0
+        sd["points_head.output_blocks.4.bias"][2] = float(case["z_bias"])
     return sd
 
 
 # the cases whose reference run takes more than a few seconds on 8 cores (the CPU suite replays the oracle on the fast ones only)
-SLOW_CASES = ("vits_house518", "vitb_normal_518_t3600", "vitl_518_t3600", "vitl_normal_518x1036", "vitl_normal_1036x518", "v1_vitl_518", "vitl_518_t3600_massive")
+SLOW_CASES = ("vits_house518", "vitb_normal_518_t3600", "vitl_518_t3600", "vitl_normal_518x1036", "vitl_normal_1036x518", "v1_vitl_518", "vitl_518_t3600_massive",
+              "vitl_normal_518_t3600")
 
 
-def run_reference(case: dict):
+def run_reference(case: dict, want=("fp32", "autocast", "half")):
+    """-> cfg, sd, x, and the reference's outputs: fp32 infer, fp32 forward, autocast-fp16 infer, .half() infer (None when not in `want`)."""
     install_stubs()
     from moge.model import import_model_class_by_version
     OM = oracle_module(case)
     MoGeModel = import_model_class_by_version(case.get("version", "v2"))
-    cfg = OM.named_configs()[case["config"]]
+    cfg = case_config(case)
     sd = case_state_dict(case, cfg)
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "model.pt")
@@ -178,13 +241,18 @@ def run_reference(case: dict):
         model.onnx_compatible_mode = True
     out = model.infer(x, **case["kwargs"])
     fwd = model.forward(x if x.dim() == 4 else x[None], num_tokens=_tokens(cfg, case))
-    # The reference's OWN fp16 path on the same input: fp32 weights + use_fp16=True = torch.autocast(float16) (v2.py:241; what
-    # scripts/infer.py --fp16 / baselines/moge.py run when the model is not .half()).  It runs on CPU unmodified.  The other form,
-    # model.half() (scripts/infer.py:84), does not: ATen has no Half kernel for the antialiased resize on CPU
-    # ("compute_index_ranges_weights" not implemented for 'Half', modules.py:121), so it cannot be a fixture source here.
+    # The reference's OWN fp16 paths on the same input.  (a) fp32 weights + use_fp16=True = torch.autocast(float16) (v2.py:241; what
+    # baselines/moge.py and scripts/infer.py run when the model is not .half()): runs on CPU unmodified.  (b) model.half()
+    # (scripts/infer.py:83-84 `--fp16`, scripts/app.py:54-56): every tensor fp16 incl. the residual stream; needs install_half_stub().
     kw16 = dict(case["kwargs"]); kw16["use_fp16"] = True
-    out16 = model.infer(x, **kw16)
-    return cfg, sd, x, out, fwd, out16
+    out16 = model.infer(x, **kw16) if "autocast" in want else None
+    out16h = None
+    if "half" in want:
+        install_half_stub()
+        model.half()
+        out16h = {k: (v.float() if v.is_floating_point() else v) for k, v in model.infer(x, **kw16).items()}
+        model.float()
+    return cfg, sd, x, out, fwd, out16, out16h
 
 
 def _tokens(cfg, case):
@@ -203,10 +271,53 @@ def maxdiff(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a[fin] - b[fin]).abs().max()) if fin.any() else 0.0
 
 
+def _strided(k: str, a: np.ndarray, st: int) -> np.ndarray:
+    if k in ("intrinsics", "metric_scale") or st <= 1:
+        return a
+    return a[..., ::st, ::st, :] if (a.ndim >= 3 and a.shape[-1] == 3 and k in ("points", "normal")) else a[..., ::st, ::st]
+
+
+def drift_stats(a16: dict, ref: dict) -> dict:
+    """fp16-vs-fp32 drift of the reference itself in the per-pixel metric the parity tests use (full resolution)."""
+    return {k: (dict(flips=MX.mask_flips(a16[k], ref[k])) if ref[k].dtype == torch.bool else MX.summarize(k, a16[k], ref[k])) for k in ref}
+
+
+def add_half(case: dict) -> None:
+    """Append the `.half()` reference outputs (`infer16half.*`, meta.drift16half) to an EXISTING fixture without touching its other arrays;
+    the fp32 outputs of this run must reproduce the stored ones (same torch build, same thread count)."""
+    path = os.path.join(GOLDEN_DIR, case["name"] + ".npz")
+    z = np.load(path)
+    blob = {k: z[k] for k in z.files}
+    meta = json.loads(bytes(blob["meta"]).decode())
+    cfg, sd, x, ref, _fwd, _o16, ref16h = run_reference(case, want=("fp32", "half"))
+    st = case.get("stride", 1)
+    worst = 0.0
+    for k, v in ref.items():
+        a, b = _strided(k, v.numpy(), st), blob["infer." + k]
+        if b.dtype == np.bool_:
+            assert (a == b).all(), (case["name"], k)
+        else:
+            fin = np.isfinite(b)
+            assert (np.isfinite(a) == fin).all()
+            worst = max(worst, float(np.abs(a[fin] - b[fin]).max()) if fin.any() else 0.0)
+    assert worst <= (1e-2 if not case["sane"] else 2e-5), f"{case['name']}: fp32 rerun differs from the stored golden by {worst}"
+    for k, v in ref16h.items():
+        blob["infer16half." + k] = _strided(k, v.numpy(), st)
+    meta["drift16half"] = drift_stats(ref16h, ref)
+    meta["drift16half_source"] = ("reference model.half().infer(): fp16 weights, fp16 residual stream, ATen Half kernels on CPU; the antialiased resize computed in "
+                                  "fp32 and rounded to fp16 (oracle/make_golden.py install_half_stub), vs its own fp32 output, full resolution")
+    blob["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(path, **blob)
+    print(f"{case['name']}: fp32 rerun max |d| {worst:.1e}; half drift " + " ".join(
+        f"{k}:{(v.get('p999', v.get('flips'))):.2e}" for k, v in meta["drift16half"].items()), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check-only", action="store_true", help="compare oracle vs reference, write nothing")
-    ap.add_argument("--only", default=None)
+    ap.add_argument("--only", default=None, help="comma-separated case names")
+    ap.add_argument("--missing", action="store_true", help="only the cases that have no fixture file yet")
+    ap.add_argument("--add-half", action="store_true", help="append the .half() reference outputs to existing fixtures that lack them")
     args = ap.parse_args()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -217,10 +328,18 @@ def main():
         im = im.resize((518, 518), Image.BILINEAR)   # cv2 (INTER_AREA in the reference CLI) is not installed; PIL bilinear, recorded here
         np.save(house, np.asarray(im, dtype=np.uint8))
     import scipy
+    only = set(args.only.split(",")) if args.only else None
     for case in CASES:
-        if args.only and case["name"] != args.only:
+        if only and case["name"] not in only:
             continue
-        cfg, sd, x, ref, ref_fwd, ref16 = run_reference(case)
+        fixture = os.path.join(GOLDEN_DIR, case["name"] + ".npz")
+        if args.missing and os.path.exists(fixture):
+            continue
+        if args.add_half:
+            if os.path.exists(fixture) and "infer16half.points" not in np.load(fixture).files and "infer16half.mask" not in np.load(fixture).files:
+                add_half(case)
+            continue
+        cfg, sd, x, ref, ref_fwd, ref16, ref16h = run_reference(case)
         kw = {k: v for k, v in case["kwargs"].items() if k != "use_fp16"}
         tr = {}
         if case.get("version") == "v1":
@@ -237,37 +356,35 @@ def main():
                 line.append(f"{k}:{maxdiff(ref[k], ora[k]):.2e}")
         for k in ref_fwd:
             line.append(f"fwd.{k}:{maxdiff(ref_fwd[k], tr['forward'][k]):.2e}")
-        line.append(f"focal={tr['focal'].tolist()} shift={tr['shift'].tolist()}")
-        # drift of the reference's own fp16 (autocast) path against its fp32 path, in the per-pixel metric the parity tests use
-        drift16 = {k: (dict(flips=MX.mask_flips(ref16[k], ref[k])) if ref[k].dtype == torch.bool else MX.summarize(k, ref16[k], ref[k])) for k in ref}
+        if "focal" in tr:
+            line.append(f"focal={tr['focal'].tolist()} shift={tr['shift'].tolist()}")
+        # drift of the reference's own fp16 paths against its fp32 path, in the per-pixel metric the parity tests use
+        drift16, drift16h = drift_stats(ref16, ref), drift_stats(ref16h, ref)
         line.append("ref-fp16 drift: " + " ".join(f"{k}:{(v.get('p999', v.get('flips'))):.2e}" for k, v in drift16.items()))
+        line.append("ref-half drift: " + " ".join(f"{k}:{(v.get('p999', v.get('flips'))):.2e}" for k, v in drift16h.items()))
         print("  ".join(line), flush=True)
         if args.check_only:
             continue
         st = case.get("stride", 1)
         blob = {}
         for k, v in ref.items():
-            a = v.numpy()
-            if k != "intrinsics" and st > 1:
-                a = a[..., ::st, ::st, :] if (a.ndim >= 3 and a.shape[-1] == 3 and k in ("points", "normal")) else a[..., ::st, ::st]
-            blob["infer." + k] = a
-        for k, v in ref16.items():          # the reference's fp16 (autocast) outputs, fp16 storage is enough for them
-            a = v.numpy()
-            if k != "intrinsics" and st > 1:
-                a = a[..., ::st, ::st, :] if (a.ndim >= 3 and a.shape[-1] == 3 and k in ("points", "normal")) else a[..., ::st, ::st]
-            blob["infer16." + k] = a
+            blob["infer." + k] = _strided(k, v.numpy(), st)
+        for k, v in ref16.items():          # the reference's fp16 (autocast) outputs
+            blob["infer16." + k] = _strided(k, v.numpy(), st)
+        for k, v in ref16h.items():         # the reference's .half() outputs
+            blob["infer16half." + k] = _strided(k, v.numpy(), st)
         for k, v in ref_fwd.items():
-            a = v.detach().numpy()
-            if st > 1 and k != "metric_scale":
-                a = a[..., ::st, ::st, :] if (a.shape[-1] == 3 and k in ("points", "normal")) else a[..., ::st, ::st]
-            blob["forward." + k] = a
+            blob["forward." + k] = _strided(k, v.detach().numpy(), st)
         meta = dict(case=case, weights_sha256=weights_digest(sd), torch=torch.__version__, scipy=scipy.__version__,
                     numpy=np.__version__, threads=torch.get_num_threads(),
                     input_sha256=hashlib.sha256(x.numpy().tobytes()).hexdigest(),
-                    focal=tr["focal"].tolist(), shift=tr["shift"].tolist(), drift16=drift16,
-                    drift16_source="reference infer(use_fp16=True): fp32 weights under torch.autocast(cpu, float16), vs its own use_fp16=False output, full resolution")
+                    focal=tr["focal"].tolist() if "focal" in tr else None, shift=tr["shift"].tolist() if "shift" in tr else None, drift16=drift16,
+                    drift16_source="reference infer(use_fp16=True): fp32 weights under torch.autocast(cpu, float16), vs its own use_fp16=False output, full resolution",
+                    drift16half=drift16h,
+                    drift16half_source="reference model.half().infer(): fp16 weights, fp16 residual stream, ATen Half kernels on CPU; the antialiased resize computed in "
+                                       "fp32 and rounded to fp16 (install_half_stub), vs its own fp32 output, full resolution")
         blob["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-        np.savez_compressed(os.path.join(GOLDEN_DIR, case["name"] + ".npz"), **blob)
+        np.savez_compressed(fixture, **blob)
 
 
 if __name__ == "__main__":

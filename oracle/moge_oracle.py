@@ -209,6 +209,7 @@ def synth_state_dict(cfg: dict, seed: int = 0, sane_geometry: bool = True) -> Di
         rs = sd["neck.resamplers.3.1.weight"]
         rs[0:2].mul_(0.15)
         ph = "points_head."
+    if sane_geometry and cfg.get("points_head") is not None:
         w = sd[ph + "input_blocks.4.weight"]
         w[0:2].mul_(0.1)
         w[0, 0, 0, 0] = 1.0
@@ -221,8 +222,9 @@ def synth_state_dict(cfg: dict, seed: int = 0, sane_geometry: bool = True) -> Di
         wo[1, 1, 0, 0] = 0.35
         sd[ph + "output_blocks.4.bias"].copy_(torch.tensor([0.0, 0.0, 0.4]))
     # mask logits: spread them and move the mean so ~70% of the pixels are valid
-    sd["mask_head.output_blocks.4.weight"].mul_(4.0)
-    sd["mask_head.output_blocks.4.bias"].fill_(-4.0)
+    if cfg.get("mask_head") is not None:
+        sd["mask_head.output_blocks.4.weight"].mul_(4.0)
+        sd["mask_head.output_blocks.4.bias"].fill_(-4.0)
     return sd
 
 

@@ -7,7 +7,7 @@ import torch
 
 from oracle import metrics as MX
 from oracle import moge_oracle as O
-from oracle.make_golden import CASES, SLOW_CASES, case_state_dict, make_input, oracle_module, weights_digest
+from oracle.make_golden import CASES, SLOW_CASES, case_config, case_state_dict, make_input, oracle_module, weights_digest
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASE_BY_NAME = {c["name"]: c for c in CASES}
@@ -18,8 +18,7 @@ def load_case(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     meta = json.loads(bytes(z["meta"]).decode())
     case = meta["case"]
-    OM = oracle_module(case)
-    cfg = OM.named_configs()[case["config"]]
+    cfg = case_config(case)
     sd = case_state_dict(case, cfg)
     x = make_input(case)
     gold = {k: z[k] for k in z.files if k != "meta"}
@@ -81,30 +80,33 @@ def check_fp32(out: dict, ref: dict, ill: bool = False) -> dict:
     return seen
 
 
-def reference_drift16(gold: dict) -> dict:
-    """The reference's OWN fp16-vs-fp32 drift on a fixture, from the two reference outputs it stores (infer.* = use_fp16=False, infer16.* =
-    use_fp16=True), in the metric of oracle/metrics.py: p99.9 of the per-pixel error, mask flip fraction.  (meta.drift16 holds the same
-    statistics as computed at full resolution when the fixture was made.)"""
+def reference_drift16(gold: dict, prefix: str = "infer16.") -> dict:
+    """The reference's OWN fp16-vs-fp32 drift on a fixture, from the reference outputs it stores (infer.* = use_fp16=False, infer16.* =
+    use_fp16=True under autocast, infer16half.* = model.half()), in the metric of oracle/metrics.py: p99.9 of the per-pixel error, mask flip
+    fraction.  (meta.drift16 / meta.drift16half hold the same statistics as computed at full resolution when the fixture was made.)"""
     out = {}
     for k, v in gold.items():
         if not k.startswith("infer."):
             continue
         name = k[6:]
-        a, b = gold["infer16." + name], v
+        a, b = gold[prefix + name], v
         out[name] = MX.mask_flips(a, b) if b.dtype == np.bool_ else MX.summarize(name, a, b)["p999"]
     return out
 
 
-def fp16_band(meta: dict, gold: dict = None) -> dict:
+def fp16_band(meta: dict, gold: dict = None, form: str = "autocast") -> dict:
     """Per-output tolerance of the fp16 mode for one golden case: FP16_FACTOR x the reference's own fp16-vs-fp32 drift on that case
-    (reference_drift16), floored where that drift is ~0."""
+    (reference_drift16), floored where that drift is ~0.  form "autocast": fp32 weights + use_fp16=True (v2.py:241), the band every
+    fixture has carried since round 2;  form "half": model.half() (scripts/infer.py:83-84: fp16 weights AND an fp16 residual stream) - the band
+    the library's .half() mode, which keeps the residual stream in fp16 as the reference does, is judged against."""
     band = {}
+    key, prefix = ("drift16", "infer16.") if form == "autocast" else ("drift16half", "infer16half.")
     # meta.drift16: full resolution, computed when the fixture was made; reference_drift16: from the stored (strided) arrays with the current
     # metric.  The larger of the two estimates is the reference's drift (the strided one is noisy on 5 k pixels, the stored one predates the
     # mask-flip handling of the normal metric).
-    drift = {k: (d["flips"] if "flips" in d else d["p999"]) for k, d in meta["drift16"].items()}
+    drift = {k: (d["flips"] if "flips" in d else d["p999"]) for k, d in meta[key].items()}
     if gold is not None:
-        for k, v in reference_drift16(gold).items():
+        for k, v in reference_drift16(gold, prefix).items():
             drift[k] = max(drift.get(k, 0.0), v)
     for k, own in drift.items():
         band[k] = FP16_FACTOR * max(own, FP16_FLOOR.get(k, 5e-4))
@@ -137,6 +139,7 @@ def check_fp16(out: dict, ref32: dict, band: dict) -> dict:
         val = float(np.quantile(e, 0.999))
         seen[k] = val
         seen[k + ".max"] = float(e.max())
+        seen[k + ".max/band"] = float(e.max()) / band[k]
         assert val <= band[k], (k, val, band[k])
         assert float(e.max()) <= FP16_MAX_FACTOR * band[k], (k, "max", float(e.max()), FP16_MAX_FACTOR * band[k])
     return seen

@@ -108,7 +108,9 @@ def test_master_blob_file_header_roundtrip_and_rejects_foreign_files(tmp_path):
 
 def test_master_blob_records_the_model_version(tmp_path):
     """A MoGe-1 blob (same container, moge_amd/model/v1.py) must not load as MoGe-2 and vice versa: read_blob_header raises ValueError, which
-    from_pretrained's sidecar path turns into a fall-back to the checkpoint.  Blobs written before the field existed are MoGe-2 blobs."""
+    from_pretrained's sidecar path turns into a fall-back to the checkpoint.  Blobs written before the field existed carry no version: their
+    header is accepted by either class (a MoGe-1 sidecar of that age must not be rejected on every load) and a config of the other family
+    fails in from_blob with the same ValueError."""
     import json
     import numpy as np
     from moge_amd.model.v1 import MoGeModel as V1
@@ -130,10 +132,13 @@ def test_master_blob_records_the_model_version(tmp_path):
     write(p1, {"model_version": "v1", "model_config": {"encoder": "dinov2_vits14"}, "nbytes": 64})
     write(p0, {"model_config": cfg, "nbytes": 64})
     assert V2.read_blob_header(p2)[0]["model_version"] == "v2" and V1.read_blob_header(p1)[0]["model_version"] == "v1"
-    V2.read_blob_header(p0)                                   # legacy header = MoGe-2
-    for cls, path in ((V2, p1), (V1, p2), (V1, p0)):
+    V2.read_blob_header(p0); V1.read_blob_header(p0)          # legacy header: no version recorded, either class may try it
+    for cls, path in ((V2, p1), (V1, p2)):
         with pytest.raises(ValueError):
             cls.read_blob_header(path)
+    with pytest.raises(ValueError):
+        V1.from_blob(p0)                                      # ... and a MoGe-2 config does not build a MoGe-1 model
+    assert V2.from_blob(p0)._blob_path == str(p0)
 
 
 def test_v1_rejects_upsample_widths_the_groupnorm_kernels_cannot_run():

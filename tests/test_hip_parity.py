@@ -29,16 +29,19 @@ def MoGeModel():
 _models = {}
 
 
-def get_model(MoGeModel, cfg_name, seed, sane, tmp_path_factory, massive=False):
+def get_model(MoGeModel, cfg_name, seed, sane, tmp_path_factory, massive=False, case=None):
+    """The model of a fixture (`case` given: its config overrides - remap_output, dropped heads, z_bias - apply) or of a named config."""
+    import json
     from oracle import moge_oracle as O
-    key = (cfg_name, seed, sane, massive)
+    from oracle.make_golden import case_config, case_state_dict
+    if case is None:
+        case = dict(config=cfg_name, seed=seed, sane=sane, massive=massive)
+    key = json.dumps({k: case.get(k) for k in ("config", "seed", "sane", "massive", "cfg_override", "z_bias")}, sort_keys=True)
     if key not in _models:
         if len(_models) >= 3:                      # vitl / vitb models hold ~2 GB of device memory each: keep a few, not all
             _models.pop(next(iter(_models)))
-        cfg = O.named_configs()[cfg_name]
-        sd = O.synth_state_dict(cfg, seed, sane)
-        if massive:
-            O.add_massive_activations(sd, cfg)
+        cfg = case_config(case)
+        sd = case_state_dict(case, cfg)
         path = os.path.join(str(tmp_path_factory.mktemp("ckpt")), "model.pt")
         O.save_checkpoint(path, cfg, sd)
         _models[key] = (MoGeModel.from_pretrained(path).to("cuda").eval(), cfg, sd)      # through the reference's loader contract
@@ -61,7 +64,7 @@ def test_fp32_mode_matches_reference_golden_and_oracle(MoGeModel, name, tmp_path
     """Every fixture, incl. the BASELINE-size ones (moge-2-vitl 518x518 T=3600, moge-2-vitb-normal, the 518x1036 / 1036x518 grids 42x85 / 85x42)."""
     from oracle import moge_oracle as O
     case, cfg, sd, x, gold, meta = load_case(name)
-    model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory, bool(case.get("massive")))
+    model, _, _ = get_model(MoGeModel, None, None, None, tmp_path_factory, case=case)
     kw = dict(case["kwargs"]); kw["use_fp16"] = False
     model.onnx_compatible_mode = bool(case.get("onnx"))        # docs/onnx.md: fixtures "tiny_onnx_mode_*" were made with the flag set
     try:
@@ -88,24 +91,25 @@ def test_fp16_mode_within_reference_fp16_band(MoGeModel, name, tmp_path_factory)
     """fp16 mode, both forms the reference has (.half() weights; fp32 weights + use_fp16=True), against the reference's fp32 golden inside
     2x the reference's own fp16 drift on that case."""
     case, cfg, sd, x, gold, meta = load_case(name)
-    model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory, bool(case.get("massive")))
+    model, _, _ = get_model(MoGeModel, None, None, None, tmp_path_factory, case=case)
     kw = dict(case["kwargs"]); kw["use_fp16"] = True
     st = case.get("stride", 1)
-    band = fp16_band(meta, gold)
+    band = {"autocast": fp16_band(meta, gold, "autocast"), "half": fp16_band(meta, gold, "half")}
     g = golden_infer(gold)
     model.onnx_compatible_mode = bool(case.get("onnx"))
     try:
-        out = model.float().infer(x, **kw)             # fp32 weights + use_fp16 (autocast analogue)
-        out_h = model.half().infer(x, **kw)            # .half() weights
+        out = model.float().infer(x, **kw)             # fp32 weights + use_fp16 (autocast analogue: fp32 residual stream)
+        out_h = model.half().infer(x, **kw)            # .half() weights (scripts/infer.py:83-84: the residual stream itself is fp16)
     finally:
         model.float()
         model.onnx_compatible_mode = False
     for tag, o in (("autocast", out), ("half", out_h)):
-        seen = check_fp16(sub(o, st), g, band)
-        print(f"[parity fp16 {tag}] {name}: " + " ".join(f"{k}={v:.1e}/{band.get(k, 0):.1e}" for k, v in seen.items()))
-    # the reference's own fp16 outputs are inside the same band by construction; ours must not be further from them than 2 bands
-    g16 = golden_infer(gold, "infer16.")
-    check_fp16(sub(out_h, st), g16, {k: 2 * v for k, v in band.items()})
+        seen = check_fp16(sub(o, st), g, band[tag])
+        print(f"[parity fp16 {tag}] {name}: " + " ".join(f"{k}={v:.1e}/{band[tag].get(k, 0):.1e}" for k, v in seen.items() if "/" not in k)
+              + " | max/band " + " ".join(f"{k[:-9]}={v:.2f}" for k, v in seen.items() if k.endswith(".max/band")))
+    # the reference's own fp16 outputs are inside the same bands by construction; ours must not be further from them than 2 bands
+    check_fp16(sub(out, st), golden_infer(gold, "infer16."), {k: 2 * v for k, v in band["autocast"].items()})
+    check_fp16(sub(out_h, st), golden_infer(gold, "infer16half."), {k: 2 * v for k, v in band["half"].items()})
 
 
 @pytest.mark.parametrize("name", BIG)
@@ -116,10 +120,10 @@ def test_fp16_throughput_kernels_in_the_model_match_reference_golden(MoGeModel, 
     must (a) stay inside the reference-fp16 band of the fixture and (b) reproduce the single-image result bit for bit."""
     from moge_amd import _lib as L
     case, cfg, sd, x, gold, meta = load_case(name)
-    model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory, bool(case.get("massive")))
+    model, _, _ = get_model(MoGeModel, None, None, None, tmp_path_factory, case=case)
     kw = dict(case["kwargs"]); kw["use_fp16"] = True
     st = case.get("stride", 1)
-    band, g = fp16_band(meta, gold), golden_infer(gold)
+    band, g = fp16_band(meta, gold, "half"), golden_infer(gold)
     try:
         model.half()
         base = model.infer(x, **kw)
@@ -142,6 +146,34 @@ def test_fp16_throughput_kernels_in_the_model_match_reference_golden(MoGeModel, 
                 assert torch.equal(fin, torch.isfinite(a)) and torch.equal(a[fin], b[fin]), f"{k}: {what} differs from the single-image result"
 
 
+def _same(a, b, what):
+    if a.dtype == torch.bool:
+        assert torch.equal(a, b), what
+    else:
+        fin = torch.isfinite(b)
+        assert torch.equal(fin, torch.isfinite(a)) and torch.equal(a[fin], b[fin]), what
+
+
+def test_bench_batch_of_32_distinct_images_matches_its_single_image_results(MoGeModel, tmp_path_factory):
+    """The bench workload itself (BASELINE configs[2]: moge-2-vitl, 32 DISTINCT 518x518 images, .half(), default tokens, two 16-image streams):
+    items 0 / 15 / 16 / 31 - both ends of both half-batch streams - equal their single-image results bit for bit, and item 0 (the fixture's
+    image: torch.rand(32, ...) with seed 0 draws it first) sits inside the reference-.half() band of the golden."""
+    case, cfg, sd, x1, gold, meta = load_case("vitl_518_t3600")
+    model, _, _ = get_model(MoGeModel, None, None, None, tmp_path_factory, case=case)
+    x = torch.rand(32, 3, 518, 518, generator=torch.Generator().manual_seed(0))
+    assert torch.equal(x[:1], x1)
+    try:
+        model.half()
+        batch = model.infer(x)
+        for i in (0, 15, 16, 31):
+            single = model.infer(x[i])
+            for k in single:
+                _same(batch[k][i], single[k], f"{k}: item {i} of the batch of 32 differs from its single-image result")
+    finally:
+        model.float()
+    check_fp16(sub({k: v[:1] for k, v in batch.items()}, case.get("stride", 1)), golden_infer(gold), fp16_band(meta, gold, "half"))
+
+
 def test_fp32_image_into_half_model_equals_prehalved_image(MoGeModel, tmp_path_factory):
     """v2.py:229 `image.to(dtype=self.dtype)`: an fp32 image given to a .half() model is rounded to fp16 inside preprocess_kernel (img_dtype 3);
     the result must equal feeding the explicitly pre-rounded fp16 tensor (img_dtype 1) bit for bit."""
@@ -162,7 +194,7 @@ def test_stage_taps_match_oracle(MoGeModel, tmp_path_factory):
     """Stage boundaries of one forward (fp32 mode): LayerNorm'ed ViT taps, cls token, encoder features, every neck level."""
     from oracle import moge_oracle as O
     case, cfg, sd, x, gold, meta = load_case("tiny_b2_up")
-    model, _, _ = get_model(MoGeModel, case["config"], case["seed"], case["sane"], tmp_path_factory, bool(case.get("massive")))
+    model, _, _ = get_model(MoGeModel, None, None, None, tmp_path_factory, case=case)
     model.float()
     fwd = model.forward(x, case["kwargs"]["num_tokens"])
     tr = {}
@@ -270,10 +302,14 @@ def test_batch_split_streams_are_bit_identical(MoGeModel, tmp_path_factory):
 
 def test_head_streams_are_bit_identical(MoGeModel, tmp_path_factory):
     """Small batches run the decoder heads after the first on their own streams and scratch buffers (model.hip forward_impl,
-    HEAD_STREAMS); same kernels on the same inputs: the result must equal the one-stream result, alone and inside a split batch."""
+    HEAD_STREAMS); same kernels on the same inputs: the result must equal the one-stream result, alone and inside a split batch.
+    HEAD_STREAMS_MAX_B defaults to 1, so the test raises it: B = 3 forks slot 0's streams with a 3-image plan, B = 9 = 4 + 5 forks the head
+    streams, events and scratch triples of BOTH sub-plans (slots 0 and 1) under BATCH_SPLIT."""
+    import ctypes as C
     from moge_amd import _lib as L
     model, cfg, sd = get_model(MoGeModel, "tiny-vits-normal", 0, True, tmp_path_factory)
     try:
+        L.tune("HEAD_STREAMS_MAX_B", 16)
         for B in (1, 3, 9):
             x = torch.rand(B, 3, 84, 112, generator=torch.Generator().manual_seed(11 + B))
             for half in (False, True):
@@ -284,14 +320,22 @@ def test_head_streams_are_bit_identical(MoGeModel, tmp_path_factory):
                 for _ in range(2):                      # twice: the second call reuses streams, events and scratch of the first
                     out = model.infer(x, num_tokens=108)
                     for k in ref:
-                        a, b = out[k], ref[k]
-                        if a.dtype == torch.bool:
-                            assert torch.equal(a, b), k
-                        else:
-                            fin = torch.isfinite(b)
-                            assert torch.equal(fin, torch.isfinite(a)) and torch.equal(a[fin], b[fin]), f"{k}: head streams != one stream (B={B}, half={half})"
+                        _same(out[k], ref[k], f"{k}: head streams != one stream (B={B}, half={half})")
+        # a subset of the outputs (forward with only normal + mask requested: head 0 is skipped, the first REQUESTED head is not head index 0)
+        model.float()
+        x = torch.rand(2, 3, 84, 112, generator=torch.Generator().manual_seed(5)).cuda()
+        full = model.forward(x, 108)
+        for hs in (0, 1):
+            L.tune("HEAD_STREAMS", hs)
+            o = L.Outputs()
+            nrm = torch.empty_like(full["normal"]); mp = torch.empty_like(full["mask"])
+            o.normal, o.mask_prob = nrm.data_ptr(), mp.data_ptr()
+            L.check(L.lib.moge_forward(model._handle, x.data_ptr(), 0, 2, 84, 112, 9, 12, C.byref(o), L.stream_ptr()))
+            torch.cuda.synchronize()
+            assert torch.equal(nrm, full["normal"]) and torch.equal(mp, full["mask"]), f"subset of outputs, HEAD_STREAMS={hs}"
     finally:
         L.tune("HEAD_STREAMS", 1)
+        L.tune("HEAD_STREAMS_MAX_B", 1)
         model.float()
 
 

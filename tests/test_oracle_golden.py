@@ -46,6 +46,9 @@ def test_oracle_matches_reference_golden(name):
         g = gold["forward." + k]
         tol = 1e-3 if ill else 1e-4
         assert rel_err(subsample(k, v.numpy(), st), g, floor=1.0) <= tol * max(1.0, float(np.abs(g).max()) if ill else 1.0), k
+    if meta["focal"] is None:                       # no points head (v2.py:251-281): nothing to recover
+        assert "focal" not in tr and "points" not in out and "depth" not in out and "intrinsics" not in out
+        return
     np.testing.assert_allclose(tr["focal"].numpy(), np.array(meta["focal"], dtype=np.float32), rtol=1e-3 if not ill else 5e-2)
     np.testing.assert_allclose(tr["shift"].numpy(), np.array(meta["shift"], dtype=np.float32), rtol=1e-3, atol=1e-4)
 
@@ -68,11 +71,20 @@ def test_token_grid_matches_survey():
 
 
 def test_fixtures_carry_reference_fp16_outputs_and_drift():
-    """Every fixture holds the reference's own fp16 (autocast) outputs and the drift statistics the fp16 gate is derived from."""
+    """Every fixture holds the reference's own fp16 outputs - autocast (infer16.*) and model.half() (infer16half.*) - and the drift statistics
+    the fp16 gates are derived from."""
     for name in CASE_BY_NAME:
         case, cfg, sd, x, gold, meta = load_case(name)
-        assert {k[8:] for k in gold if k.startswith("infer16.")} == {k[6:] for k in gold if k.startswith("infer.")}, name
-        d = meta["drift16"]
-        assert set(d) == {k[6:] for k in gold if k.startswith("infer.")}
-        if case["sane"]:
-            assert 1e-4 < d["points"]["p999"] < 1e-2 and d["mask"]["flips"] < 2e-3, (name, d)
+        keys = {k[6:] for k in gold if k.startswith("infer.")}
+        assert {k[8:] for k in gold if k.startswith("infer16.")} == keys, name
+        assert {k[12:] for k in gold if k.startswith("infer16half.")} == keys, name
+        remapped = (case.get("cfg_override") or {}).get("remap_output") in ("linear", "sinh")       # depth ~ 0 against the head's noise: large relative drift
+        for d in (meta["drift16"], meta["drift16half"]):
+            assert set(d) == keys
+            if case["sane"] and "points" in d:
+                assert 1e-4 < d["points"]["p999"] < (1e-1 if remapped else 1e-2), (name, d)
+            if case["sane"] and "mask" in d:
+                assert d["mask"]["flips"] < 2e-3, (name, d)
+        # the half model (fp16 residual stream) drifts at least as much as autocast (fp32 residual stream) on the big models
+        if name.startswith("vitl_normal") or name == "vitl_518_t3600":
+            assert meta["drift16half"]["points"]["p999"] > meta["drift16"]["points"]["p999"], name

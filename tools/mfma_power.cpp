@@ -47,6 +47,7 @@ int main() {
     _Float16* h = (_Float16*)malloc(4096 * 16);
     for (int i = 0; i < 4096 * 8; i++) h[i] = (_Float16)(((rand() & 0xffff) / 32768.f - 1.f));
     CK(hipMemcpy(in, h, 4096 * 16, hipMemcpyHostToDevice));
+    const double secs = getenv("MFMA_POWER_SECONDS") ? atof(getenv("MFMA_POWER_SECONDS")) : 0.0;       // > 0: hold every configuration that long (SMI power sampling)
     for (int zero = 0; zero < 2; zero++) {
         if (zero) CK(hipMemset(in, 0, 4096 * 16));
         for (int kind = 0; kind < 2; kind++)
@@ -55,12 +56,20 @@ int main() {
                 hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
                 auto launch = [&]() { if (kind == 0) chain<0><<<256 * 4, wpb>>>(in, out, iters, clk); else chain<1><<<256 * 4, wpb>>>(in, out, iters, clk); };
                 launch(); CK(hipDeviceSynchronize());
-                CK(hipEventRecord(e0)); for (int r = 0; r < 5; r++) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+                int reps = 5;
+                if (secs > 0) {                                   // one timed launch sizes the repeat count
+                    CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    float one; CK(hipEventElapsedTime(&one, e0, e1));
+                    reps = (int)(secs * 1e3 / one) + 1;
+                    printf("  -> holding this configuration for %.1f s (%d launches)\n", secs, reps); fflush(stdout);
+                }
+                CK(hipEventRecord(e0)); for (int r = 0; r < reps; r++) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
                 unsigned long long hc[2]; CK(hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost));
                 const double flops = 256.0 * 4 * (wpb / 64) * (double)iters * (kind == 0 ? 32 * 32768.0 : 64 * 16384.0);
                 printf("%s data, %s, %d waves/WG (x4 WG/CU-slots): %.1f TF/s, shader clock %.0f MHz, cycles/MFMA/SIMD %.1f\n", zero ? "zero  " : "random", kind == 0 ? "32x32x16" : "16x16x32",
                        wpb / 64, flops / (ms * 1e-3) / 1e12, 100.0 * hc[0] / hc[1], (double)hc[0] / (iters * (kind == 0 ? 32.0 : 64.0)));
+                fflush(stdout);
             }
     }
     return 0;

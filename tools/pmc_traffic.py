@@ -56,6 +56,19 @@ def main(tag):
                   "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); Infinity-Cache hits are "
                   "counted, so this is fabric traffic = an upper bound on HBM bytes",
     }
+    # which kernel source the passes measured (bench.py flags the number as stale when csrc/gemm_pp.hip has changed since): the hash
+    # tools/profile_round.sh recorded on the GPU box, else the tree's (run this right after the profile)
+    import hashlib
+    import subprocess
+    hpath = os.path.join(ROOT, "profiles", f"{tag}_source_hash.txt")
+    if os.path.exists(hpath):
+        out["gemm_pp_sha256_16"] = open(hpath).read().split()[0][:16]
+    else:
+        out["gemm_pp_sha256_16"] = hashlib.sha256(open(os.path.join(ROOT, "moge_amd", "csrc", "gemm_pp.hip"), "rb").read()).hexdigest()[:16]
+    try:
+        out["git_commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        out["git_commit"] = None
     with open(os.path.join(ROOT, "moge_amd", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))

@@ -20,6 +20,7 @@ done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT \
   --kernel-trace --output-format csv -d $out/pmc_MFMA -o pmc -- $CMD > $out/pmc_MFMA.log 2>&1
 python3 tools/pmc_summary.py $out/pmc_MFMA > $out/pmc_MFMA.csv
+sha256sum moge_amd/csrc/gemm_pp.hip > $out/source_hash.txt
 grep -h '"metric"' $out/trace.log | tail -1 > $out/bench_under_rocprof.json
 rm -rf $out/trace $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_MFMA     # keep the summaries only (raw CSVs are tens of MB)
 ls -la $out
