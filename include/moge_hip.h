@@ -37,8 +37,11 @@ typedef enum moge_status {
 } moge_status;
 
 typedef enum moge_precision {
-    MOGE_FP32 = 0,   /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity mode */
-    MOGE_FP16 = 1    /* fp16 storage, fp32 accumulate (v_mfma_f32_16x16x32_f16): the throughput mode */
+    MOGE_FP32 = 0,        /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity mode */
+    MOGE_FP16 = 1,        /* fp16 storage, fp32 accumulate (v_mfma_f32_16x16x32_f16), fp32 residual stream: fp32 weights + use_fp16=True, i.e. the
+                           * reference under torch.autocast (v2.py:241: LayerNorm / residual adds stay fp32 there) */
+    MOGE_FP16_HALF = 2    /* the same kernels and packed weights with the residual stream itself in fp16: `model.half()` (scripts/infer.py:83-84,
+                           * block.py:110-112 on half tensors) - 4 instead of 10 bytes per element in the proj / fc2 epilogues */
 } moge_precision;
 
 typedef enum moge_remap { MOGE_REMAP_LINEAR = 0, MOGE_REMAP_SINH = 1, MOGE_REMAP_EXP = 2, MOGE_REMAP_SINH_EXP = 3 } moge_remap;
@@ -233,6 +236,8 @@ int moge_test_gemm(int precision, const float* A, const float* W, const float* b
  *   MOGE_TG_STORE  out[m][n]  = act(lnfold(acc) + bias[n] (+ wu[n] u(x) + wv[n] v(y)))            attention.py:72, mlp.py:35, modules.py:128-131
  *   MOGE_TG_RESID  xres[m][n] += gamma[n] (acc + bias[n]); optional x16_out (fp16 copy, returned as fp32) and ln_part_out[m][N/32][2]
  *                  = (sum, sum of squares) of every 32-column group of the updated row               block.py:111-112, layer_scale.py:27
+ *                  xres == NULL: the fp16 residual stream of a `.half()` model - x16_out is IN / OUT (fp32 values, rounded to fp16 on the
+ *                  way in): x16 <- fp16(x16 + gamma (acc + bias)); ln_part_out (optional) = the statistics of the ROUNDED row
  *   MOGE_TG_QKV    q/k/v_out (B,nh,Ntok,64) = head-major split of lnfold(acc) + bias, q scaled by qscale          attention.py:72-74
  *   MOGE_TG_CONVT  out (B,2 pixH,2 pixW,Cout): n = (dy*2+dx)*Cout + co of pixel m = (b*pixH + y)*pixW + x goes to (2y+dy, 2x+dx)   modules.py:162
  * lnfold(acc) = ln_mr[m][1] * (acc - ln_mr[m][0] * ln_c[n]) when ln_mr != NULL (LayerNorm folded into the consumer GEMM), else acc.

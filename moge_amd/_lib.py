@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libmoge_hip.so")
 
 MOGE_MAX_TAPS = 8
 MOGE_LEVELS = 5
-FP32, FP16 = 0, 1
+FP32, FP16, FP16_HALF = 0, 1, 2        # moge_precision: FP16 = fp32 weights under autocast (fp32 residual stream), FP16_HALF = model.half() (fp16 residual stream)
 HEAD_POINTS, HEAD_NORMAL, HEAD_MASK, HEAD_SCALE = 1, 2, 4, 8
 FORCE_PROJECTION, APPLY_MASK = 1, 2
 REMAP = {"linear": 0, "sinh": 1, "exp": 2, "sinh_exp": 3}

@@ -33,7 +33,7 @@ def _stale(target: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True, experiments: bool = False) -> str:
-    """experiments=True adds -DMOGE_EXPERIMENTS: the superseded / rejected kernel variants under csrc/experiments/ are compiled in and become
+    """experiments=True adds -DMOGE_EXPERIMENTS: the superseded / rejected kernel variants under tools/experiments/ are compiled in and become
     selectable through MOGE_PP_EXP / MOGE_ATTN_EXP / ... (tools/kbench A-B timing only; the product library is built without them)."""
     hipcc = _hipcc()
     flags = FLAGS + (["-DMOGE_EXPERIMENTS"] if experiments else [])
@@ -50,7 +50,8 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     if experiments:
-        hdrs += [os.path.join(CSRC, "experiments", f) for f in os.listdir(os.path.join(CSRC, "experiments"))]
+        exp = os.path.join(os.path.dirname(HERE), "tools", "experiments")
+        hdrs += [os.path.join(exp, f) for f in os.listdir(exp)]
     jobs = []
     objs = []
     for src in SOURCES:

@@ -48,7 +48,7 @@ constexpr int AP_STAGE = 16384;          // K tile 8 KiB + V tile 8 KiB
 constexpr float AP_PSUM_LIMIT = 16384.f;
 
 #ifdef MOGE_EXPERIMENTS
-#include "experiments/attention_pp_exp.inc"     // the v_mfma_f32_32x32x16_f16 form of this kernel (tools/kbench A-B builds only)
+#include "../../tools/experiments/attention_pp_exp.inc"     // the v_mfma_f32_32x32x16_f16 form of this kernel (tools/kbench A-B builds only)
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------------

@@ -230,8 +230,8 @@ int launch_cls_row(float* x, const float* cls, const float* pos, int B, int Ntok
 //   tap  : (get_intermediate_layers, vision_transformer.py:321-324) token 0 -> cls_out[b*D + col] (fp32, optional),
 //          token t>0 -> out[(b*Np + t-1)*ldo + coloff + col]  (the K-concatenated output-projection operand)
 // --------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+template <typename T, typename TX = float>      // TX: element type of the residual stream (float; f16 for `.half()` models, whose stream is fp16)
+__global__ __launch_bounds__(256) void layernorm_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                         T* __restrict__ out, float* __restrict__ cls_out, long rowsN, int D, int ldo,
                                                         int coloff, int tap_mode, int Ntok) {
     // One wave per row, LN_RPW consecutive rows per wave: a lane owns columns i*256 + 4*lane .. +3 (16-byte loads: a wave
@@ -251,13 +251,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int r = 0; r < LN_RPW; r++) {
         const long row = row0 + r;
         if (row >= rowsN) break;
-        const float* xr = x + row * (long)D;
+        const TX* xr = x + row * (long)D;
         f32x4 v[4];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int col = i * 256 + lane * 4;
-            if (i < nit && col < D) { v[i] = *reinterpret_cast<const f32x4*>(xr + col); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+            if (i < nit && col < D) {
+                float t[4];
+                load4(xr + col, t);
+                v[i] = f32x4{t[0], t[1], t[2], t[3]};
+                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -395,7 +400,7 @@ int launch_fold_ln(const float* W, const float* g, const float* beta, const floa
 template int launch_fold_ln<f16>(const float*, const float*, const float*, const float*, void*, float*, float*, int, int, hipStream_t);
 
 #ifdef MOGE_EXPERIMENTS
-#include "experiments/layernorm_lr_exp.inc"     // low-register LayerNorm (a measured, rejected co-residency experiment)
+#include "../../tools/experiments/layernorm_lr_exp.inc"     // low-register LayerNorm (a measured, rejected co-residency experiment)
 #endif
 
 template <typename T>
@@ -415,6 +420,15 @@ int launch_layernorm(const float* x, const float* w, const float* b, void* out, 
 }
 template int launch_layernorm<f16>(const float*, const float*, const float*, void*, float*, long, int, int, int, int, int, hipStream_t);
 template int launch_layernorm<float>(const float*, const float*, const float*, void*, float*, long, int, int, int, int, int, hipStream_t);
+
+// the same LayerNorm on an fp16 residual stream (`.half()` models: the final-norm taps, vision_transformer.py:322)
+int launch_layernorm_x16(const void* x16, const float* w, const float* b, void* out, float* cls_out, long rowsN, int D, int ldo, int coloff,
+                         int tap_mode, int Ntok, hipStream_t st) {
+    if (D % 4 != 0 || D > 1024 || (ldo & 3) || (coloff & 3)) return -1;
+    hipLaunchKernelGGL((layernorm_kernel<f16, f16>), dim3((unsigned)((rowsN + 15) / 16)), dim3(256), 0, st, (const f16*)x16, w, b, (f16*)out, cls_out, rowsN, D, ldo,
+                       coloff, tap_mode, Ntok);
+    return (int)hipGetLastError();
+}
 
 // --------------------------------------------------------------------------------------------
 // small helpers: fp32 <-> storage conversions (weight packing, test entry points, debug taps)

@@ -24,6 +24,19 @@ template <typename T>
 __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float v0, float v1, float v2, float v3) {
     if (m >= g.M || n >= g.N) return;
     float v[4] = {v0, v1, v2, v3};
+    if (g.epi == EPI_RESID && !g.xres) {
+        // fp16 residual stream (`.half()` models; gemm_pp.hip EPK_RESID16): x16 <- fp16(fp32(x16) + gamma (acc + bias)), no statistics on this path
+        f16* p = reinterpret_cast<f16*>(g.x16) + (size_t)m * g.ldc + n;
+        const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+        f16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = (f16)((float)h[i] + resid_term(gm[i], v[i], b[i]));
+        *reinterpret_cast<f16x4*>(p) = o;
+        return;
+    }
     if (g.epi == EPI_RESID) {
         // x[m][n] += gamma[n] * (acc + bias[n]); same operation order as gemm_pp.hip (resid_term, then one add)
         float* p = g.xres + (size_t)m * g.ldc + n;
@@ -129,6 +142,21 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float
     }
 }
 
+// fp16 residual stream, one quad: x16[m][n..n+3] <- fp16(fp32(x16) + gamma (acc + bias)); returns the ROUNDED values (what the LN-fold statistics
+// are taken from in this mode, as gemm_pp.hip's pp_resid16_store does)
+__device__ __forceinline__ f32x4 resid16_quad(const GemmArgs& g, int m, int n, const float* a) {
+    f16* p = reinterpret_cast<f16*>(g.x16) + (size_t)m * g.ldc + n;
+    const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+    f16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = (f16)((float)h[i] + resid_term(gm[i], a[i], b[i]));
+    *reinterpret_cast<f16x4*>(p) = o;
+    return f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+}
+
 // One 32 x 32 accumulator tile of a lane: row m, quads at columns nb + 8q (nb already includes 4*hi).  EPI_RESID with the LN-fold
 // producer outputs (GemmArgs::x16 / ln_part): residual update + fp16 copy + the (sum, sum of squares) of the row's 32-column group with the
 // SAME summation tree as gemm_pp.hip's pp_resid_rows (quad sums, then pairs 2q/2q+1 across the two half-waves, then (0+1)+(2+3)), so the
@@ -142,7 +170,10 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, int m, int nb
         for (int q = 0; q < 4; q++) {
             const int n = nb + 8 * q;
             f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
+            if (ok && !g.xres) {
+                const float aq[4] = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+                x = resid16_quad(g, m, n, aq);
+            } else if (ok) {
                 float* p = g.xres + (size_t)m * g.ldc + n;
                 x = *reinterpret_cast<f32x4*>(p);
                 const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
@@ -159,7 +190,7 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, int m, int nb
             t2[q] = s2 + __shfl_xor(s2, 32);
         }
         const float u1 = (t1[0] + t1[1]) + (t1[2] + t1[3]), u2 = (t2[0] + t2[1]) + (t2[2] + t2[3]);
-        if (hi == 0 && ok) *reinterpret_cast<f32x2*>(g.ln_part + ((size_t)m * (g.N >> 5) + (nb >> 5)) * 2) = f32x2{u1, u2};
+        if (hi == 0 && ok && g.ln_part) *reinterpret_cast<f32x2*>(g.ln_part + ((size_t)m * (g.N >> 5) + (nb >> 5)) * 2) = f32x2{u1, u2};
         return;
     }
 #pragma unroll
@@ -179,7 +210,10 @@ __device__ __forceinline__ void epilogue_pair16(const GemmArgs& g, int m, int nb
             const f32x4& a = jh ? a1 : a0;
             const int n = nb32 + jh * 16 + 4 * g4;
             f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
+            if (ok && !g.xres) {
+                const float aq[4] = {a[0], a[1], a[2], a[3]};
+                x = resid16_quad(g, m, n, aq);
+            } else if (ok) {
                 float* p = g.xres + (size_t)m * g.ldc + n;
                 x = *reinterpret_cast<f32x4*>(p);
                 const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
@@ -196,7 +230,7 @@ __device__ __forceinline__ void epilogue_pair16(const GemmArgs& g, int m, int nb
             s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
             u1[jh] = s1; u2[jh] = s2;
         }
-        if (g4 == 0 && ok) *reinterpret_cast<f32x2*>(g.ln_part + ((size_t)m * (g.N >> 5) + (nb32 >> 5)) * 2) = f32x2{u1[0] + u1[1], u2[0] + u2[1]};
+        if (g4 == 0 && ok && g.ln_part) *reinterpret_cast<f32x2*>(g.ln_part + ((size_t)m * (g.N >> 5) + (nb32 >> 5)) * 2) = f32x2{u1[0] + u1[1], u2[0] + u2[1]};
         return;
     }
     epilogue4<T>(g, m, nb32 + 4 * g4, a0[0], a0[1], a0[2], a0[3]);

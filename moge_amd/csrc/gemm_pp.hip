@@ -32,7 +32,8 @@
 // The flavour is a COMPILE-TIME parameter: with run-time switches inside the 128-accumulator loops the compiler emitted
 // ~1000 register copies and ~100 branches per wave (measured 13-45k cycles per tile against a 43k-cycle K=1024 main loop).
 enum { EPK_RESID = 0, EPK_STORE = 1, EPK_GELU = 2, EPK_QKV = 3, EPK_CONVT = 4, EPK_UV = 5, EPK_RELU = 6,
-       EPK_GELU_LN = 7, EPK_QKV_LN = 8 };        // _LN: consumer of a folded LayerNorm (GemmArgs::ln_mr), otherwise as GELU / QKV
+       EPK_GELU_LN = 7, EPK_QKV_LN = 8,          // _LN: consumer of a folded LayerNorm (GemmArgs::ln_mr), otherwise as GELU / QKV
+       EPK_RESID16 = 9 };                        // RESID on an fp16 residual stream (GemmArgs::xres == nullptr: x16 IS the stream; `.half()` models)
 template <int EPK> struct EpkBase { static constexpr int K = EPK == EPK_GELU_LN ? EPK_GELU : (EPK == EPK_QKV_LN ? EPK_QKV : EPK);
                                     static constexpr bool FOLD = EPK == EPK_GELU_LN || EPK == EPK_QKV_LN; };
 
@@ -102,6 +103,84 @@ __device__ __forceinline__ void pp_resid_store(const ResidBufs& rb, bool fold, i
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{s1, s2}), rb.part, (int)(cc ? p0 : p0 + (unsigned)it * 8u * rb.npart8), 0, 0);
         }
     }
+}
+
+// ---- fp16 residual stream (EPK_RESID16) ----------------------------------------------------------------------------------------------
+// `model.half()` keeps the residual stream itself in fp16 (block.py:110-112 on half tensors; scripts/infer.py:83-84): x16 is read, updated and
+// written in place - 4 bytes per element instead of the 10 of the fp32 stream + fp16 copy - and the LN-fold statistics are taken from the
+// ROUNDED values (the operand the consumer GEMM reads).  x_new = fp16(fp32(x_old) + gamma (acc + bias)): one rounding, where the reference
+// rounds the projection, the LayerScale product and the sum separately.
+// Staging: PROWS rows x 256 B (the wave's 64 fp32 columns), 16-byte chunks XOR-swizzled by row & 15; a lane owns 8 consecutive columns of
+// rows rr, rr + 8, ...: one 16-byte load and one 16-byte store per row, full 128-byte row segments.  Summation tree of the statistics = the
+// fp32 flavour's (quads, pairs of quads, 1-2-4 butterfly: here the first pair is lane-local), so gemm.hip's latency kernels agree bit for bit.
+struct Resid16Bufs {
+    __amdgpu_buffer_rsrc_t x16, part;
+    unsigned ldc2, npart8;
+};
+__device__ __forceinline__ Resid16Bufs pp_resid16_bufs(const GemmArgs& g) {
+    Resid16Bufs r;
+    r.ldc2 = (unsigned)g.ldc * 2u; r.npart8 = (unsigned)(g.N >> 5) * 8u;
+    r.x16 = __builtin_amdgcn_make_buffer_rsrc(g.x16, 0, (int)((unsigned)g.M * r.ldc2), 0x00020000);
+    r.part = __builtin_amdgcn_make_buffer_rsrc(g.ln_part, 0, g.ln_part ? (int)((unsigned)g.M * r.npart8) : 0, 0x00020000);
+    return r;
+}
+template <int PROWS>
+__device__ __forceinline__ void pp_resid16_load(const Resid16Bufs& rb, int lane, int mw, int ncol, u32x4 (&xv)[PROWS / 8]) {
+    const int rr = lane >> 3, cc = lane & 7;
+    const unsigned off0 = (unsigned)(mw + rr) * rb.ldc2 + (unsigned)(ncol + cc * 8) * 2u;
+#pragma unroll
+    for (int it = 0; it < PROWS / 8; it++) xv[it] = __builtin_amdgcn_raw_buffer_load_b128(rb.x16, (int)(off0 + (unsigned)it * 8u * rb.ldc2), 0, 0);
+}
+// x <- fp16(x + staged update); returns the packed result in xv
+template <int PROWS>
+__device__ __forceinline__ void pp_resid16_add(const char* R, int lane, u32x4 (&xv)[PROWS / 8]) {
+    const int rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+    for (int it = 0; it < PROWS / 8; it++) {
+        const int row = it * 8 + rr;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(R + row * 256 + (((2 * cc) ^ (row & 15)) << 4));
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(R + row * 256 + (((2 * cc + 1) ^ (row & 15)) << 4));
+        const f16x8 h = __builtin_bit_cast(f16x8, xv[it]);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { o[e] = (f16)((float)h[e] + v0[e]); o[4 + e] = (f16)((float)h[4 + e] + v1[e]); }
+        xv[it] = __builtin_bit_cast(u32x4, o);
+    }
+}
+template <int PROWS>
+__device__ __forceinline__ void pp_resid16_store(const Resid16Bufs& rb, bool fold, int lane, int mw, int ncol, const u32x4 (&xv)[PROWS / 8]) {
+    const int rr = lane >> 3, cc = lane & 7;
+    const unsigned off0 = (unsigned)(mw + rr) * rb.ldc2 + (unsigned)(ncol + cc * 8) * 2u;
+#pragma unroll
+    for (int it = 0; it < PROWS / 8; it++) __builtin_amdgcn_raw_buffer_store_b128(xv[it], rb.x16, (int)(off0 + (unsigned)it * 8u * rb.ldc2), 0, 0);
+    if (fold) {
+        // one (sum, sum of squares) pair per row and 32-column group: lanes cc = 0 and 4 store, the others point past the descriptor
+        const unsigned p0 = (cc & 3) ? 0xffffff00u : (unsigned)(mw + rr) * rb.npart8 + (unsigned)((ncol + cc * 8) >> 5) * 8u;
+#pragma unroll
+        for (int it = 0; it < PROWS / 8; it++) {
+            const f16x8 h = __builtin_bit_cast(f16x8, xv[it]);
+            const f32x4 a = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]}, b = {(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+            float a1, a2, b1, b2;
+            ln_quad_sums(a, a1, a2);
+            ln_quad_sums(b, b1, b2);
+            float s1 = a1 + b1, s2 = a2 + b2;
+#pragma unroll
+            for (int o = 1; o < 4; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{s1, s2}), rb.part, (int)((cc & 3) ? p0 : p0 + (unsigned)it * 8u * rb.npart8), 0, 0);
+        }
+    }
+}
+// stage the 16-row blocks i0 .. i0 + PROWS / 16 - 1 of a wave's accumulators (all 64 columns) into R
+template <int PROWS, int NJT>
+__device__ __forceinline__ void pp_resid16_stage(char* R, const f32x4 (&acc)[8][NJT], int j0, int i0, int lane) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int ii = 0; ii < PROWS / 16; ii++)
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int row = ii * 16 + l15;
+            *reinterpret_cast<f32x4*>(R + row * 256 + (((jj * 4 + g4) ^ (row & 15)) << 4)) = acc[i0 + ii][j0 + jj];
+        }
 }
 
 template <int WROWS, int EPK>
@@ -177,7 +256,7 @@ __device__ __forceinline__ f16x4 pp_quad_f16(const f32x4& a, const f32x4& b, flo
 }
 
 #ifdef MOGE_EXPERIMENTS
-#include "experiments/gemm_pp_exp.inc"     // 32x32x16-form kernels, 64-byte-row kernels: tools/kbench A-B builds only
+#include "../../tools/experiments/gemm_pp_exp.inc"     // 32x32x16-form kernels, 64-byte-row kernels: tools/kbench A-B builds only
 #endif
 
 // ---- 16x16x32 accumulators acc[i][j0 + jj] (128 rows x 64 columns of the wave's tile): row i*16 + (lane & 15), columns jj*16 + 4*(lane >> 4) .. +3 ----
@@ -190,7 +269,31 @@ __device__ __forceinline__ void pp_epilogue16(const GemmArgs& g, f32x4 (&acc)[8]
     char* R = smem + wave * (WROWS * 128);
     const int M = g.M;
 
-    if constexpr (EPK == EPK_RESID) {
+    if constexpr (EPK == EPK_RESID16) {
+        // two passes of 64 rows x 64 columns (256 B per staging row = the wave's 16 KiB)
+        constexpr int PROWS = 64;
+        const Resid16Bufs rb = pp_resid16_bufs(g);
+        const bool fold = g.ln_part != nullptr;
+        u32x4 x0[PROWS / 8], x1[PROWS / 8];
+        pp_resid16_load<PROWS>(rb, lane, mw, nw, x0);
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int n = nw + jj * 16 + 4 * g4;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(g.gamma + n);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[i][j0 + jj][e] = resid_term(gm[e], acc[i][j0 + jj][e], b[e]);
+        }
+        pp_resid16_stage<PROWS, NJT>(R, acc, j0, 0, lane);
+        pp_resid16_add<PROWS>(R, lane, x0);
+        pp_resid16_load<PROWS>(rb, lane, mw + PROWS, nw, x1);
+        pp_resid16_store<PROWS>(rb, fold, lane, mw, nw, x0);
+        pp_resid16_stage<PROWS, NJT>(R, acc, j0, PROWS / 16, lane);
+        pp_resid16_add<PROWS>(R, lane, x1);
+        pp_resid16_store<PROWS>(rb, fold, lane, mw + PROWS, nw, x1);
+    } else if constexpr (EPK == EPK_RESID) {
         // two passes of 32 fp32 columns (128 B per staging row); pass 1's row loads are in flight before pass 0's stores are issued.
         // gamma (acc + bias) is applied IN PLACE to all accumulators first: a bias / gamma load issued after the first stores would sit
         // behind them in the in-order vmcnt queue
@@ -277,7 +380,7 @@ __device__ __forceinline__ void pp_epilogue16(const GemmArgs& g, f32x4 (&acc)[8]
 }
 
 #ifdef MOGE_EXPERIMENTS
-#include "experiments/gemm_pp4w16_exp.inc"     // 4-wave form (128 x 128 per wave): slower on every hot-path shape, tools/kbench A-B builds only
+#include "../../tools/experiments/gemm_pp4w16_exp.inc"     // 4-wave form (128 x 128 per wave): slower on every hot-path shape, tools/kbench A-B builds only
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -436,6 +539,8 @@ template <int EPKX, int SROWS> struct PpEpiPre {
     float mu[8], rs[8], u[8], vv[8];
     f32x4 x0[SROWS / 8];
     ResidBufs rb;
+    u32x4 h0[SROWS / 16];               // EPK_RESID16: first pass of SROWS / 2 rows x 64 columns
+    Resid16Bufs rb16;
     __amdgpu_buffer_rsrc_t ob;
     float scale;
     bool fold;
@@ -448,7 +553,17 @@ __device__ __forceinline__ void pp_epi_pre(const GemmArgs& g, PpEpiPre<EPKX, SRO
     constexpr bool FOLD = EpkBase<EPKX>::FOLD;
     const int l15 = lane & 15, g4 = lane >> 4;
     const int M = g.M;
-    if constexpr (EPK == EPK_RESID) {
+    if constexpr (EPK == EPK_RESID16) {
+        P.rb16 = pp_resid16_bufs(g);
+        P.fold = g.ln_part != nullptr;
+        pp_resid16_load<SROWS / 2>(P.rb16, lane, mw, nw, P.h0);
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int n = nw + jj * 16 + 4 * g4;
+            P.bq[jj] = *reinterpret_cast<const f32x4*>(g.bias + n);
+            P.lq[jj] = *reinterpret_cast<const f32x4*>(g.gamma + n);
+        }
+    } else if constexpr (EPK == EPK_RESID) {
         P.rb = pp_resid_bufs(g);
         P.fold = g.x16 != nullptr;
         pp_resid_load<SROWS>(P.rb, lane, mw, nw, P.x0);
@@ -561,7 +676,9 @@ __device__ __forceinline__ void pp_store_rows_buf(const GemmArgs& g, __amdgpu_bu
 // mid(): called once, at the first point behind which the epilogue has no load left that the COMPILER waits for (it places s_waitcnt vmcnt(0)
 // in front of the first use of any ordinary load while LDS-DMA is in flight): the kernel requests the next tile's first pieces there.
 // Behind it follow PpTrail<> unconditional stores per lane.
-template <int EPKX, int SROWS> struct PpTrail { static constexpr int N = EpkBase<EPKX>::K == EPK_RESID ? SROWS / 8 : 16; };
+template <int EPKX, int SROWS> struct PpTrail {
+    static constexpr int N = EpkBase<EPKX>::K == EPK_RESID ? SROWS / 8 : (EpkBase<EPKX>::K == EPK_RESID16 ? SROWS / 16 : 16);      // (a LOWER bound is safe: the head wait then also covers some stores)
+};
 template <int EPKX, int SROWS, class Mid>
 __device__ __forceinline__ void pp_epi_run(const GemmArgs& g, f32x4 (&acc)[8][4], PpEpiPre<EPKX, SROWS>& P, char* R, int lane, int mw, int nw, Mid mid) {
     constexpr int EPK = EpkBase<EPKX>::K;
@@ -569,7 +686,27 @@ __device__ __forceinline__ void pp_epi_run(const GemmArgs& g, f32x4 (&acc)[8][4]
     constexpr int NI = SROWS / 16, NP = 128 / SROWS;
     const int l15 = lane & 15, g4 = lane >> 4;
 
-    if constexpr (EPK == EPK_RESID) {
+    if constexpr (EPK == EPK_RESID16) {
+        // 128 / PROWS passes of PROWS = SROWS / 2 rows x all 64 columns (256-byte staging rows fill the wave's SROWS x 128 B region)
+        constexpr int PROWS = SROWS / 2, NPASS = 128 / PROWS;
+        u32x4 h1[PROWS / 8];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[i][jj][e] = resid_term(P.lq[jj][e], acc[i][jj][e], P.bq[jj][e]);
+#pragma unroll
+        for (int p = 0; p < NPASS; p++) {
+            u32x4 (&xc)[PROWS / 8] = (p & 1) ? h1 : P.h0;
+            u32x4 (&xn)[PROWS / 8] = (p & 1) ? P.h0 : h1;
+            pp_resid16_stage<PROWS, 4>(R, acc, 0, p * (PROWS / 16), lane);
+            pp_resid16_add<PROWS>(R, lane, xc);
+            if (p + 1 < NPASS) pp_resid16_load<PROWS>(P.rb16, lane, mw + (p + 1) * PROWS, nw, xn);
+            else mid();
+            pp_resid16_store<PROWS>(P.rb16, P.fold, lane, mw + p * PROWS, nw, xc);
+        }
+    } else if constexpr (EPK == EPK_RESID) {
         f32x4 x1[SROWS / 8];
 #pragma unroll
         for (int jj = 0; jj < 4; jj++)
@@ -931,7 +1068,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
             // request the next tile's first pieces - UNCONDITIONALLY (after the last tile: this tile's own pieces again, never read): a branch
             // here would merge into a conservative wait as well
             setup(more ? li : li - wgs_x);
-            if constexpr (EpkBase<EPK>::K != EPK_RESID) __builtin_amdgcn_s_waitcnt(0x0F70);      // (RESID: the last row loads were waited for by the add in front)
+            if constexpr (EpkBase<EPK>::K != EPK_RESID && EpkBase<EPK>::K != EPK_RESID16) __builtin_amdgcn_s_waitcnt(0x0F70);      // (RESID: the last row loads were waited for by the add in front)
             prefetch();
             asm volatile("" ::: "memory");
         };
@@ -1031,7 +1168,8 @@ bool gemm_pp_eligible(const GemmArgs& g) {
         if (!g.ln_c || !g.bias) return false;
         if (!(g.epi == EPI_QKV || (g.epi == EPI_STORE && g.act == ACT_GELU && !g.uv.wu))) return false;
     }
-    if (g.x16 && (g.epi != EPI_RESID || !g.ln_part)) return false;
+    if (g.x16 && (g.epi != EPI_RESID || (!g.ln_part && g.xres))) return false;                      // (fp16 stream, xres == nullptr: the statistics are optional)
+    if (g.epi == EPI_RESID && !g.xres && !g.x16) return false;
     if (g.epi == EPI_RESID && (size_t)g.M * (size_t)g.ldc * 4 >= 0xffffff00ull) return false;       // 32-bit buffer offsets in the RESID epilogue
     switch (g.epi) {
     case EPI_STORE: return (g.ldc & 7) == 0 && (!g.uv.wu || g.bias);
@@ -1044,7 +1182,7 @@ bool gemm_pp_eligible(const GemmArgs& g) {
 
 static int epilogue_kind(const GemmArgs& g) {
     switch (g.epi) {
-    case EPI_RESID: return EPK_RESID;
+    case EPI_RESID: return g.xres ? EPK_RESID : EPK_RESID16;
     case EPI_QKV: return g.ln_mr ? EPK_QKV_LN : EPK_QKV;
     case EPI_CONVT: return EPK_CONVT;
     default: break;
@@ -1097,6 +1235,7 @@ int launch_gemm_pp(const GemmArgs& g0, hipStream_t st) {
     }
     switch (epilogue_kind(g)) {
     case EPK_RESID: return launch_pp_any<EPK_RESID>(g, st);
+    case EPK_RESID16: return launch_pp_any<EPK_RESID16>(g, st);
     case EPK_QKV: return launch_pp_any<EPK_QKV>(g, st);
     case EPK_CONVT: return launch_pp_any<EPK_CONVT>(g, st);
     case EPK_UV: return launch_pp_any<EPK_UV>(g, st);

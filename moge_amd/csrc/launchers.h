@@ -22,6 +22,8 @@ int launch_cls_row(float* x, const float* cls, const float* pos, int B, int Ntok
 template <typename T>
 int launch_layernorm(const float* x, const float* w, const float* b, void* out, float* cls_out, long rowsN, int D, int ldo, int coloff,
                      int tap_mode, int Ntok, hipStream_t st);
+int launch_layernorm_x16(const void* x16, const float* w, const float* b, void* out, float* cls_out, long rowsN, int D, int ldo, int coloff,
+                         int tap_mode, int Ntok, hipStream_t st);        // fp16 residual stream in, fp16 out (cls_out fp32)
 template <typename TS, typename TD> int launch_convert(const void* s, void* d, long n, hipStream_t st);
 template <typename TD>
 int launch_repack(const float* src, void* dst, int n0, int n1, int n2, int n3, long ss0, long ss1, long ss2, long ss3, long ds0, long ds1,

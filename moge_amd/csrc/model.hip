@@ -68,7 +68,8 @@ struct moge_handle {
     size_t pk_elems = 0;
     void* packed[2] = {nullptr, nullptr};
     bool pk_ready[2] = {false, false};
-    int prec = MOGE_FP32;
+    int prec = MOGE_FP32;       // MOGE_FP32 / MOGE_FP16: storage type of the kernels (index into packed[])
+    bool half_resid = false;    // MOGE_FP16_HALF: prec == MOGE_FP16 with the residual stream in fp16 (`.half()` semantics)
     // workspace
     char* ws = nullptr;
     size_t ws_bytes = 0;
@@ -180,7 +181,13 @@ static void build_tables_v2_decoder(moge_handle* h) {
             if (neck) {
                 aadd(h, name + S(".in%d.wu", l), cl);
                 aadd(h, name + S(".in%d.wv", l), cl);
-                if (l == 0) padd(h, name + ".in0.w", (int64_t)cl * c0);
+                if (l == 0) {
+                    padd(h, name + ".in0.w", (int64_t)cl * c0);
+                    // fp16 path: the summed output projections and this 1x1 block have no non-linearity between them (modules.py:128-131,
+                    // 245): composed at pack time into ONE [c0][n_taps * D] matrix applied to the K-concatenated taps (COMPOSE, below)
+                    padd(h, name + ".in0c.w", (int64_t)cl * c.n_taps * D);
+                    aadd(h, name + ".in0c.bias", cl);
+                }
                 else aadd(h, name + S(".rs%d.bias2", l - 1), cl);
             } else {
                 padd(h, name + S(".in%d.w", l), (int64_t)cl * cl);
@@ -197,6 +204,12 @@ static void build_tables_v2_decoder(moge_handle* h) {
                 padd(h, name + S(".rs%d.w3", l), (int64_t)co * 9 * co);
                 aadd(h, name + S(".rs%d.biasT", l), 4 * co);
                 if (!neck) aadd(h, name + S(".rs%d.bias_in", l), co);     // resampler conv bias + next level's input-block bias (fused path)
+                if (!neck && l == 0 && nres[0] == 0) {
+                    // fp16 path: a head without level-0 residual blocks applies its ConvTranspose2d directly to its level-0 input block
+                    // (modules.py:245-250): both linear, composed at pack time into one [4 co][c0] matrix on the neck's level-0 map
+                    padd(h, name + ".rs0.wTc", (int64_t)4 * co * ci);
+                    aadd(h, name + ".rs0.biasTc", 4 * co);
+                }
             } else {
                 tadd(h, name + S(".resamplers.%d.1.weight", l), (int64_t)co * ci * 9);
                 tadd(h, name + S(".resamplers.%d.1.bias", l), co);
@@ -340,7 +353,91 @@ static int build_aux(moge_handle* h, hipStream_t st) {
             }
         }
     if (ndot > 0) LCHK(launch_pack_dot_table(A(h, "neck.dot.w2cat"), 4 * ndot, ndot, A(h, "neck.dot"), st));
+    // ---- composed linear chains (fp16 path, COMPOSE): the bias vectors, in double on the host (one-off, a few MB of D2H) ----
+    {   // neck level 0: in0(sum_k proj_k(tap_k)) = (Win0 Wout) tapcat + (Win0 sum_k b_k + b_in0) + uv term
+        std::vector<float> win((size_t)c0 * (c0 + 2)), bo(c0), bi(c0), bc(c0);
+        HIPCHK(hipMemcpyAsync(win.data(), M(h, "neck.input_blocks.0.weight"), win.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(bo.data(), A(h, "outproj.bias"), (size_t)c0 * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(bi.data(), M(h, "neck.input_blocks.0.bias"), (size_t)c0 * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int o = 0; o < c0; o++) {
+            double a = bi[o];
+            for (int j = 0; j < c0; j++) a += (double)win[(size_t)o * (c0 + 2) + j] * bo[j];
+            bc[o] = (float)a;
+        }
+        HIPCHK(hipMemcpyAsync(A(h, "neck.in0c.bias"), bc.data(), (size_t)c0 * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    if (c.head_res_blocks[0] == 0)
+        for (int k = 0; k < 3; k++)
+            if (c.heads & HEAD_BITS[k]) {
+                // head level 0 -> 1: convT(in0(n0)) = (WT Win0) n0 + (WT b_in0 + bT); torch ConvTranspose2d weight [ci][co][2][2]
+                const std::string name = HEAD_NAMES[k];
+                const int ci = c0, co = c.dims[1];
+                std::vector<float> wt((size_t)ci * co * 4), bin(ci), bt(co), bc((size_t)4 * co);
+                HIPCHK(hipMemcpyAsync(wt.data(), M(h, name + ".resamplers.0.0.weight"), wt.size() * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(bin.data(), M(h, name + ".input_blocks.0.bias"), (size_t)ci * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(bt.data(), M(h, name + ".resamplers.0.0.bias"), (size_t)co * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                for (int q = 0; q < 4; q++)
+                    for (int o = 0; o < co; o++) {
+                        double a = bt[o];
+                        for (int m = 0; m < ci; m++) a += (double)wt[((size_t)m * co + o) * 4 + q] * bin[m];
+                        bc[(size_t)q * co + o] = (float)a;
+                    }
+                HIPCHK(hipMemcpyAsync(A(h, name + ".rs0.biasTc"), bc.data(), bc.size() * 4, hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+            }
     h->aux_ready = true;
+    return 0;
+}
+
+// C[M][N] = A[M][K] * Bm[K][N], all fp32 row-major on the device, in exact fp32 (gemm.hip's v_mfma_f32_32x32x2_f32 path).  `scr` holds
+// M * K + N * K floats (A made contiguous, Bm transposed: the GEMM kernels contract K-contiguous rows of both operands).
+static int dev_matmul_f32(const float* Am, long lda, const float* Bm, long ldb, float* Cm, int Mr, int Nc, int Kc, float* scr, hipStream_t st) {
+    float* Ac = scr;
+    float* Bt = scr + (size_t)Mr * Kc;
+    LCHK(launch_repack<float>(Am, Ac, Mr, 1, 1, Kc, lda, 0, 0, 1, Kc, 0, 0, st));
+    LCHK(launch_repack<float>(Bm, Bt, Nc, 1, 1, Kc, 1, 0, 0, ldb, Kc, 0, 0, st));         // Bt[n][k] = Bm[k][n]
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.a = Ac; g.lda = Kc; g.w = Bt; g.ldw = Kc; g.M = Mr; g.N = Nc; g.K = Kc; g.epi = EPI_STORE; g.out = Cm; g.ldc = Nc;
+    LCHK(launch_gemm<float>(g, AMODE_LINEAR, st));
+    return 0;
+}
+
+// Composed linear chains of the fp16 path (COMPOSE): products formed in fp32 from the master weights, ONE rounding to fp16.
+static int compose_weights_f16(moge_handle* h, hipStream_t st) {
+    const moge_config& c = h->cfg;
+    const int D = c.embed_dim, c0 = c.dims[0], K4 = c.n_taps * D, co = c.dims[1];
+    const size_t nscr = (size_t)c0 * c0 + (size_t)K4 * c0 + (size_t)4 * co * c0 + (size_t)c0 * c0;
+    const size_t ntmp = (size_t)c0 * K4 > (size_t)4 * co * c0 ? (size_t)c0 * K4 : (size_t)4 * co * c0;
+    float *scr = nullptr, *tmp = nullptr, *wcat = nullptr, *wT = nullptr;
+    HIPCHK(hipMalloc(&scr, nscr * 4));
+    HIPCHK(hipMalloc(&tmp, ntmp * 4));
+    HIPCHK(hipMalloc(&wcat, (size_t)c0 * K4 * 4));
+    HIPCHK(hipMalloc(&wT, (size_t)4 * co * c0 * 4));
+    int rc = 0;
+    do {
+        // Wout_cat [c0][n_taps * D] (fp32), then (Win0[:, :c0]) . Wout_cat
+        for (int k = 0; k < c.n_taps && !rc; k++)
+            rc = launch_repack<float>(M(h, S(h->proj_fmt, k) + ".weight"), wcat + (size_t)k * D, c0, 1, 1, D, D, 0, 0, 1, K4, 0, 0, st);
+        if (rc) break;
+        if ((rc = dev_matmul_f32(M(h, "neck.input_blocks.0.weight"), c0 + 2, wcat, K4, tmp, c0, K4, c0, scr, st))) break;
+        if ((rc = launch_convert<float, f16>(tmp, Pm<f16>(h, "neck.in0c.w"), (long)c0 * K4, st))) break;
+        if (c.head_res_blocks[0] == 0)
+            for (int k = 0; k < 3 && !rc; k++)
+                if (c.heads & HEAD_BITS[k]) {
+                    const std::string name = HEAD_NAMES[k];
+                    // WT [(dy*2+dx)*co + o][ci] (fp32) . Win0_head [ci][ci]
+                    rc = launch_repack<float>(M(h, name + ".resamplers.0.0.weight"), wT, 4, co, 1, c0, 1, 4, 0, (long)co * 4, (long)co * c0, c0, 0, st);
+                    if (!rc) rc = dev_matmul_f32(wT, c0, M(h, name + ".input_blocks.0.weight"), c0, tmp, 4 * co, c0, c0, scr, st);
+                    if (!rc) rc = launch_convert<float, f16>(tmp, Pm<f16>(h, name + ".rs0.wTc"), (long)4 * co * c0, st);
+                }
+    } while (0);
+    hipError_t e = hipStreamSynchronize(st);
+    hipFree(scr); hipFree(tmp); hipFree(wcat); hipFree(wT);
+    if (rc) return fail(rc < 0 ? MOGE_ERR_INVALID : MOGE_ERR_HIP, "composing the level-0 linear chains failed (%d)", rc);
+    HIPCHK(e);
     return 0;
 }
 
@@ -404,6 +501,7 @@ static int pack_weights(moge_handle* h, hipStream_t st) {
     CHK(stack("neck", true, c.neck_res_blocks));
     for (int k = 0; k < 3; k++)
         if (c.heads & HEAD_BITS[k]) CHK(stack(HEAD_NAMES[k], false, c.head_res_blocks));
+    if constexpr (std::is_same<T, f16>::value) CHK(compose_weights_f16(h, st));
     h->pk_ready[pr] = true;
     return 0;
 }
@@ -525,7 +623,7 @@ static int run_gemm(moge_handle* h, const GemmArgs& g, int amode, int cls, hipSt
     if (amode == AMODE_CONV3) bytes += (double)g.M * g.C * e * (g.a2 ? 2 : 1);                 // input map (+ side map)
     else bytes += (double)g.M * k * e;                                                        // A rows
     switch (g.epi) {
-    case EPI_RESID: bytes += (double)g.M * g.N * (8.0 + (g.x16 ? 2.0 : 0.0)) + (g.ln_part ? (double)g.M * (g.N / 32) * 8.0 : 0.0); break;   // fp32 x read + write, fp16 copy, LN partials
+    case EPI_RESID: bytes += (double)g.M * g.N * (g.xres ? 8.0 + (g.x16 ? 2.0 : 0.0) : 4.0) + (g.ln_part ? (double)g.M * (g.N / 32) * 8.0 : 0.0); break;   // fp32 x read + write, fp16 copy (fp16 stream: read + write), LN partials
     case EPI_PATCH: bytes += (double)g.M * g.N * 8.0; break;                                  // + pos read, fp32 x write
     default:
         if (g.dot_tab) bytes += (double)g.M * 4 * (16.0 * g.dot_nd);                           // fused output conv: 4 phases x 4 nd floats per low-res pixel
@@ -663,7 +761,7 @@ static int get_pos(moge_handle* h, int rows, int cols, hipStream_t st, const flo
 // final-norm taps and their summed 1x1 projections -> pl.feat (B, rows, cols, c0) [+ pl.cls].  v2: modules.py:120-136; v1: v1.py:280-283 +
 // the `projects` of Head.forward (v1.py:108-111).
 template <typename T>
-static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, int imgW, const Plan& pl, hipStream_t st) {
+static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, int imgW, const Plan& pl, hipStream_t st, bool want_feat = true) {
     const moge_config& c = h->cfg;
     const int D = c.embed_dim, nh = c.num_heads, L = c.depth, c0 = c.dims[0];
     const int B = pl.B, rows = pl.rows, cols = pl.cols, Np = pl.Np, Ntok = pl.Ntok, Npad = pl.Npad;
@@ -711,6 +809,9 @@ static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, in
     // and apply (mean, rstd) in their epilogues.  Removes 2 x 0.7 GB of LayerNorm traffic per block; the final-norm taps still run
     // layernorm_kernel on the fp32 residual.  The statistics' summation tree is the same in gemm.hip and gemm_pp.hip (batch invariance).
     const bool ln_fold = std::is_same<T, f16>::value && (D % 64) == 0 && moge_tune_get("LN_FOLD", 1) != 0;
+    // `.half()` models (MOGE_FP16_HALF): the residual stream lives in `xn` as fp16 from the first block on - the proj / fc2 epilogues update it in
+    // place (EPK_RESID16) and the fp32 stream `x` is only the patch-embedding output.  Needs the LN fold (its operand IS the raw stream).
+    const bool half_resid = ln_fold && h->half_resid && moge_tune_get("HALF_RESID", 1) != 0;
     float* ln_part = (float*)(ws + pl.ln_part);
     float* ln_mr = (float*)(ws + pl.ln_mr);
     int tap_k = 0;
@@ -747,6 +848,7 @@ static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, in
             g.M = (int)BN; g.N = D; g.K = D;
             g.epi = EPI_RESID; g.bias = M(h, p + "attn.proj.bias"); g.xres = x; g.ldc = D; g.gamma = M(h, p + "ls1.gamma");
             if (ln_fold) { g.x16 = xn; g.ln_part = ln_part; }
+            if (half_resid) g.xres = nullptr;
             CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
         }
         if (!ln_fold) {
@@ -770,19 +872,24 @@ static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, in
             g.M = (int)BN; g.N = D; g.K = 4 * D;
             g.epi = EPI_RESID; g.bias = M(h, p + "mlp.fc2.bias"); g.xres = x; g.ldc = D; g.gamma = M(h, p + "ls2.gamma");
             if (ln_fold && i + 1 < L) { g.x16 = xn; g.ln_part = ln_part; }
+            if (half_resid) { g.xres = nullptr; g.x16 = xn; }          // (last block: no statistics wanted, the stream is still updated)
             CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
         }
         for (int k = 0; k < c.n_taps; k++)
             if (c.taps[k] == i) {
                 // shared final LayerNorm on the tap, cls/patch split (vision_transformer.py:321-324); cls of the LAST tap only
-                ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * D * (4 + sizeof(T)));
+                ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * D * ((half_resid ? 2 : 4) + sizeof(T)));
+                if (half_resid)
+                    LCHK(launch_layernorm_x16(xn, M(h, bb + "norm.weight"), M(h, bb + "norm.bias"), tapcat, k == c.n_taps - 1 ? cls : nullptr, BN, D,
+                                              c.n_taps * D, k * D, 1, Ntok, st));
+                else
                 LCHK(launch_layernorm<T>(x, M(h, bb + "norm.weight"), M(h, bb + "norm.bias"), tapcat, k == c.n_taps - 1 ? cls : nullptr, BN, D,
                                          c.n_taps * D, k * D, 1, Ntok, st));
                 tap_k++;
             }
     }
     if (tap_k != c.n_taps) return fail(MOGE_ERR_INVALID, "intermediate_layers must be distinct block indices < depth");
-    {   // sum_k Conv1x1_k(tap_k) == one GEMM over K = n_taps*D (modules.py:128-131)
+    if (want_feat) {   // sum_k Conv1x1_k(tap_k) == one GEMM over K = n_taps*D (modules.py:128-131)
         GemmArgs g = gemm_args();
         g.a = tapcat; g.lda = c.n_taps * D; g.w = P<T>(h, "outproj.w"); g.ldw = c.n_taps * D;
         g.M = (int)BP; g.N = c0; g.K = c.n_taps * D;
@@ -803,7 +910,12 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     float* cls = (float*)(ws + pl.cls);
     T* feat = (T*)(ws + pl.feat);
     const long BN = (long)B * Ntok, BP = (long)B * Np;
-    CHK(encode<T>(h, image, img_dtype, pl.H, pl.W, pl, st));
+    // fp16 path: chains of linear layers with nothing between them are composed at pack time (compose_weights_f16): the summed output
+    // projections + the neck's level-0 input block become one GEMM on the K-concatenated taps (`feat` is never formed), and a head without
+    // level-0 residual blocks applies (ConvTranspose2d . input block) to the neck's level-0 map in one GEMM.  Same mathematics, fewer
+    // roundings; the fp32 parity path keeps the reference's layer-by-layer order.
+    const bool compose = std::is_same<T, f16>::value && moge_tune_get("COMPOSE", 1) != 0;
+    CHK(encode<T>(h, image, img_dtype, pl.H, pl.W, pl, st, !compose));
     // ---- scale head (modules.py:184-192, v2.py:167,182) ---------------------------------------------------------
     if ((c.heads & MOGE_HEAD_SCALE) && o_metric) {
         float* m1 = (float*)(ws + pl.mlp1); float* m2 = (float*)(ws + pl.mlp2);
@@ -825,6 +937,13 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     T* Sc[3] = {(T*)(ws + pl.scratch[0]), (T*)(ws + pl.scratch[1]), (T*)(ws + pl.scratch[2])};
     {
         UVTerm uv = uv_term(A(h, "neck.in0.wu"), A(h, "neck.in0.wv"), cols, rows, aspect);
+        if (compose) {
+            GemmArgs g = gemm_args();
+            g.a = ws + pl.tapcat; g.lda = c.n_taps * D; g.w = P<T>(h, "neck.in0c.w"); g.ldw = c.n_taps * D;
+            g.M = (int)BP; g.N = c0; g.K = c.n_taps * D;
+            g.epi = EPI_STORE; g.bias = A(h, "neck.in0c.bias"); g.out = N[0]; g.ldc = c0; g.pixW = cols; g.pixH = rows; g.uv = uv;
+            CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
+        } else
         CHK(conv1x1<T>(h, feat, P<T>(h, "neck.in0.w"), M(h, "neck.input_blocks.0.bias"), N[0], BP, c0, c0, nullptr, &uv, cols, rows, st));
         CHK(res_blocks<T>(h, "neck", 0, c.neck_res_blocks[0], N[0], Sc[0], B, rows, cols, c0, st));
         for (int l = 1; l < MOGE_LEVELS; l++) {
@@ -890,14 +1009,20 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
             for (int i = 0; i < 3; i++) Sc[i] = (T*)(ws + pl.scratch[i]);
         }
         int cur = 0;                       // Sc[cur] holds the running x
-        CHK(conv1x1<T>(h, N[0], P<T>(h, name + ".in0.w"), M(h, name + ".input_blocks.0.bias"), Sc[cur], BP, c0, c0, nullptr, nullptr, cols, rows, st));
-        CHK(res_blocks<T>(h, name, 0, c.head_res_blocks[0], Sc[cur], Sc[(cur + 1) % 3], B, rows, cols, c0, st));
+        const bool compose0 = compose && c.head_res_blocks[0] == 0;       // level 0 -> 1: ConvTranspose2d(input block(n0)) as one GEMM on n0
+        if (!compose0) {
+            CHK(conv1x1<T>(h, N[0], P<T>(h, name + ".in0.w"), M(h, name + ".input_blocks.0.bias"), Sc[cur], BP, c0, c0, nullptr, nullptr, cols, rows, st));
+            CHK(res_blocks<T>(h, name, 0, c.head_res_blocks[0], Sc[cur], Sc[(cur + 1) % 3], B, rows, cols, c0, st));
+        }
         for (int l = 1; l < MOGE_LEVELS; l++) {
             const int Hh = rows << l, Ww = cols << l, ci = c.dims[l - 1], co = c.dims[l];
             const int a = (cur + 1) % 3, b2 = (cur + 2) % 3;
             int nxt;
             bool in_fused = false;
             if (l <= 3) {
+                if (l == 1 && compose0)
+                    CHK(convT2<T>(h, N[0], P<T>(h, name + ".rs0.wTc"), A(h, name + ".rs0.biasTc"), Sc[a], B, Hh / 2, Ww / 2, ci, co, st));
+                else
                 CHK(convT2<T>(h, Sc[cur], P<T>(h, name + S(".rs%d.wT", l - 1)), A(h, name + S(".rs%d.biasT", l - 1)), Sc[a], B, Hh / 2, Ww / 2, ci, co, st));
                 // resampler conv, with the head's `x + in_l(neck_l)` fused as a 1x1 side input when the halo kernel takes the shape
                 // (the first attempt passes the combined bias; if the shape is not eligible nothing ran and the plain form follows)
@@ -959,10 +1084,11 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     // remember buffers for debug taps
     h->last.valid = true; h->last.prec = TT<T>::PREC; h->last.B = B; h->last.rows = rows; h->last.cols = cols;
     h->last.bufs.clear();
-    h->last.bufs["x_final"] = {pl.x, {(int64_t)BN * D, 0}};
+    if (std::is_same<T, f16>::value && h->half_resid && moge_tune_get("HALF_RESID", 1) != 0 && moge_tune_get("LN_FOLD", 1) != 0) h->last.bufs["x_final"] = {pl.xn, {(int64_t)BN * D, 1}};
+    else h->last.bufs["x_final"] = {pl.x, {(int64_t)BN * D, 0}};
     h->last.bufs["tapcat"] = {pl.tapcat, {(int64_t)BP * c.n_taps * D, 1}};
     h->last.bufs["cls"] = {pl.cls, {(int64_t)B * D, 0}};
-    h->last.bufs["features"] = {pl.feat, {(int64_t)BP * c0, 1}};
+    if (!compose) h->last.bufs["features"] = {pl.feat, {(int64_t)BP * c0, 1}};      // (composed path: never formed)
     for (int l = 0; l < MOGE_LEVELS; l++)
         if (!(l == MOGE_LEVELS - 1 && l4dot))       // (fused output conv: the level-4 map is never materialised)
             h->last.bufs[S("neck%d", l)] = {pl.neck[l], {(int64_t)BP * ((int64_t)1 << (2 * l)) * c.dims[l], 1}};
@@ -1370,13 +1496,14 @@ int moge_load_weights(moge_handle* h, const moge_tensor_desc* descs, int n, void
 
 int moge_set_precision(moge_handle* h, int precision, void* stream) {
     if (!h) return fail(MOGE_ERR_INVALID, "null handle");
-    if (precision != MOGE_FP32 && precision != MOGE_FP16) return fail(MOGE_ERR_INVALID, "bad precision");
+    if (precision != MOGE_FP32 && precision != MOGE_FP16 && precision != MOGE_FP16_HALF) return fail(MOGE_ERR_INVALID, "bad precision");
     if (!h->master_ready) return fail(MOGE_ERR_NOT_LOADED, "weights not loaded");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     CHK(build_aux(h, st));
-    if (precision == MOGE_FP16) CHK(pack_weights<f16>(h, st)); else CHK(pack_weights<float>(h, st));
-    h->prec = precision;
+    if (precision != MOGE_FP32) CHK(pack_weights<f16>(h, st)); else CHK(pack_weights<float>(h, st));
+    h->prec = precision == MOGE_FP32 ? MOGE_FP32 : MOGE_FP16;
+    h->half_resid = precision == MOGE_FP16_HALF;
     return 0;
 }
 
@@ -1426,7 +1553,7 @@ static size_t forward_ws_bytes(moge_handle* h, const Plan& pl) {
 }
 
 static int forward_dispatch(moge_handle* h, const void* image, int img_dtype, const Plan& pl, float* pts, float* nrm, float* mp, float* metric, hipStream_t st) {
-    if (!h->pk_ready[h->prec]) CHK(moge_set_precision(h, h->prec, st));
+    if (!h->pk_ready[h->prec]) CHK(moge_set_precision(h, h->half_resid ? MOGE_FP16_HALF : h->prec, st));
     const int B = pl.B;
     const int n = split_parts(h, B);
     if (n == 1) {
@@ -1554,7 +1681,7 @@ static int v1_check(moge_handle* h, const void* image, int B, int H, int W, int 
     if (rh < 14 || rw < 14) return fail(MOGE_ERR_INVALID, "resized image %dx%d is smaller than one 14x14 patch", rh, rw);
     // lazy weight packing runs on the CALL's stream (as forward_dispatch does for v2): on the NULL stream it would race the forward of a
     // caller that uses a hipStreamNonBlocking stream and never called moge_set_precision
-    if (!h->pk_ready[h->prec]) CHK(moge_set_precision(h, h->prec, stream));
+    if (!h->pk_ready[h->prec]) CHK(moge_set_precision(h, h->half_resid ? MOGE_FP16_HALF : h->prec, stream));
     return 0;
 }
 

@@ -64,7 +64,14 @@ static int t_gemm_ex(const moge_test_gemm_args& a, hipStream_t st) {
         break;
     case MOGE_TG_RESID:
         g.epi = EPI_RESID; g.xres = a.xres; g.ldc = N; g.gamma = a.gamma;
-        if (a.x16_out) {
+        if (!a.xres) {
+            // fp16 residual stream (`.half()` models): x16_out is IN / OUT - its fp32 values are rounded to fp16, updated in place by the
+            // epilogue and returned as fp32; ln_part_out (optional) receives the statistics of the ROUNDED result
+            if (!std::is_same<T, f16>::value || !a.x16_out) return MOGE_ERR_INVALID;
+            TCHK(x16.alloc(mn * sizeof(f16)));
+            TL((launch_convert<float, f16>(a.x16_out, x16.p, (long)mn, st)));
+            g.x16 = x16.p; g.ln_part = a.ln_part_out;
+        } else if (a.x16_out) {
             if (!std::is_same<T, f16>::value || !a.ln_part_out) return MOGE_ERR_INVALID;
             TCHK(x16.alloc(mn * sizeof(f16)));
             g.x16 = x16.p; g.ln_part = a.ln_part_out;

@@ -102,7 +102,7 @@ class MoGeModel(_MoGeModelV2):
         rh, rw = self._resized(H, W, int(num_tokens))
         dev = self._device
         with torch.cuda.device(dev):
-            self._set_precision(L.FP16 if self._dtype == torch.float16 else L.FP32)
+            self._set_precision(L.FP16_HALF if self._dtype == torch.float16 else L.FP32)
             o = L.Outputs()
             res = {"points": torch.empty((B, H, W, 3), dtype=torch.float32, device=dev), "mask": torch.empty((B, H, W), dtype=torch.float32, device=dev)}
             o.points, o.mask_prob = res["points"].data_ptr(), res["mask"].data_ptr()

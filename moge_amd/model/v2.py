@@ -180,7 +180,7 @@ class MoGeModel:
             self._ensure_handle()
         if self._handle is not None and self._state_ready:
             with torch.cuda.device(self._device):
-                L.check(L.lib.moge_set_precision(self._handle, L.FP16 if self._dtype == torch.float16 else L.FP32, L.stream_ptr(self._device)))
+                L.check(L.lib.moge_set_precision(self._handle, L.FP16_HALF if self._dtype == torch.float16 else L.FP32, L.stream_ptr(self._device)))
         return self
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
@@ -367,7 +367,11 @@ class MoGeModel:
         return 3 if self._dtype == torch.float16 else 0
 
     def _precision(self, use_fp16: bool) -> int:
-        return L.FP16 if (self._dtype == torch.float16 or use_fp16) else L.FP32
+        # a .half() model keeps everything in fp16, the residual stream included (scripts/infer.py:83-84; autocast is off then, v2.py:241);
+        # fp32 weights + use_fp16 = torch.autocast: matrix products in fp16, LayerNorm inputs / residual adds in fp32
+        if self._dtype == torch.float16:
+            return L.FP16_HALF
+        return L.FP16 if use_fp16 else L.FP32
 
     def _set_precision(self, prec: int):
         L.check(L.lib.moge_set_precision(self._handle, prec, L.stream_ptr(self._device)))
@@ -379,7 +383,7 @@ class MoGeModel:
         rows, cols = self._grid(H, W, int(num_tokens))
         dev = self._device
         with torch.cuda.device(dev):
-            self._set_precision(L.FP16 if self._dtype == torch.float16 else L.FP32)
+            self._set_precision(L.FP16_HALF if self._dtype == torch.float16 else L.FP32)
             o = L.Outputs()
             res: Dict[str, torch.Tensor] = {}
             if self._bits & L.HEAD_POINTS:

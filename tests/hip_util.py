@@ -30,7 +30,7 @@ TG_STORE, TG_RESID, TG_QKV, TG_CONVT = 0, 1, 2, 3
 
 
 def gemm_ex(kind, A, W, bias, prec=1, act=0, ln_mr=None, ln_c=None, uv=None, pix=None, Cout=0, xres=None, gamma=None, want_x16=False,
-            nh=0, Ntok=0, qscale=1.0):
+            nh=0, Ntok=0, qscale=1.0, x16_stream=None, want_part=True):
     """One GEMM through a fused epilogue (moge_test_gemm_ex).  All tensors fp32 on the GPU.  Returns a dict of outputs."""
     import ctypes as C
     A, W = _f(A), _f(W)
@@ -58,6 +58,13 @@ def gemm_ex(kind, A, W, bias, prec=1, act=0, ln_mr=None, ln_c=None, uv=None, pix
     if kind in (TG_STORE, TG_CONVT):
         out["out"] = torch.empty((M, N), device="cuda", dtype=torch.float32)
         a.out, a.Cout = out["out"].data_ptr(), Cout
+    elif kind == TG_RESID and x16_stream is not None:
+        # fp16 residual stream of a `.half()` model (EPK_RESID16): x16 in / out (fp32 values that are exact fp16 numbers), xres = NULL
+        out["x16"] = _f(x16_stream).clone()
+        a.x16_out, a.gamma = out["x16"].data_ptr(), dev(gamma)
+        if want_part:
+            out["ln_part"] = torch.empty((M, N // 32, 2), device="cuda", dtype=torch.float32)
+            a.ln_part_out = out["ln_part"].data_ptr()
     elif kind == TG_RESID:
         out["xres"] = _f(xres).clone()
         a.xres, a.gamma = out["xres"].data_ptr(), dev(gamma)

@@ -125,6 +125,33 @@ def test_resid_flavour_forced_pp(H, kern, M, N, K):
     assert torch.equal(o2["xres"], o["xres"])
 
 
+@pytest.mark.parametrize("M,N,K", SHAPES_SMALL[:3] + [(517, 384, 1536)])
+def test_resid16_flavour_forced_pp(H, kern, M, N, K):
+    """EPK_RESID16 <9>: the proj / fc2 epilogue of a `.half()` model - the residual stream itself is fp16 and is updated in place:
+    x16 <- fp16(x16 + gamma (acc + bias)) (one rounding), with the (sum, sum of squares) of every 32-column group of the ROUNDED row."""
+    A, W, b = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=K ** -0.5), rnd(N, seed=6)
+    gamma, x0 = rnd(N, seed=7), h16(rnd(M, N, seed=8, scale=3.0))
+    ref = x0 + gamma * (acc_ref(A, W) + b)
+    pp_ok = N % 256 == 0
+    with Force("pp", kern):
+        o = H.gemm_ex(H.TG_RESID, A, W, b, gamma=gamma, x16_stream=x0)
+    # one fp16 rounding of a value whose fp32 sum may differ in the last bits: within 1 fp16 ulp of the fp32 reference's rounding
+    err = (o["x16"] - h16(ref)).abs()
+    bound = ref.abs() * 2.0 ** -10 + 2e-5            # one fp16 ulp of the result + the fp32 summation-order difference where x and the update cancel
+    assert bool((err <= bound).all()), float((err - bound).max())
+    assert float((err > 0).float().mean()) < 5e-3, "more than 0.5 % of the entries round differently from the fp32 reference"
+    assert torch.equal(o["x16"], h16(o["x16"]))
+    g = o["x16"].double().reshape(M, N // 32, 32)
+    close(o["ln_part"], torch.stack([g.sum(-1), (g * g).sum(-1)], dim=-1), tol=2e-6, what="ln_part of the rounded stream")
+    with Force("latency"):
+        l = H.gemm_ex(H.TG_RESID, A, W, b, gamma=gamma, x16_stream=x0)
+    for k in ("x16", "ln_part"):
+        assert torch.equal(o[k], l[k]), f"{k}: pp and latency kernels differ on {int((o[k] != l[k]).sum())} entries (pp eligible: {pp_ok})"
+    with Force("pp", kern):                                                     # without the statistics (last block's fc2)
+        o2 = H.gemm_ex(H.TG_RESID, A, W, b, gamma=gamma, x16_stream=x0, want_part=False)
+    assert torch.equal(o2["x16"], o["x16"])
+
+
 def ln_stats(M, seed):
     mean = rnd(M, seed=seed, scale=0.3)
     rstd = rnd(M, seed=seed + 1).abs() * 0.5 + 0.5
@@ -238,6 +265,17 @@ def test_full_baseline_shapes_production_dispatch(H):
         g = o["xres"].double().reshape(M, D // 32, 32)
         close(o["ln_part"], torch.stack([g.sum(-1), (g * g).sum(-1)], dim=-1), tol=2e-6, what="full ln_part")
         del o, ref, g
+    # proj / fc2 of a `.half()` model (RESID16 <9>): fp16 stream in place
+    for K, seed in ((D, 45), (4 * D, 55)):
+        A, W, b = rnd(M, K, seed=seed), rnd(D, K, seed=seed + 1, scale=K ** -0.5), rnd(D, seed=seed + 2)
+        gamma, x0 = rnd(D, seed=seed + 3), h16(rnd(M, D, seed=seed + 4, scale=3.0))
+        ref = x0 + gamma * (acc_ref(A, W) + b)
+        o = H.gemm_ex(H.TG_RESID, A, W, b, gamma=gamma, x16_stream=x0)
+        err = (o["x16"] - h16(ref)).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -10 + 2e-5).all()), (K, float((err - ref.abs() * 2.0 ** -10).max()))
+        g = o["x16"].double().reshape(M, D // 32, 32)
+        close(o["ln_part"], torch.stack([g.sum(-1), (g * g).sum(-1)], dim=-1), tol=2e-6, what="full ln_part (fp16 stream)")
+        del o, ref, g, err
     # fc1 (GELU_LN <7>)
     A, W, b, c, mr = rnd(M, D, seed=60), rnd(4 * D, D, seed=61, scale=D ** -0.5), rnd(4 * D, seed=62), rnd(4 * D, seed=63), ln_stats(M, 64)
     ref = F.gelu(mr[:, 1:2] * (acc_ref(A, W) - mr[:, 0:1] * c) + b)

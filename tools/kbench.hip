@@ -44,6 +44,13 @@ __global__ void ref_gemm(const f16* A, int lda, const f16* W, int ldw, const flo
     ref[(size_t)r * N + n] = (float)acc + (bias ? bias[n] : 0.f);
 }
 
+__global__ void round_f32_to_f16_values(float* x, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = (float)(f16)x[i];
+}
+__global__ void f32_to_f16_copy(const float* x, f16* y, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (f16)x[i];
+}
+
 struct CheckArgs {
     GemmArgs g;
     const int* rows; int nrows;
@@ -69,7 +76,12 @@ __global__ void check_out(CheckArgs c) {
     const int m = c.rows[r];
     float v = c.ref[(size_t)r * g.N + n];
     float got, tol;
-    if (g.epi == EPI_RESID) {
+    if (g.epi == EPI_RESID && !g.xres) {            // fp16 stream: x0 holds the stream before the call as fp32
+        const float e = c.x0[(size_t)m * g.ldc + n] + g.gamma[n] * v;
+        got = (float)((const f16*)g.x16)[(size_t)m * g.ldc + n];
+        tol = fabsf(e) * (1.0f / 1024.0f) + 3e-4f;
+        v = e;
+    } else if (g.epi == EPI_RESID) {
         const float e = c.x0[(size_t)m * g.ldc + n] + g.gamma[n] * v;
         got = g.xres[(size_t)m * g.ldc + n];
         tol = 2e-5f * fabsf(e) + 3e-4f;
@@ -105,7 +117,7 @@ __global__ void check_out(CheckArgs c) {
     atomicMaxF(c.maxratio, ratio == ratio ? ratio : 1e30f);
 }
 
-struct Shape { const char* name; int M, N, K, epi, act; int D, nh, Ntok; int Cout, pixW, pixH; int uv; };
+struct Shape { const char* name; int M, N, K, epi, act; int D, nh, Ntok; int Cout, pixW, pixH; int uv; int fold = 0; };      // fold (RESID): 1 = + fp16 copy + LN partials (production, fp32 stream), 2 = fp16 stream in place (`.half()` models, EPK_RESID16)
 
 static double time_launches(const GemmArgs& g, int iters, hipStream_t st) {
     hipEvent_t e0, e1;
@@ -131,6 +143,10 @@ static int bench_gemm(const char* filter, int iters) {
         {"proj", B * Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"fc1", B * Ntok, 4096, 1024, EPI_STORE, ACT_GELU, 0, 0, 0, 0, 0, 0, 0},
         {"fc2", B * Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
+        {"proj+fold", B * Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0, 1},
+        {"fc2+fold", B * Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0, 1},
+        {"proj.h16", B * Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0, 2},
+        {"fc2.h16", B * Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0, 2},
         {"outproj", B * 3600, 1024, 4096, EPI_STORE, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"neck.in0(uv)", B * 3600, 1024, 1024, EPI_STORE, ACT_NONE, 0, 0, 0, 0, 60, 60, 1},
         {"convT0", B * 3600, 1024, 1024, EPI_CONVT, ACT_NONE, 0, 0, 0, 256, 60, 60, 0},
@@ -195,6 +211,15 @@ static int bench_gemm(const char* filter, int iters) {
         g.a = A; g.lda = (int)K; g.w = W; g.ldw = (int)K; g.M = (int)M; g.N = (int)N; g.K = (int)K;
         g.epi = s.epi; g.act = s.act; g.bias = bias; g.out = out; g.ldc = (int)N;
         if (s.epi == EPI_RESID) { g.xres = x; g.gamma = gamma; }
+        f16* x16 = nullptr; float* part = nullptr;
+        if (s.epi == EPI_RESID && s.fold) {
+            CK(hipMalloc(&x16, M * N * 2)); CK(hipMalloc(&part, M * (N / 32) * 8));
+            g.x16 = x16; g.ln_part = part;
+            if (s.fold == 2) {                            // the stream itself is fp16: x0 := fp16-rounded values, x16 is reset from it before the checked launch
+                g.xres = nullptr;
+                round_f32_to_f16_values<<<2048, 256, 0, st>>>(x0, M * N);
+            }
+        }
         if (s.epi == EPI_QKV) {
             const size_t per = M * s.D;
             g.q = out; g.k = out + per; g.vT = out + 2 * per; g.v_rowmajor = 1;
@@ -220,6 +245,7 @@ static int bench_gemm(const char* filter, int iters) {
             // correctness: one launch on fresh buffers
             CK(hipMemsetAsync(out, 0, out_elems * 2, st));
             if (x) CK(hipMemcpyAsync(x, x0, M * N * 4, hipMemcpyDeviceToDevice, st));
+            if (s.fold == 2) f32_to_f16_copy<<<2048, 256, 0, st>>>(x0, x16, M * N);
             int rc = launch_gemm<f16>(g, AMODE_LINEAR, st);
             if (rc) { printf("%-14s %-10s launch failed rc=%d\n", s.name, v.name, rc); fails++; continue; }
             CK(hipMemsetAsync(dmax, 0, 4, st)); CK(hipMemsetAsync(dbad, 0, 4, st));
@@ -276,6 +302,7 @@ static int bench_gemm(const char* filter, int iters) {
         }
         CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(gamma)); CK(hipFree(out)); CK(hipFree(wu)); CK(hipFree(wv));
         if (x) { CK(hipFree(x)); CK(hipFree(x0)); }
+        if (x16) { CK(hipFree(x16)); CK(hipFree(part)); }
         CK(hipFree(drows)); CK(hipFree(ref)); CK(hipFree(dmax)); CK(hipFree(dbad));
         (void)out2; (void)out3;
     }

@@ -13,9 +13,19 @@ mkdir -p gpurun_out
   echo "# MFMA_POWER_SECONDS=4: every configuration is repeated for ~4 s; rocm-smi is sampled every 0.5 s in the background (power = average socket power)"
   rocm-smi --showproductname 2>/dev/null | grep -i "card series\|GFX" | head -3
   ( while true; do
-      p=$(rocm-smi --showpower 2>/dev/null | grep -i "power" | head -1 | sed 's/.*: //')
-      c=$(rocm-smi --showclocks 2>/dev/null | grep -i "sclk" | head -1 | sed 's/.*(//; s/).*//')
-      echo "    [smi t=$(date +%s.%N | cut -c1-14)] power ${p} W  sclk ${c}"
+      j=$(rocm-smi --showpower --showclocks --json 2>/dev/null | tr -d '\n')
+      echo "    [smi t=$(date +%s.%N | cut -c1-14)] $j" | python3 -c "
+import sys, json, re
+ln = sys.stdin.read()
+m = re.search(r'(\{.*\})', ln)
+head = ln[:ln.index('{')] if m else ln
+try:
+    d = json.loads(m.group(1)); c = d[sorted(d)[0]]
+    keep = {k: v for k, v in c.items() if re.search(r'power|sclk', k, re.I)}
+    print(head + json.dumps(keep))
+except Exception:
+    print(ln.strip()[:300])
+"
       sleep 0.5
     done ) &
   smi=$!
