@@ -278,6 +278,18 @@ def main():
             torch.cuda.synchronize(dev)
             lat.append((time.perf_counter() - t1) * 1e3)
         lat = sorted(lat[2:])
+        # the reference's OTHER fp16 form, for transparency (never `value`): fp32 weights + use_fp16=True = torch.autocast (v2.py:241), which keeps
+        # the residual stream in fp32 (MOGE_FP16) - `value` above is model.half() (scripts/infer.py:83-84), whose stream is fp16 (MOGE_FP16_HALF)
+        model.float()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(max(3, args.steps // 2)):
+            step()
+        torch.cuda.synchronize(dev)
+        autocast_rate = B * max(3, args.steps // 2) / (time.perf_counter() - t1)
+        model.half()
         res = {
             "metric": f"images/sec (MoGeModel.infer, {args.config} {args.shape} fp16)", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -286,6 +298,9 @@ def main():
                                    f"fp16 weights, synthetic checkpoint (seed 0), inputs resident in HBM, outputs left on device",
                        "global_batch": world * B, "parallelism": f"dp{world} (independent shards, one-time RCCL weight broadcast)"},
             "p50_latency_ms_batch1": round(lat[len(lat) // 2], 3),
+            "fp16_forms": {"value_is": "model.half(): fp16 weights and fp16 residual stream, as the reference's `--fp16` (scripts/infer.py:83-84)",
+                           "autocast_fp32_weights_images_per_s": round(autocast_rate, 3),
+                           "note": "infer(use_fp16=True) on fp32 weights = torch.autocast in the reference (v2.py:241): residual stream stays fp32; this rank only"},
         }
         if rccl is not None:
             res["rccl"] = rccl

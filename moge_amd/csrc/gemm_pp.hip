@@ -676,8 +676,11 @@ __device__ __forceinline__ void pp_store_rows_buf(const GemmArgs& g, __amdgpu_bu
 // mid(): called once, at the first point behind which the epilogue has no load left that the COMPILER waits for (it places s_waitcnt vmcnt(0)
 // in front of the first use of any ordinary load while LDS-DMA is in flight): the kernel requests the next tile's first pieces there.
 // Behind it follow PpTrail<> unconditional stores per lane.
+// (a LOWER bound would be safe - the head wait then also covers some stores - and costly: it makes every tile head wait for store
+//  acknowledgements.  The RESID flavours therefore issue their optional outputs - fp16 copy, LN partials - UNCONDITIONALLY in this kernel: a
+//  null output is an empty buffer descriptor, its stores are dropped by the bounds check, and the count is exact: x + x16 + partials.)
 template <int EPKX, int SROWS> struct PpTrail {
-    static constexpr int N = EpkBase<EPKX>::K == EPK_RESID ? SROWS / 8 : (EpkBase<EPKX>::K == EPK_RESID16 ? SROWS / 16 : 16);      // (a LOWER bound is safe: the head wait then also covers some stores)
+    static constexpr int N = EpkBase<EPKX>::K == EPK_RESID ? 3 * (SROWS / 8) : (EpkBase<EPKX>::K == EPK_RESID16 ? 2 * (SROWS / 16) : 16);
 };
 template <int EPKX, int SROWS, class Mid>
 __device__ __forceinline__ void pp_epi_run(const GemmArgs& g, f32x4 (&acc)[8][4], PpEpiPre<EPKX, SROWS>& P, char* R, int lane, int mw, int nw, Mid mid) {
@@ -704,7 +707,7 @@ __device__ __forceinline__ void pp_epi_run(const GemmArgs& g, f32x4 (&acc)[8][4]
             pp_resid16_add<PROWS>(R, lane, xc);
             if (p + 1 < NPASS) pp_resid16_load<PROWS>(P.rb16, lane, mw + (p + 1) * PROWS, nw, xn);
             else mid();
-            pp_resid16_store<PROWS>(P.rb16, P.fold, lane, mw + p * PROWS, nw, xc);
+            pp_resid16_store<PROWS>(P.rb16, true, lane, mw + p * PROWS, nw, xc);       // (statistics stores always issued: see PpTrail)
         }
     } else if constexpr (EPK == EPK_RESID) {
         f32x4 x1[SROWS / 8];
@@ -729,7 +732,7 @@ __device__ __forceinline__ void pp_epi_run(const GemmArgs& g, f32x4 (&acc)[8][4]
             pp_resid_add<SROWS>(R, lane, xc);
             if (p + 1 < 2 * NP) pp_resid_load<SROWS>(P.rb, lane, mw + ((p + 1) >> 1) * SROWS, nw + ((p + 1) & 1) * 32, xn);
             else mid();
-            pp_resid_store<SROWS>(P.rb, P.fold, lane, mw + ih * SROWS, nw + J * 32, xc);
+            pp_resid_store<SROWS>(P.rb, true, lane, mw + ih * SROWS, nw + J * 32, xc);        // (fp16 copy / statistics always issued: see PpTrail)
         }
     } else {
 #pragma unroll

@@ -50,7 +50,11 @@ def rel_err(a, b, floor=1.0):
 FP32_TOL = 1e-3            # fp32 mode: every pixel within 1e-3 relative (oracle.metrics: per-pixel, norm-relative), mask bit-exact
 ILL_TOL = 5e-2             # ill-posed checkpoint: p99.9 (the LM trajectory amplifies 1e-7 forward noise; so does the reference between thread counts)
 FP16_FACTOR = 2.0          # fp16 mode: at most 2x the drift of the reference's OWN fp16 path against its fp32 path on the same case
-FP16_MAX_FACTOR = 8.0      # ... and NO pixel further than 8x that band (the p99.9 gate alone would let 0.1 % of the pixels - a tile corner, a border row - be arbitrarily wrong)
+# ... and NO pixel further than a small multiple of that band (the p99.9 gate alone would let 0.1 % of the pixels - a tile corner, a border row - be
+# arbitrarily wrong).  Observed max / band over all fixtures, both fp16 forms (profiles/r04c_pytest_gpu_half_resid.log): points / depth <= 0.61,
+# intrinsics <= 0.60, normals <= 4.7 (unit vectors of a random tiny net: a pixel whose raw normal is nearly 0 turns by a large angle) - the
+# reference's own fp16 outputs show max / band <= 3.2.  Gates at ~3x what is seen for the geometry outputs:
+FP16_MAX_FACTOR = dict(points=2.0, depth=2.0, intrinsics=2.0, metric_scale=2.0, normal=8.0)
 FLIP_SLACK = 4              # pixels
 FP16_FLOOR = dict(points=5e-4, depth=5e-4, normal=2e-3, intrinsics=1e-4, metric_scale=5e-4, mask=1e-4)   # where the reference's drift is ~0 (e.g. fov_x given)
 
@@ -141,5 +145,5 @@ def check_fp16(out: dict, ref32: dict, band: dict) -> dict:
         seen[k + ".max"] = float(e.max())
         seen[k + ".max/band"] = float(e.max()) / band[k]
         assert val <= band[k], (k, val, band[k])
-        assert float(e.max()) <= FP16_MAX_FACTOR * band[k], (k, "max", float(e.max()), FP16_MAX_FACTOR * band[k])
+        assert float(e.max()) <= FP16_MAX_FACTOR.get(k, 8.0) * band[k], (k, "max", float(e.max()), FP16_MAX_FACTOR.get(k, 8.0) * band[k])
     return seen

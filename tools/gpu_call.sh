@@ -12,6 +12,8 @@ for what in "$@"; do
     tests_s)    timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider -s > $out/${tag}_pytest_s.log 2>&1; grep "passed\|failed\|error" $out/${tag}_pytest_s.log | tail -5; grep "^FAILED\|^ERROR\|Error" $out/${tag}_pytest_s.log | head -20 ;;
     kb_resid)   KB_PP=1 KB_ROUNDS=3 timeout 400 ./tools/kbench gemm proj 10 > $out/${tag}_kbench_resid.log 2>&1; KB_PP=1 KB_ROUNDS=3 timeout 400 ./tools/kbench gemm fc2 10 >> $out/${tag}_kbench_resid.log 2>&1; grep -v "^ " $out/${tag}_kbench_resid.log | grep -v "vit\|b1\.\|b4\." | head -60 ;;
     tests_half) timeout 900 python -m pytest tests/test_hip_gemm_pp.py tests/test_hip_parity.py tests/test_hip_v1.py tests/test_hip_kernels.py -m gpu -q -p no:cacheprovider -s -x > $out/${tag}_pytest_half.log 2>&1; grep "passed\|failed\|error" $out/${tag}_pytest_half.log | tail -5; grep "^FAILED\|^ERROR\|Error\|assert" $out/${tag}_pytest_half.log | head -20 ;;
+    tests_gemm) timeout 900 python -m pytest tests/test_hip_gemm_pp.py -m gpu -q -p no:cacheprovider > $out/${tag}_pytest_gemm.log 2>&1; tail -3 $out/${tag}_pytest_gemm.log ;;
+    tests_model) timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_v1.py tests/test_hip_multiproc.py -m gpu -q -p no:cacheprovider -s > $out/${tag}_pytest_model.log 2>&1; grep "passed\|failed\|error" $out/${tag}_pytest_model.log | tail -5; grep "^FAILED\|^ERROR\|Error\|assert" $out/${tag}_pytest_model.log | head -20 ;;
     tests)      timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $out/${tag}_pytest.log 2>&1; tail -25 $out/${tag}_pytest.log ;;
     tests_new)  timeout 600 python -m pytest tests/test_hip_conv_ex.py tests/test_hip_parity.py -m gpu -q -p no:cacheprovider -s > $out/${tag}_pytest_new.log 2>&1; tail -30 $out/${tag}_pytest_new.log ;;
     kb_rb)      KB_ROUNDS=3 timeout 300 ./tools/kbench rb - 10 > $out/${tag}_kbench_rb.log 2>&1; cat $out/${tag}_kbench_rb.log ;;
