@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MOGE_ABI_VERSION 2
+#define MOGE_ABI_VERSION 3
 #define MOGE_MAX_TAPS 8
 #define MOGE_LEVELS 5
 
@@ -52,9 +52,14 @@ typedef enum moge_remap { MOGE_REMAP_LINEAR = 0, MOGE_REMAP_SINH = 1, MOGE_REMAP
 #define MOGE_HEAD_MASK   4
 #define MOGE_HEAD_SCALE  8
 
-/* Mirrors the checkpoint's `model_config` (moge/model/v2.py:29-56, configs/train/v2.json:238-285).
- * Only the released MoGe-2 layout is supported: 5 levels, resamplers [conv_transpose x3, bilinear],
- * res-block norms "none", ReLU, replicate padding. */
+/* ConvStack options (moge/model/modules.py:18-67, 139-181, 195-240).  Resampler of level l -> l + 1 (x2 up-samplers only: the decoder stacks): */
+typedef enum moge_resampler { MOGE_RS_CONV_TRANSPOSE = 0, MOGE_RS_BILINEAR = 1, MOGE_RS_NEAREST = 2, MOGE_RS_PIXEL_SHUFFLE = 3 } moge_resampler;
+/* in_norm / hidden_norm of the residual blocks: Identity, GroupNorm(1, C) ("layer_norm") or GroupNorm(C / 32, C) ("group_norm") */
+typedef enum moge_res_norm { MOGE_NORM_NONE = 0, MOGE_NORM_LAYER = 1, MOGE_NORM_GROUP = 2 } moge_res_norm;
+
+/* Mirrors the checkpoint's `model_config` (moge/model/v2.py:29-56, configs/train/v2.json:238-285): 5 levels, ReLU, replicate padding,
+ * hidden width = width.  The released layout - resamplers [conv_transpose x3, bilinear], res-block norms "none" - runs on the fused
+ * throughput kernels; the other resamplers / norms (ABI v3) run on the generic kernels of the same library. */
 typedef struct moge_config {
     int32_t embed_dim;                 /* ViT width D (384 / 768 / 1024)            vision_transformer.py:351-390 */
     int32_t depth;                     /* ViT blocks                                                               */
@@ -67,6 +72,10 @@ typedef struct moge_config {
     int32_t heads;                     /* MOGE_HEAD_* bitmask                                                      */
     int32_t scale_hidden;              /* scale_head dims = [D, scale_hidden, scale_hidden, 1]                     */
     int32_t remap_output;              /* moge_remap                                v2.py:122-136                  */
+    int32_t neck_resamplers[MOGE_LEVELS - 1];   /* moge_resampler per level transition       modules.py:139-181            */
+    int32_t head_resamplers[MOGE_LEVELS - 1];   /* (all heads share one layout)                                            */
+    int32_t neck_in_norm, neck_hidden_norm;     /* moge_res_norm                             modules.py:47-60              */
+    int32_t head_in_norm, head_hidden_norm;
 } moge_config;
 
 /* Mirrors the `model_config` of a MoGe-1 checkpoint (moge/model/v1.py:148-163).  Supported layout = the released one:

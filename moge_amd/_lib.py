@@ -16,16 +16,20 @@ FP32, FP16, FP16_HALF = 0, 1, 2        # moge_precision: FP16 = fp32 weights und
 HEAD_POINTS, HEAD_NORMAL, HEAD_MASK, HEAD_SCALE = 1, 2, 4, 8
 FORCE_PROJECTION, APPLY_MASK = 1, 2
 REMAP = {"linear": 0, "sinh": 1, "exp": 2, "sinh_exp": 3}
+RESAMPLER = {"conv_transpose": 0, "bilinear": 1, "nearest": 2, "pixel_shuffle": 3}      # moge_resampler (x2 up-samplers, modules.py:139-181)
+RES_NORM = {"none": 0, "layer_norm": 1, "group_norm": 2}                                # moge_res_norm (modules.py:47-60)
 ERR_NONFINITE = -5
 KC_NAMES = ["gemm", "attn", "conv", "norm", "pre", "post", "recover", "gemm_pp"]
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MogeConfig(C.Structure):
     _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32), ("n_taps", C.c_int32),
                 ("taps", C.c_int32 * MOGE_MAX_TAPS), ("dims", C.c_int32 * MOGE_LEVELS),
                 ("neck_res_blocks", C.c_int32 * MOGE_LEVELS), ("head_res_blocks", C.c_int32 * MOGE_LEVELS),
-                ("heads", C.c_int32), ("scale_hidden", C.c_int32), ("remap_output", C.c_int32)]
+                ("heads", C.c_int32), ("scale_hidden", C.c_int32), ("remap_output", C.c_int32),
+                ("neck_resamplers", C.c_int32 * (MOGE_LEVELS - 1)), ("head_resamplers", C.c_int32 * (MOGE_LEVELS - 1)),
+                ("neck_in_norm", C.c_int32), ("neck_hidden_norm", C.c_int32), ("head_in_norm", C.c_int32), ("head_hidden_norm", C.c_int32)]
 
 
 MOGE_V1_MAX_UP = 4

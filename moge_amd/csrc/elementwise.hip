@@ -486,8 +486,12 @@ template int launch_repack<float>(const float*, void*, int, int, int, int, long,
 // dst: [(py*2+px)*Cout + co][(a*3+b)*Cin + ci], torch src: [co][ci][3][3].  Combination in fp32, one rounding to T.
 // --------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void pack_phase_conv_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin) {
-    const float R[2][3][3] = {{{.75f, .25f, 0.f}, {.25f, .75f, 0.f}, {0.f, .75f, .25f}}, {{.25f, .75f, 0.f}, {0.f, .75f, .25f}, {0.f, .25f, .75f}}};
+__global__ void pack_phase_conv_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin, int nearest) {
+    // nearest (Resampler 'nearest', modules.py:152-156): hi-res rows 2i and 2i + 1 are both x[i], so tap dy of output parity p reads low-res row
+    // i + floor((p + dy - 1) / 2): R[0] = [[1,0,0],[0,1,0],[0,1,0]], R[1] = [[0,1,0],[0,1,0],[0,0,1]]; the replicate pad again coincides with index clamping
+    const float RB[2][3][3] = {{{.75f, .25f, 0.f}, {.25f, .75f, 0.f}, {0.f, .75f, .25f}}, {{.25f, .75f, 0.f}, {0.f, .75f, .25f}, {0.f, .25f, .75f}}};
+    const float RN[2][3][3] = {{{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 1.f, 0.f}}, {{0.f, 1.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}};
+    const float (*R)[3][3] = nearest ? RN : RB;
     const long total = 4L * Cout * 9 * Cin;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         long t = idx;
@@ -506,15 +510,15 @@ __global__ void pack_phase_conv_kernel(const float* __restrict__ w, T* __restric
     }
 }
 template <typename T>
-int launch_pack_phase_conv(const float* w, void* dst, int Cout, int Cin, hipStream_t st) {
+int launch_pack_phase_conv(const float* w, void* dst, int Cout, int Cin, hipStream_t st, int nearest) {
     const long total = 4L * Cout * 9 * Cin;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(pack_phase_conv_kernel<T>, dim3(blocks), dim3(256), 0, st, w, (T*)dst, Cout, Cin);
+    hipLaunchKernelGGL(pack_phase_conv_kernel<T>, dim3(blocks), dim3(256), 0, st, w, (T*)dst, Cout, Cin, nearest);
     return (int)hipGetLastError();
 }
-template int launch_pack_phase_conv<f16>(const float*, void*, int, int, hipStream_t);
-template int launch_pack_phase_conv<float>(const float*, void*, int, int, hipStream_t);
+template int launch_pack_phase_conv<f16>(const float*, void*, int, int, hipStream_t, int);
+template int launch_pack_phase_conv<float>(const float*, void*, int, int, hipStream_t, int);
 
 // ============================================================================================================================
 // MoGe-1 (moge/model/v1.py) support kernels

@@ -169,10 +169,19 @@ static void build_tables(moge_handle* h) {
     else build_tables_v2_decoder(h);
 }
 
+// ConvStack options (ABI v3).  The released layout is what the fused throughput paths (side inputs, level-4 dot, composed chains) are built
+// for; every other combination runs the same kernels un-fused.
+static const int* stack_rs(const moge_config& c, bool neck) { return neck ? c.neck_resamplers : c.head_resamplers; }
+static bool rs_is_phase(int r) { return r == MOGE_RS_BILINEAR || r == MOGE_RS_NEAREST; }
+static const char* rs_final_conv(int r) { return r == MOGE_RS_PIXEL_SHUFFLE ? "2" : "1"; }      // index of the resampler's last 3x3 conv in its nn.Sequential
+static bool stack_has_norm(const moge_config& c, bool neck) { return neck ? (c.neck_in_norm || c.neck_hidden_norm) : (c.head_in_norm || c.head_hidden_norm); }
+
 static void build_tables_v2_decoder(moge_handle* h) {
     const moge_config& c = h->cfg;
     const int D = c.embed_dim, c0 = c.dims[0];
     auto stack = [&](const std::string& name, bool neck, const int* nres, int cout) {
+        const int* rs = stack_rs(c, neck);
+        const int in_norm = neck ? c.neck_in_norm : c.head_in_norm, hid_norm = neck ? c.neck_hidden_norm : c.head_hidden_norm;
         for (int l = 0; l < MOGE_LEVELS; l++) {
             const int cl = c.dims[l];
             const int cin = neck ? (l == 0 ? c0 + 2 : 2) : cl;
@@ -195,7 +204,16 @@ static void build_tables_v2_decoder(moge_handle* h) {
         }
         for (int l = 0; l < MOGE_LEVELS - 1; l++) {
             const int ci = c.dims[l], co = c.dims[l + 1];
-            if (l < 3) {
+            if (rs[l] == MOGE_RS_PIXEL_SHUFFLE) {
+                // Conv2d(ci, 4 co, 3x3) -> PixelShuffle(2) -> Conv2d(co, co, 3x3)   (modules.py:146-151)
+                tadd(h, name + S(".resamplers.%d.0.weight", l), (int64_t)4 * co * ci * 9);
+                tadd(h, name + S(".resamplers.%d.0.bias", l), 4 * co);
+                tadd(h, name + S(".resamplers.%d.2.weight", l), (int64_t)co * co * 9);
+                tadd(h, name + S(".resamplers.%d.2.bias", l), co);
+                padd(h, name + S(".rs%d.w3p", l), (int64_t)4 * co * 9 * ci);       // rows permuted to (dy, dx, co): the phase-conv layout
+                padd(h, name + S(".rs%d.w3", l), (int64_t)co * 9 * co);
+                aadd(h, name + S(".rs%d.bias4", l), 4 * co);
+            } else if (rs[l] == MOGE_RS_CONV_TRANSPOSE) {
                 tadd(h, name + S(".resamplers.%d.0.weight", l), (int64_t)ci * co * 4);
                 tadd(h, name + S(".resamplers.%d.0.bias", l), co);
                 tadd(h, name + S(".resamplers.%d.1.weight", l), (int64_t)co * co * 9);
@@ -220,6 +238,8 @@ static void build_tables_v2_decoder(moge_handle* h) {
         for (int l = 0; l < MOGE_LEVELS; l++)
             for (int j = 0; j < nres[l]; j++) {
                 const int cl = c.dims[l];
+                if (in_norm) { tadd(h, name + S(".res_blocks.%d.%d.layers.0.weight", l, j), cl); tadd(h, name + S(".res_blocks.%d.%d.layers.0.bias", l, j), cl); }
+                if (hid_norm) { tadd(h, name + S(".res_blocks.%d.%d.layers.3.weight", l, j), cl); tadd(h, name + S(".res_blocks.%d.%d.layers.3.bias", l, j), cl); }
                 for (int li = 2; li <= 5; li += 3) {
                     tadd(h, name + S(".res_blocks.%d.%d.layers.%d.weight", l, j, li), (int64_t)cl * cl * 9);
                     tadd(h, name + S(".res_blocks.%d.%d.layers.%d.bias", l, j, li), cl);
@@ -285,7 +305,7 @@ static int build_aux(moge_handle* h, hipStream_t st) {
         LCHK(launch_repack<float>(w + (cin - 1), A(h, S("neck.in%d.wv", l)), cl, 1, 1, 1, cin, 0, 0, 0, 1, 0, 0, st));
         if (l > 0) {
             std::vector<float> a(cl), b(cl);
-            HIPCHK(hipMemcpyAsync(a.data(), M(h, S("neck.resamplers.%d.1.bias", l - 1)), cl * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(a.data(), M(h, S("neck.resamplers.%d.%s.bias", l - 1, rs_final_conv(c.neck_resamplers[l - 1]))), cl * sizeof(float), hipMemcpyDeviceToHost, st));
             HIPCHK(hipMemcpyAsync(b.data(), M(h, S("neck.input_blocks.%d.bias", l)), cl * sizeof(float), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             for (int i = 0; i < cl; i++) a[i] += b[i];
@@ -294,24 +314,30 @@ static int build_aux(moge_handle* h, hipStream_t st) {
         }
     }
     auto stack = [&](const std::string& name) -> int {
-        for (int l = 0; l < 3; l++) {
+        const bool neck = name == "neck";
+        const int* rs = stack_rs(c, neck);
+        for (int l = 0; l < MOGE_LEVELS - 1; l++) {
             const int co = c.dims[l + 1];
-            LCHK(launch_repack<float>(M(h, name + S(".resamplers.%d.0.bias", l)), A(h, name + S(".rs%d.biasT", l)), 4, 1, 1, co, 0, 0, 0, 1, co, 0, 0, st));
-        }
-        if (name != "neck")
-            for (int l = 0; l < 3; l++) {
-                const int co = c.dims[l + 1];
-                std::vector<float> a(co), b(co);
-                HIPCHK(hipMemcpyAsync(a.data(), M(h, name + S(".resamplers.%d.1.bias", l)), co * sizeof(float), hipMemcpyDeviceToHost, st));
-                HIPCHK(hipMemcpyAsync(b.data(), M(h, name + S(".input_blocks.%d.bias", l + 1)), co * sizeof(float), hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
-                for (int i = 0; i < co; i++) a[i] += b[i];
-                HIPCHK(hipMemcpyAsync(A(h, name + S(".rs%d.bias_in", l)), a.data(), co * sizeof(float), hipMemcpyHostToDevice, st));
-                HIPCHK(hipStreamSynchronize(st));
+            if (rs[l] == MOGE_RS_CONV_TRANSPOSE) {
+                LCHK(launch_repack<float>(M(h, name + S(".resamplers.%d.0.bias", l)), A(h, name + S(".rs%d.biasT", l)), 4, 1, 1, co, 0, 0, 0, 1, co, 0, 0, st));
+                if (!neck) {
+                    std::vector<float> a(co), b(co);
+                    HIPCHK(hipMemcpyAsync(a.data(), M(h, name + S(".resamplers.%d.1.bias", l)), co * sizeof(float), hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipMemcpyAsync(b.data(), M(h, name + S(".input_blocks.%d.bias", l + 1)), co * sizeof(float), hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    for (int i = 0; i < co; i++) a[i] += b[i];
+                    HIPCHK(hipMemcpyAsync(A(h, name + S(".rs%d.bias_in", l)), a.data(), co * sizeof(float), hipMemcpyHostToDevice, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                }
+            } else if (rs_is_phase(rs[l])) {
+                // up-sample x2 + 3x3 as a 4-phase conv: bias replicated per phase; the neck adds its next level's input-block bias (rs%d.bias2)
+                const float* b4 = neck ? A(h, S("neck.rs%d.bias2", l)) : M(h, name + S(".resamplers.%d.1.bias", l));
+                LCHK(launch_repack<float>(b4, A(h, name + S(".rs%d.bias4", l)), 4, 1, 1, co, 0, 0, 0, 1, co, 0, 0, st));
+            } else {
+                // pixel_shuffle: bias of the first conv, permuted from PixelShuffle's (co, dy, dx) channel order to (dy, dx, co)
+                LCHK(launch_repack<float>(M(h, name + S(".resamplers.%d.0.bias", l)), A(h, name + S(".rs%d.bias4", l)), 4, 1, 1, co, 1, 0, 0, 4, co, 0, 0, st));
             }
-        // level 3->4 (bilinear + 3x3 as a 4-phase conv): bias replicated per phase; the neck adds its level-4 input-block bias
-        const float* b4 = name == "neck" ? A(h, "neck.rs3.bias2") : M(h, name + ".resamplers.3.1.bias");
-        LCHK(launch_repack<float>(b4, A(h, name + ".rs3.bias4"), 4, 1, 1, c.dims[4], 0, 0, 0, 1, c.dims[4], 0, 0, st));
+        }
         return 0;
     };
     CHK(stack("neck"));
@@ -368,7 +394,7 @@ static int build_aux(moge_handle* h, hipStream_t st) {
         HIPCHK(hipMemcpyAsync(A(h, "neck.in0c.bias"), bc.data(), (size_t)c0 * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
     }
-    if (c.head_res_blocks[0] == 0)
+    if (c.head_res_blocks[0] == 0 && c.head_resamplers[0] == MOGE_RS_CONV_TRANSPOSE)
         for (int k = 0; k < 3; k++)
             if (c.heads & HEAD_BITS[k]) {
                 // head level 0 -> 1: convT(in0(n0)) = (WT Win0) n0 + (WT b_in0 + bT); torch ConvTranspose2d weight [ci][co][2][2]
@@ -424,7 +450,7 @@ static int compose_weights_f16(moge_handle* h, hipStream_t st) {
         if (rc) break;
         if ((rc = dev_matmul_f32(M(h, "neck.input_blocks.0.weight"), c0 + 2, wcat, K4, tmp, c0, K4, c0, scr, st))) break;
         if ((rc = launch_convert<float, f16>(tmp, Pm<f16>(h, "neck.in0c.w"), (long)c0 * K4, st))) break;
-        if (c.head_res_blocks[0] == 0)
+        if (c.head_res_blocks[0] == 0 && c.head_resamplers[0] == MOGE_RS_CONV_TRANSPOSE)
             for (int k = 0; k < 3 && !rc; k++)
                 if (c.heads & HEAD_BITS[k]) {
                     const std::string name = HEAD_NAMES[k];
@@ -480,15 +506,21 @@ static int pack_weights(moge_handle* h, hipStream_t st) {
     auto stack = [&](const std::string& name, bool neck, const int* nres) -> int {
         for (int l = 0; l < MOGE_LEVELS; l++)
             if (!neck) LCHK((launch_convert<float, T>(M(h, name + S(".input_blocks.%d.weight", l)), Pm<T>(h, name + S(".in%d.w", l)), (long)c.dims[l] * c.dims[l], st)));
+        const int* rs = stack_rs(c, neck);
         for (int l = 0; l < MOGE_LEVELS - 1; l++) {
             const int ci = c.dims[l], co = c.dims[l + 1];
-            if (l < 3) {
+            if (rs[l] == MOGE_RS_CONV_TRANSPOSE) {
                 // ConvTranspose2d weight [ci][co][2][2] -> [(dy*2+dx)*co + o][ci]
                 LCHK(launch_repack<T>(M(h, name + S(".resamplers.%d.0.weight", l)), Pm<T>(h, name + S(".rs%d.wT", l)), 4, co, 1, ci, 1, 4, 0, (long)co * 4,
                                       (long)co * ci, ci, 0, st));
                 LCHK(conv3(M(h, name + S(".resamplers.%d.1.weight", l)), Pm<T>(h, name + S(".rs%d.w3", l)), co, co));
+            } else if (rs_is_phase(rs[l])) {
+                LCHK(launch_pack_phase_conv<T>(M(h, name + S(".resamplers.%d.1.weight", l)), Pm<T>(h, name + S(".rs%d.w3p", l)), co, ci, st, rs[l] == MOGE_RS_NEAREST ? 1 : 0));
             } else {
-                LCHK(launch_pack_phase_conv<T>(M(h, name + S(".resamplers.%d.1.weight", l)), Pm<T>(h, name + S(".rs%d.w3p", l)), co, ci, st));
+                // pixel_shuffle: Conv2d weight [(o*4 + q)][ci][3][3] -> [(q*co + o)][tap*ci + c]   (q = dy*2 + dx of nn.PixelShuffle(2))
+                LCHK(launch_repack<T>(M(h, name + S(".resamplers.%d.0.weight", l)), Pm<T>(h, name + S(".rs%d.w3p", l)), 4, co, 9, ci, (long)ci * 9, (long)4 * ci * 9, 1, 9,
+                                      (long)co * 9 * ci, (long)9 * ci, ci, st));
+                LCHK(conv3(M(h, name + S(".resamplers.%d.2.weight", l)), Pm<T>(h, name + S(".rs%d.w3", l)), co, co));
             }
         }
         for (int l = 0; l < MOGE_LEVELS; l++)
@@ -517,6 +549,7 @@ struct Plan {
     int slot = 0;             // index of this (sub-)batch among the batch-split parts (selects the head streams)
     size_t ln_part, ln_mr;    // LN fold: (sum, sum of squares) per row and 32-column group; (mean, rstd) per row
     size_t maskprob, focal, shift, intr, pts_tmp, nrm_tmp, post_end;
+    size_t gn = 0;            // GroupNorm partial sums (normalised residual blocks, ABI v3)
     int B, H, W, rows, cols, Np, Ntok, Npad;
     size_t scratch_elems;
 };
@@ -566,8 +599,18 @@ static Plan make_plan(const moge_config& c, int prec, int B, int H, int W, int r
     p.scratch_elems = mx;
     int nheads = 0;
     for (int k = 0; k < 3; k++) nheads += (c.heads & HEAD_BITS[k]) ? 1 : 0;
-    p.head_sets = (nheads > 1 && moge_tune_get("HEAD_STREAMS", 1) != 0 && B <= moge_tune_get("HEAD_STREAMS_MAX_B", 1)) ? nheads : 1;
+    // (normalised residual blocks share ONE GroupNorm scratch per plan: heads then run one after the other)
+    p.head_sets = (nheads > 1 && moge_tune_get("HEAD_STREAMS", 1) != 0 && B <= moge_tune_get("HEAD_STREAMS_MAX_B", 1) && !stack_has_norm(c, false)) ? nheads : 1;
     for (int i = 0; i < 3 * p.head_sets; i++) p.scratch[i] = take(p, mx * s);
+    if (stack_has_norm(c, true) || stack_has_norm(c, false)) {
+        size_t gmax = 0;
+        for (int l = 0; l < MOGE_LEVELS; l++) {
+            const int G = c.dims[l] / 32 > 0 ? c.dims[l] / 32 : 1;
+            const size_t g1 = groupnorm_scratch_floats(B, rows << l, cols << l, G);
+            if (g1 > gmax) gmax = g1;
+        }
+        p.gn = take(p, gmax * 4);
+    }
     return p;
 }
 static size_t forward_ws_bytes(moge_handle* h, const Plan& pl);
@@ -700,11 +743,38 @@ static int convT2(moge_handle* h, const T* in, const T* w, const float* biasT, T
 // launch, the intermediate map never leaves LDS) cannot run in place, a neighbouring tile still needs the input pixels it would overwrite.
 template <typename T>
 static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* x, T* tmp, int B, int Hh, int Ww, int C, hipStream_t st, bool may_swap = false,
-                      T** res = nullptr) {
+                      T** res = nullptr, T* tmp2 = nullptr, float* gn = nullptr) {
     T* cur = x; T* oth = tmp;
+    const bool neck = name == "neck";
+    const int in_norm = neck ? h->cfg.neck_in_norm : h->cfg.head_in_norm, hid_norm = neck ? h->cfg.neck_hidden_norm : h->cfg.head_hidden_norm;
     for (int j = 0; j < n; j++) {
         const T* w1 = P<T>(h, name + S(".res%d.%d.w1", l, j)); const T* w2 = P<T>(h, name + S(".res%d.%d.w2", l, j));
         const float* b1 = M(h, name + S(".res_blocks.%d.%d.layers.2.bias", l, j)); const float* b2 = M(h, name + S(".res_blocks.%d.%d.layers.5.bias", l, j));
+        if (in_norm || hid_norm) {
+            // normalised block (modules.py:47-67): [GroupNorm ->] ReLU -> 3x3 -> [GroupNorm ->] ReLU -> 3x3, + x.  "layer_norm" = GroupNorm(1, C),
+            // "group_norm" = GroupNorm(C / 32, C); the GroupNorm + ReLU pairs run on MoGe-1's deterministic slab kernels (elementwise.hip)
+            if (!tmp2 || !gn) return fail(MOGE_ERR_INVALID, "res_blocks: normalised blocks need a second scratch map");
+            const std::string r = name + S(".res_blocks.%d.%d.layers.", l, j);
+            auto groups = [&](int mode) { return mode == MOGE_NORM_LAYER ? 1 : (C / 32 > 0 ? C / 32 : 1); };
+            const T* in1 = cur;
+            int relu1 = 1;
+            if (in_norm) {
+                ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)B * Hh * Ww * C * 2 * sizeof(T));
+                LCHK(launch_groupnorm_relu<T>(cur, oth, M(h, r + "0.weight"), M(h, r + "0.bias"), gn, B, Hh, Ww, C, groups(in_norm), st));
+                in1 = oth; relu1 = 0;
+            }
+            T* h1 = in_norm ? tmp2 : oth;                 // conv1's output
+            CHK(conv3x3<T>(h, in1, w1, b1, h1, B, Hh, Ww, C, C, relu1, hid_norm ? ACT_NONE : ACT_RELU, nullptr, nullptr, st));
+            const T* in2 = h1;
+            if (hid_norm) {
+                T* h2 = in_norm ? oth : tmp2;
+                ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)B * Hh * Ww * C * 2 * sizeof(T));
+                LCHK(launch_groupnorm_relu<T>(h1, h2, M(h, r + "3.weight"), M(h, r + "3.bias"), gn, B, Hh, Ww, C, groups(hid_norm), st));
+                in2 = h2;
+            }
+            CHK(conv3x3<T>(h, in2, w2, b2, cur, B, Hh, Ww, C, C, 0, ACT_NONE, cur, nullptr, st));
+            continue;
+        }
         // CONV_RB (default OFF): measured on MI355X the fused launch is 5-10 % SLOWER than the two conv_pp launches at the bench's level-3 shape
         // (1.44-1.46 vs 1.37-1.38 ms at batch 32, profiles/r03a_kbench_rb.log, timeline r03j: one 130 KiB workgroup per CU exposes every
         // latency the two-per-CU conv_pp form hides, and the MFMA segments run at 21.7 clocks per MFMA beside the partner's read segment)
@@ -930,11 +1000,13 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     int nheads = 0;
     for (int k = 0; k < 3; k++) nheads += (c.heads & HEAD_BITS[k]) ? 1 : 0;
     const bool l4dot = std::is_same<T, f16>::value && c.head_res_blocks[MOGE_LEVELS - 1] == 0 && c.neck_res_blocks[MOGE_LEVELS - 1] == 0 && c.dims[4] == 32 &&
-                       c.dims[3] == 64 && moge_tune_get("FUSE_L4", 1) != 0 && moge_tune_get("L4DOT", 1) != 0 && moge_tune_get("CONV_PP", 1) != 0;
+                       c.dims[3] == 64 && rs_is_phase(c.neck_resamplers[3]) && rs_is_phase(c.head_resamplers[3]) &&
+                       moge_tune_get("FUSE_L4", 1) != 0 && moge_tune_get("L4DOT", 1) != 0 && moge_tune_get("CONV_PP", 1) != 0;
     // ---- neck (modules.py:242-254; level-0 uv concat folded into a rank-2 epilogue term, v2.py:154-160) -----------
     T* N[MOGE_LEVELS];
     for (int l = 0; l < MOGE_LEVELS; l++) N[l] = (T*)(ws + pl.neck[l]);
     T* Sc[3] = {(T*)(ws + pl.scratch[0]), (T*)(ws + pl.scratch[1]), (T*)(ws + pl.scratch[2])};
+    float* gn = (float*)(ws + pl.gn);                  // GroupNorm partial sums of the normalised residual blocks (ABI v3 options; unused in the released layout)
     {
         UVTerm uv = uv_term(A(h, "neck.in0.wu"), A(h, "neck.in0.wv"), cols, rows, aspect);
         if (compose) {
@@ -945,23 +1017,30 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
             CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
         } else
         CHK(conv1x1<T>(h, feat, P<T>(h, "neck.in0.w"), M(h, "neck.input_blocks.0.bias"), N[0], BP, c0, c0, nullptr, &uv, cols, rows, st));
-        CHK(res_blocks<T>(h, "neck", 0, c.neck_res_blocks[0], N[0], Sc[0], B, rows, cols, c0, st));
+        CHK(res_blocks<T>(h, "neck", 0, c.neck_res_blocks[0], N[0], Sc[0], B, rows, cols, c0, st, false, nullptr, Sc[1], gn));
         for (int l = 1; l < MOGE_LEVELS; l++) {
             const int Hh = rows << l, Ww = cols << l, ci = c.dims[l - 1], co = c.dims[l];
+            const int rsl = c.neck_resamplers[l - 1];
+            // level l's input block sees the (u, v) planes only (v2.py:154-160): a rank-2 term + bias, carried by the epilogue of the resampler's LAST conv
             UVTerm uvl = uv_term(A(h, S("neck.in%d.wu", l)), A(h, S("neck.in%d.wv", l)), Ww, Hh, aspect);
-            if (l <= 3) {
+            if (rsl == MOGE_RS_CONV_TRANSPOSE) {
                 CHK(convT2<T>(h, N[l - 1], P<T>(h, S("neck.rs%d.wT", l - 1)), A(h, S("neck.rs%d.biasT", l - 1)), Sc[0], B, Hh / 2, Ww / 2, ci, co, st));
                 CHK(conv3x3<T>(h, Sc[0], P<T>(h, S("neck.rs%d.w3", l - 1)), A(h, S("neck.rs%d.bias2", l - 1)), N[l], B, Hh, Ww, co, co, 0, ACT_NONE, nullptr,
                                &uvl, st));
-            } else if (l4dot) {
+            } else if (rsl == MOGE_RS_PIXEL_SHUFFLE) {
+                // Conv2d(ci, 4 co) + PixelShuffle = a 3x3 conv on the low-res map stored through the pixel-shuffle epilogue, then the second 3x3 conv
+                CHK(conv_up2_phase<T>(h, N[l - 1], P<T>(h, S("neck.rs%d.w3p", l - 1)), A(h, S("neck.rs%d.bias4", l - 1)), Sc[0], B, Hh / 2, Ww / 2, ci, co, nullptr, st));
+                CHK(conv3x3<T>(h, Sc[0], P<T>(h, S("neck.rs%d.w3", l - 1)), A(h, S("neck.rs%d.bias2", l - 1)), N[l], B, Hh, Ww, co, co, 0, ACT_NONE, nullptr,
+                               &uvl, st));
+            } else if (l == MOGE_LEVELS - 1 && l4dot) {
                 // the neck's level-4 map is only ever read through the heads' composed input block + output conv (no residual blocks at level
                 // 4): the resampler applies all of them per pixel and stores 4 floats per head instead of 32 halves
                 CHK(conv_up2_phase<T>(h, N[l - 1], P<T>(h, "neck.rs3.w3p"), A(h, "neck.rs3.bias4"), N[l], B, Hh / 2, Ww / 2, ci, co, &uvl, st, A(h, "neck.dot"), nheads,
                                       (float*)N[l]));
             } else {
-                CHK(conv_up2_phase<T>(h, N[l - 1], P<T>(h, "neck.rs3.w3p"), A(h, "neck.rs3.bias4"), N[l], B, Hh / 2, Ww / 2, ci, co, &uvl, st));
+                CHK(conv_up2_phase<T>(h, N[l - 1], P<T>(h, S("neck.rs%d.w3p", l - 1)), A(h, S("neck.rs%d.bias4", l - 1)), N[l], B, Hh / 2, Ww / 2, ci, co, &uvl, st));
             }
-            CHK(res_blocks<T>(h, "neck", l, c.neck_res_blocks[l], N[l], Sc[1], B, Hh, Ww, co, st));
+            CHK(res_blocks<T>(h, "neck", l, c.neck_res_blocks[l], N[l], Sc[1], B, Hh, Ww, co, st, false, nullptr, Sc[2], gn));
         }
     }
     // ---- heads -------------------------------------------------------------------------------------------------------
@@ -1009,24 +1088,29 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
             for (int i = 0; i < 3; i++) Sc[i] = (T*)(ws + pl.scratch[i]);
         }
         int cur = 0;                       // Sc[cur] holds the running x
-        const bool compose0 = compose && c.head_res_blocks[0] == 0;       // level 0 -> 1: ConvTranspose2d(input block(n0)) as one GEMM on n0
+        const bool compose0 = compose && c.head_res_blocks[0] == 0 && c.head_resamplers[0] == MOGE_RS_CONV_TRANSPOSE;       // level 0 -> 1: ConvTranspose2d(input block(n0)) as one GEMM on n0
         if (!compose0) {
             CHK(conv1x1<T>(h, N[0], P<T>(h, name + ".in0.w"), M(h, name + ".input_blocks.0.bias"), Sc[cur], BP, c0, c0, nullptr, nullptr, cols, rows, st));
-            CHK(res_blocks<T>(h, name, 0, c.head_res_blocks[0], Sc[cur], Sc[(cur + 1) % 3], B, rows, cols, c0, st));
+            CHK(res_blocks<T>(h, name, 0, c.head_res_blocks[0], Sc[cur], Sc[(cur + 1) % 3], B, rows, cols, c0, st, false, nullptr, Sc[(cur + 2) % 3], gn));
         }
         for (int l = 1; l < MOGE_LEVELS; l++) {
             const int Hh = rows << l, Ww = cols << l, ci = c.dims[l - 1], co = c.dims[l];
             const int a = (cur + 1) % 3, b2 = (cur + 2) % 3;
+            const int rsl = c.head_resamplers[l - 1];
             int nxt;
             bool in_fused = false;
-            if (l <= 3) {
-                if (l == 1 && compose0)
+            if (rsl == MOGE_RS_CONV_TRANSPOSE || rsl == MOGE_RS_PIXEL_SHUFFLE) {
+                if (rsl == MOGE_RS_PIXEL_SHUFFLE)
+                    CHK(conv_up2_phase<T>(h, Sc[cur], P<T>(h, name + S(".rs%d.w3p", l - 1)), A(h, name + S(".rs%d.bias4", l - 1)), Sc[a], B, Hh / 2, Ww / 2, ci, co, nullptr, st));
+                else if (l == 1 && compose0)
                     CHK(convT2<T>(h, N[0], P<T>(h, name + ".rs0.wTc"), A(h, name + ".rs0.biasTc"), Sc[a], B, Hh / 2, Ww / 2, ci, co, st));
                 else
                 CHK(convT2<T>(h, Sc[cur], P<T>(h, name + S(".rs%d.wT", l - 1)), A(h, name + S(".rs%d.biasT", l - 1)), Sc[a], B, Hh / 2, Ww / 2, ci, co, st));
+                const float* plain_bias = M(h, name + S(".resamplers.%d.%s.bias", l - 1, rs_final_conv(rsl)));
                 // resampler conv, with the head's `x + in_l(neck_l)` fused as a 1x1 side input when the halo kernel takes the shape
                 // (the first attempt passes the combined bias; if the shape is not eligible nothing ran and the plain form follows)
-                const bool try_fuse = std::is_same<T, f16>::value && moge_tune_get("FUSE_IN", 1) != 0 && moge_tune_get("CONV_PP", 1) != 0;
+                const bool try_fuse = std::is_same<T, f16>::value && rsl == MOGE_RS_CONV_TRANSPOSE && moge_tune_get("FUSE_IN", 1) != 0 && moge_tune_get("CONV_PP", 1) != 0 &&
+                                      !(l == MOGE_LEVELS - 1 && fuse_l4);
                 if (try_fuse) {
                     GemmArgs probe = gemm_args();
                     probe.a = Sc[a]; probe.H = Hh; probe.W = Ww; probe.C = co; probe.w = P<T>(h, name + S(".rs%d.w3", l - 1)); probe.ldw = 9 * co;
@@ -1038,15 +1122,15 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
                     }
                 }
                 if (!in_fused)
-                    CHK(conv3x3<T>(h, Sc[a], P<T>(h, name + S(".rs%d.w3", l - 1)), M(h, name + S(".resamplers.%d.1.bias", l - 1)), Sc[b2], B, Hh, Ww, co, co, 0,
+                    CHK(conv3x3<T>(h, Sc[a], P<T>(h, name + S(".rs%d.w3", l - 1)), plain_bias, Sc[b2], B, Hh, Ww, co, co, 0,
                                    ACT_NONE, nullptr, nullptr, st));
                 nxt = b2;
-            } else if (l4dot) {
+            } else if (l == MOGE_LEVELS - 1 && l4dot) {
                 CHK(conv_up2_phase<T>(h, Sc[cur], P<T>(h, name + ".rs3.w3p"), A(h, name + ".rs3.bias4"), Sc[a], B, Hh / 2, Ww / 2, ci, co, nullptr, st, A(h, name + ".dot.own"), 1,
                                       (float*)Sc[a]));
                 nxt = a;
             } else {
-                CHK(conv_up2_phase<T>(h, Sc[cur], P<T>(h, name + ".rs3.w3p"), A(h, name + ".rs3.bias4"), Sc[a], B, Hh / 2, Ww / 2, ci, co, nullptr, st));
+                CHK(conv_up2_phase<T>(h, Sc[cur], P<T>(h, name + S(".rs%d.w3p", l - 1)), A(h, name + S(".rs%d.bias4", l - 1)), Sc[a], B, Hh / 2, Ww / 2, ci, co, nullptr, st));
                 nxt = a;
             }
             // x = x + in_l(neck_l)   (in place: each element is read and written by the same lane); at the last level of the fp16
@@ -1057,7 +1141,7 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
             cur = nxt;
             {
                 T* r = nullptr;                 // fused blocks ping-pong between the two buffers: follow the result
-                CHK(res_blocks<T>(h, name, l, c.head_res_blocks[l], Sc[cur], Sc[(cur + 1) % 3], B, Hh, Ww, co, st, true, &r));
+                CHK(res_blocks<T>(h, name, l, c.head_res_blocks[l], Sc[cur], Sc[(cur + 1) % 3], B, Hh, Ww, co, st, true, &r, Sc[(cur + 2) % 3], gn));
                 if (r != Sc[cur]) cur = (cur + 1) % 3;
             }
         }
@@ -1319,6 +1403,20 @@ int moge_create(const moge_config* cfg, int device, moge_handle** out) {
         if (c.dims[l] % 8 != 0 || c.dims[l] <= 0) return fail(MOGE_ERR_INVALID, "stack dims must be positive multiples of 8");
     if (c.dims[4] > 64) return fail(MOGE_ERR_INVALID, "last level wider than 64 channels is not supported");
     if ((c.heads & MOGE_HEAD_SCALE) && (c.scale_hidden <= 0 || c.scale_hidden % 4 != 0)) return fail(MOGE_ERR_INVALID, "bad scale_hidden");
+    for (int l = 0; l < MOGE_LEVELS - 1; l++)
+        if (c.neck_resamplers[l] < 0 || c.neck_resamplers[l] > MOGE_RS_PIXEL_SHUFFLE || c.head_resamplers[l] < 0 || c.head_resamplers[l] > MOGE_RS_PIXEL_SHUFFLE)
+            return fail(MOGE_ERR_INVALID, "bad resampler code at level %d", l);
+    for (int nk = 0; nk < 2; nk++) {
+        const int in_n = nk ? c.neck_in_norm : c.head_in_norm, hid_n = nk ? c.neck_hidden_norm : c.head_hidden_norm;
+        if (in_n < 0 || in_n > MOGE_NORM_GROUP || hid_n < 0 || hid_n > MOGE_NORM_GROUP) return fail(MOGE_ERR_INVALID, "bad res-block norm code");
+        if (in_n || hid_n)
+            for (int l = 0; l < MOGE_LEVELS; l++) {
+                // GroupNorm runs on gn_partial's fixed slabs (as in moge_create_v1): widths 32 ... 512, powers of two
+                const int C = c.dims[l], nb = nk ? c.neck_res_blocks[l] : c.head_res_blocks[l];
+                if (nb > 0 && C != 32 && C != 64 && C != 128 && C != 256 && C != 512)
+                    return fail(MOGE_ERR_INVALID, "normalised residual blocks at level %d need a width of 32 / 64 / 128 / 256 / 512, got %d", l, C);
+            }
+    }
     HIPCHK(hipSetDevice(device));
     moge_handle* h = new moge_handle();
     h->cfg = c;
@@ -1457,7 +1555,10 @@ RcclApi& rccl_api() {
 int moge_broadcast_weights(moge_handle* h, void* nccl_comm, int root, void* stream) {
     if (!h || !nccl_comm) return fail(MOGE_ERR_INVALID, "null argument");
     RcclApi& api = rccl_api();
-    if (!api.ok) return fail(MOGE_ERR_INVALID, "RCCL not available: librccl.so.1 could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+    if (!api.ok) {
+        const char* why = dlerror();                            // (one call: dlerror() clears the message it returns)
+        return fail(MOGE_ERR_INVALID, "RCCL not available: librccl.so.1 could not be loaded (%s)", why ? why : "symbols missing");
+    }
     HIPCHK(hipSetDevice(h->device));
     int rank = -1, n = 0;
     int rc = api.user_rank(nccl_comm, &rank);

@@ -23,18 +23,27 @@ _RESAMPLERS = ["conv_transpose", "conv_transpose", "conv_transpose", "bilinear"]
 _HEADS = [("points_head", L.HEAD_POINTS, 3), ("normal_head", L.HEAD_NORMAL, 3), ("mask_head", L.HEAD_MASK, 1)]
 
 
-def _check_stack(name: str, sc: Dict[str, Any], dims: List[int], neck: bool) -> List[int]:
+def _check_stack(name: str, sc: Dict[str, Any], dims: List[int], neck: bool):
+    """-> (num_res_blocks per level, resampler codes, (in_norm, hidden_norm) codes) of one ConvStack config (modules.py:195-240).
+    Supported: x2 up-samplers conv_transpose / bilinear / nearest / pixel_shuffle per level, residual-block norms none / layer_norm /
+    group_norm, ReLU, hidden width = width.  (Down-samplers, instance_norm, other activations: no MoGe decoder uses them.)"""
     if list(sc["dim_res_blocks"]) != list(dims):
         raise NotImplementedError(f"{name}: dim_res_blocks must equal the neck's ({dims})")
     res = sc.get("resamplers", "conv_transpose")
-    if list(res) != _RESAMPLERS:
-        raise NotImplementedError(f"{name}: only resamplers {_RESAMPLERS} (the released MoGe-2 layout) are implemented, got {res}")
-    if sc.get("res_block_in_norm", "layer_norm") != "none" or sc.get("res_block_hidden_norm", "group_norm") != "none":
-        raise NotImplementedError(f"{name}: only res_block_*_norm='none' is implemented")
+    res = list(res) if isinstance(res, (list, tuple)) else [res] * 4
+    if len(res) != 4 or any(r not in L.RESAMPLER for r in res):
+        raise NotImplementedError(f"{name}: resamplers {res} unsupported (four of {sorted(L.RESAMPLER)})")
+    in_norm, hid_norm = sc.get("res_block_in_norm", "layer_norm"), sc.get("res_block_hidden_norm", "group_norm")
+    if in_norm not in L.RES_NORM or hid_norm not in L.RES_NORM:
+        raise NotImplementedError(f"{name}: res_block norms ({in_norm}, {hid_norm}) unsupported ({sorted(L.RES_NORM)})")
     if sc.get("activation", "relu") != "relu" or sc.get("dim_times_res_block_hidden", 1) != 1:
         raise NotImplementedError(f"{name}: only ReLU res blocks with hidden = dim are implemented")
     nres = sc.get("num_res_blocks", 1)
     nres = list(nres) if isinstance(nres, (list, tuple)) else [nres] * 5
+    if in_norm != "none" or hid_norm != "none":
+        for l in range(5):
+            if nres[l] > 0 and dims[l] not in (32, 64, 128, 256, 512):
+                raise NotImplementedError(f"{name}: normalised residual blocks need a width of 32 / 64 / 128 / 256 / 512 (level {l}: {dims[l]})")
     dim_in = list(sc["dim_in"])
     want_in = [dims[0] + 2, 2, 2, 2, 2] if neck else list(dims)
     if dim_in != want_in:
@@ -43,7 +52,7 @@ def _check_stack(name: str, sc: Dict[str, Any], dims: List[int], neck: bool) -> 
     dim_out = list(dim_out) if isinstance(dim_out, (list, tuple)) else [dim_out] * 5
     if neck and any(d is not None for d in dim_out):
         raise NotImplementedError("neck.dim_out must be null")
-    return nres
+    return nres, [L.RESAMPLER[r] for r in res], (L.RES_NORM[in_norm], L.RES_NORM[hid_norm])
 
 
 class MoGeModel:
@@ -74,21 +83,21 @@ class MoGeModel:
         cfg.embed_dim, cfg.depth, cfg.num_heads, cfg.n_taps = D, depth, heads, len(taps)
         for i, t in enumerate(taps):
             cfg.taps[i] = t
-        neck_res = _check_stack("neck", neck, dims, True)
-        head_res = None
+        neck_res, neck_rs, neck_norm = _check_stack("neck", neck, dims, True)
+        head_res = head_rs = head_norm = None
         bits = 0
         self._head_names = []
         for name, bit, cout in _HEADS:
             sc = {"points_head": points_head, "normal_head": normal_head, "mask_head": mask_head}[name]
             if sc is None:
                 continue
-            r = _check_stack(name, sc, dims, False)
+            r, rs, nm = _check_stack(name, sc, dims, False)
             do = sc.get("dim_out")
             if not isinstance(do, (list, tuple)) or list(do[:4]) != [None] * 4 or do[4] != cout:
                 raise NotImplementedError(f"{name}: dim_out must be [null,null,null,null,{cout}]")
-            if head_res is not None and r != head_res:
-                raise NotImplementedError("all heads must share num_res_blocks")
-            head_res = r
+            if head_res is not None and (r != head_res or rs != head_rs or nm != head_norm):
+                raise NotImplementedError("all heads must share num_res_blocks, resamplers and res-block norms")
+            head_res, head_rs, head_norm = r, rs, nm
             bits |= bit
             self._head_names.append(name)
         if scale_head is not None:
@@ -101,6 +110,11 @@ class MoGeModel:
             cfg.dims[l] = dims[l]
             cfg.neck_res_blocks[l] = neck_res[l]
             cfg.head_res_blocks[l] = (head_res or [0] * 5)[l]
+        for l in range(4):
+            cfg.neck_resamplers[l] = neck_rs[l]
+            cfg.head_resamplers[l] = (head_rs or neck_rs)[l]
+        cfg.neck_in_norm, cfg.neck_hidden_norm = neck_norm
+        cfg.head_in_norm, cfg.head_hidden_norm = head_norm or (0, 0)
         cfg.heads = bits
         cfg.remap_output = L.REMAP[remap_output]
         self._cfg = cfg

@@ -185,6 +185,12 @@ CASES = [
     # points only -> no mask, no metric scale, no normal
     dict(name="tiny_no_points_head", config="tiny-vits-normal", cfg_override=dict(drop=["points_head"]), seed=0, sane=True, input_seed=24, shape=[2, 3, 84, 112],
          kwargs=dict(num_tokens=108, use_fp16=False)),
+    # every ConvStack option the released models do not use (modules.py:139-181: pixel_shuffle / nearest / bilinear / conv_transpose at every
+    # level of both stacks; modules.py:47-60: GroupNorm(1, C) and GroupNorm(C / 32, C) residual blocks)
+    dict(name="tiny_generic_stack", config="tiny-generic-stack", seed=0, sane=True, input_seed=26, shape=[2, 3, 84, 112],
+         kwargs=dict(num_tokens=108, use_fp16=False)),
+    dict(name="tiny_generic_stack_b", config="tiny-generic-stack-b", seed=1, sane=True, input_seed=27, shape=[1, 3, 98, 126],
+         kwargs=dict(num_tokens=120, use_fp16=False)),
     dict(name="tiny_points_head_only", config="tiny-vits-normal", cfg_override=dict(drop=["mask_head", "normal_head", "scale_head"]), seed=0, sane=True, input_seed=25,
          shape=[2, 3, 84, 112], kwargs=dict(num_tokens=108, use_fp16=False)),
 ]

@@ -53,22 +53,24 @@ HEAD_NAMES = ("points_head", "normal_head", "mask_head")
 # --------------------------------------------------------------------------------------------
 def make_config(backbone: str = "dinov2_vitl14", taps: Sequence[int] = (5, 11, 17, 23),
                 dims: Sequence[int] = (1024, 256, 128, 64, 32), normal: bool = True,
-                scale_hidden: Optional[int] = None, num_tokens_range=(1200, 3600)) -> dict:
-    """model_config in the shape of configs/train/v2.json:238-285 (vitl) for any backbone/dims."""
+                scale_hidden: Optional[int] = None, num_tokens_range=(1200, 3600),
+                neck_resamplers=None, head_resamplers=None, neck_norms=("none", "none"), head_norms=("none", "none")) -> dict:
+    """model_config in the shape of configs/train/v2.json:238-285 (vitl) for any backbone/dims; the ConvStack options the released models
+    leave at [conv_transpose x3, bilinear] / no norms (modules.py:139-181, 47-60) can be set for the generic-layout test configs."""
     D = VIT_SPECS[backbone][0]
     dims = list(dims)
     resamplers = ["conv_transpose", "conv_transpose", "conv_transpose", "bilinear"]
 
     def head(cout):
         return {"dim_in": list(dims), "dim_out": [None, None, None, None, cout], "dim_res_blocks": list(dims),
-                "num_res_blocks": [0, 1, 1, 1, 0], "res_block_in_norm": "none", "res_block_hidden_norm": "none",
-                "resamplers": list(resamplers)}
+                "num_res_blocks": [0, 1, 1, 1, 0], "res_block_in_norm": head_norms[0], "res_block_hidden_norm": head_norms[1],
+                "resamplers": list(head_resamplers or resamplers)}
 
     cfg = {
         "encoder": {"backbone": backbone, "intermediate_layers": list(taps), "dim_out": dims[0]},
         "neck": {"dim_in": [dims[0] + 2, 2, 2, 2, 2], "dim_out": None, "dim_res_blocks": list(dims),
-                 "num_res_blocks": [0, 2, 2, 2, 0], "res_block_in_norm": "none", "res_block_hidden_norm": "none",
-                 "resamplers": list(resamplers)},
+                 "num_res_blocks": [0, 2, 2, 2, 0], "res_block_in_norm": neck_norms[0], "res_block_hidden_norm": neck_norms[1],
+                 "resamplers": list(neck_resamplers or resamplers)},
         "points_head": head(3),
         "mask_head": head(1),
         "scale_head": {"dims": [D, scale_hidden or D, scale_hidden or D, 1]},
@@ -89,6 +91,16 @@ def named_configs() -> Dict[str, dict]:
         "moge-2-vitb-normal": make_config("dinov2_vitb14", (2, 5, 8, 11), (512, 256, 128, 64, 32), True),
         "moge-2-vits-normal": make_config("dinov2_vits14", (2, 5, 8, 11), (384, 256, 128, 64, 32), True),
         "tiny-vits-normal": make_config("dinov2_vits14", (2, 5, 8, 11), (128, 64, 64, 32, 32), True, scale_hidden=128),
+        # every ConvStack option of the decoder that no released model uses (modules.py:139-181, 47-60): all four x2 up-samplers in both
+        # stacks, GroupNorm(1, C) / GroupNorm(C / 32, C) residual blocks
+        "tiny-generic-stack": make_config("dinov2_vits14", (2, 5, 8, 11), (128, 64, 64, 32, 32), True, scale_hidden=128,
+                                          neck_resamplers=["pixel_shuffle", "nearest", "bilinear", "conv_transpose"],
+                                          head_resamplers=["nearest", "conv_transpose", "pixel_shuffle", "bilinear"],
+                                          neck_norms=("layer_norm", "group_norm"), head_norms=("none", "layer_norm")),
+        "tiny-generic-stack-b": make_config("dinov2_vits14", (2, 5, 8, 11), (128, 64, 64, 32, 32), True, scale_hidden=128,
+                                            neck_resamplers=["bilinear", "conv_transpose", "pixel_shuffle", "nearest"],
+                                            head_resamplers=["conv_transpose", "pixel_shuffle", "bilinear", "conv_transpose"],
+                                            neck_norms=("none", "none"), head_norms=("group_norm", "none")),
     }
 
 
@@ -133,13 +145,24 @@ def state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
                 out.append((f"{name}.resamplers.{l}.0.bias", (cout,)))
                 out.append((f"{name}.resamplers.{l}.1.weight", (cout, cout, 3, 3)))
                 out.append((f"{name}.resamplers.{l}.1.bias", (cout,)))
-            elif kind == "bilinear":
+            elif kind in ("bilinear", "nearest"):
                 out.append((f"{name}.resamplers.{l}.1.weight", (cout, cin, 3, 3)))
                 out.append((f"{name}.resamplers.{l}.1.bias", (cout,)))
+            elif kind == "pixel_shuffle":           # Conv2d(cin, 4 cout, 3) -> PixelShuffle(2) -> Conv2d(cout, cout, 3)   (modules.py:146-151)
+                out.append((f"{name}.resamplers.{l}.0.weight", (4 * cout, cin, 3, 3)))
+                out.append((f"{name}.resamplers.{l}.0.bias", (4 * cout,)))
+                out.append((f"{name}.resamplers.{l}.2.weight", (cout, cout, 3, 3)))
+                out.append((f"{name}.resamplers.{l}.2.bias", (cout,)))
             else:
                 raise NotImplementedError(kind)
         for l, c in enumerate(dims):
             for j in range(nres[l]):
+                if sc["res_block_in_norm"] != "none":          # GroupNorm affine parameters (modules.py:47-50)
+                    out.append((f"{name}.res_blocks.{l}.{j}.layers.0.weight", (c,)))
+                    out.append((f"{name}.res_blocks.{l}.{j}.layers.0.bias", (c,)))
+                if sc["res_block_hidden_norm"] != "none":
+                    out.append((f"{name}.res_blocks.{l}.{j}.layers.3.weight", (c,)))
+                    out.append((f"{name}.res_blocks.{l}.{j}.layers.3.bias", (c,)))
                 for li in (2, 5):
                     out.append((f"{name}.res_blocks.{l}.{j}.layers.{li}.weight", (c, c, 3, 3)))
                     out.append((f"{name}.res_blocks.{l}.{j}.layers.{li}.bias", (c,)))
@@ -183,6 +206,8 @@ def synth_state_dict(cfg: dict, seed: int = 0, sane_geometry: bool = True) -> Di
             t = 0.5 * torch.randn(shape, generator=g)
         elif "norm" in key and leaf == "weight" and len(shape) == 1:
             t = 1.0 + 0.2 * torch.randn(shape, generator=g)
+        elif leaf == "weight" and len(shape) == 1:          # GroupNorm weights of normalised residual blocks (generic-layout configs only)
+            t = 1.0 + 0.2 * torch.randn(shape, generator=g)
         elif leaf == "gamma":
             t = 0.05 + 0.25 * torch.rand(shape, generator=g)
         elif leaf == "bias":
@@ -206,7 +231,7 @@ def synth_state_dict(cfg: dict, seed: int = 0, sane_geometry: bool = True) -> Di
         w.mul_(0.3)
         w[0, 0, 0, 0] = 4.0
         w[1, 1, 0, 0] = 4.0
-        rs = sd["neck.resamplers.3.1.weight"]
+        rs = sd["neck.resamplers.3.%s.weight" % ("2" if cfg["neck"]["resamplers"][3] == "pixel_shuffle" else "1")]
         rs[0:2].mul_(0.15)
         ph = "points_head."
     if sane_geometry and cfg.get("points_head") is not None:
@@ -214,7 +239,7 @@ def synth_state_dict(cfg: dict, seed: int = 0, sane_geometry: bool = True) -> Di
         w[0:2].mul_(0.1)
         w[0, 0, 0, 0] = 1.0
         w[1, 1, 0, 0] = 1.0
-        sd[ph + "resamplers.3.1.weight"][0:2].mul_(0.1)
+        sd[ph + "resamplers.3.%s.weight" % ("2" if cfg["points_head"]["resamplers"][3] == "pixel_shuffle" else "1")][0:2].mul_(0.1)
         wo = sd[ph + "output_blocks.4.weight"]
         wo.mul_(0.25)
         wo[0].mul_(0.2); wo[1].mul_(0.2)
@@ -375,9 +400,18 @@ def _conv3(x, w, b):
     return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), w, b)
 
 
+def _res_norm(x, kind, w, b):
+    """in_norm / hidden_norm of ResidualConvBlock (modules.py:47-58): GroupNorm(1, C) ("layer_norm") or GroupNorm(C // 32, C) ("group_norm")."""
+    if kind == "none":
+        return x
+    C = x.shape[1]
+    return F.group_norm(x, 1 if kind == "layer_norm" else C // 32, w, b, eps=1e-5)
+
+
 def conv_stack(sc: dict, sd: Dict[str, torch.Tensor], name: str, feats: List[Optional[torch.Tensor]]) -> List[torch.Tensor]:
-    """ConvStack.forward (modules.py:242-254) with the released v2 options: no norms, ReLU, conv_transpose/bilinear."""
-    assert sc["res_block_in_norm"] == "none" and sc["res_block_hidden_norm"] == "none"
+    """ConvStack.forward (modules.py:242-254): ReLU residual blocks with optional GroupNorms, the x2 up-samplers conv_transpose / bilinear /
+    nearest / pixel_shuffle (modules.py:139-181).  The released v2 models use no norms and [conv_transpose x3, bilinear]."""
+    in_norm, hid_norm = sc["res_block_in_norm"], sc["res_block_hidden_norm"]
     dims = sc["dim_res_blocks"]
     dim_out = sc["dim_out"] if isinstance(sc["dim_out"], list) else [sc["dim_out"]] * len(dims)
     outs = []
@@ -389,7 +423,9 @@ def conv_stack(sc: dict, sd: Dict[str, torch.Tensor], name: str, feats: List[Opt
         x = f if l == 0 else x + f
         for j in range(sc["num_res_blocks"][l]):
             p = f"{name}.res_blocks.{l}.{j}.layers."
-            y = _conv3(F.relu(x), sd[p + "2.weight"], sd[p + "2.bias"])
+            y = _res_norm(x, in_norm, sd.get(p + "0.weight"), sd.get(p + "0.bias"))
+            y = _conv3(F.relu(y), sd[p + "2.weight"], sd[p + "2.bias"])
+            y = _res_norm(y, hid_norm, sd.get(p + "3.weight"), sd.get(p + "3.bias"))
             y = _conv3(F.relu(y), sd[p + "5.weight"], sd[p + "5.bias"])
             x = x + y
         if dim_out[l] is not None:
@@ -398,12 +434,19 @@ def conv_stack(sc: dict, sd: Dict[str, torch.Tensor], name: str, feats: List[Opt
             outs.append(x)
         if l < len(dims) - 1:
             p = f"{name}.resamplers.{l}."
-            if sc["resamplers"][l] == "conv_transpose":
+            kind = sc["resamplers"][l]
+            if kind == "pixel_shuffle":
+                x = F.pixel_shuffle(_conv3(x, sd[p + "0.weight"], sd[p + "0.bias"]), 2)
+                x = _conv3(x, sd[p + "2.weight"], sd[p + "2.bias"])
+                continue
+            if kind == "conv_transpose":
                 x = F.conv_transpose2d(x, sd[p + "0.weight"], sd[p + "0.bias"], stride=2)
-            elif sc["resamplers"][l] == "bilinear":
+            elif kind == "bilinear":
                 x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+            elif kind == "nearest":
+                x = F.interpolate(x, scale_factor=2, mode="nearest")
             else:
-                raise NotImplementedError(sc["resamplers"][l])
+                raise NotImplementedError(kind)
             x = _conv3(x, sd[p + "1.weight"], sd[p + "1.bias"])
     return outs
 

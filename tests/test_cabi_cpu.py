@@ -16,12 +16,12 @@ def test_library_exports_match_header():
     assert declared == sorted(L.EXPORTS)
     for name in declared:
         assert hasattr(L.lib, name), f"libmoge_hip.so does not export {name}"
-    assert L.lib.moge_abi_version() == L.ABI_VERSION == 2
+    assert L.lib.moge_abi_version() == L.ABI_VERSION == 3
 
 
 def test_config_struct_layout():
     from moge_amd import _lib as L
-    assert ctypes.sizeof(L.MogeConfig) == 4 * (4 + 8 + 5 + 5 + 5 + 3)
+    assert ctypes.sizeof(L.MogeConfig) == 4 * (4 + 8 + 5 + 5 + 5 + 3 + 4 + 4 + 4)
     assert ctypes.sizeof(L.Outputs) == 9 * ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(L.Profile) == 8 * 8 * 4
 
@@ -45,6 +45,33 @@ def test_model_mirror_host_logic():
         M(**{**O.named_configs()["tiny-vits-normal"], "remap_output": "bogus"})
     with pytest.raises(RuntimeError):
         m.to("cpu")            # no CPU fallback, by design
+
+
+def test_mirror_maps_every_convstack_option_it_supports():
+    """modules.py:139-181, 47-60: the x2 up-samplers and residual-block norms of ConvStack reach the C ABI as codes (ABI v3); options no decoder
+    uses (down-samplers, instance_norm, other activations, a hidden-width multiplier) are refused when the model is constructed."""
+    import copy
+    from moge_amd import _lib as L
+    from moge_amd.model import import_model_class_by_version
+    from oracle import moge_oracle as O
+    M = import_model_class_by_version("v2")
+    cfg = O.named_configs()["tiny-generic-stack"]
+    m = M(**cfg)
+    assert list(m._cfg.neck_resamplers) == [L.RESAMPLER[r] for r in cfg["neck"]["resamplers"]] == [3, 2, 1, 0]
+    assert list(m._cfg.head_resamplers) == [2, 0, 3, 1]
+    assert (m._cfg.neck_in_norm, m._cfg.neck_hidden_norm, m._cfg.head_in_norm, m._cfg.head_hidden_norm) == (1, 2, 0, 1)
+    rel = M(**O.named_configs()["moge-2-vitl-normal"])._cfg
+    assert list(rel.neck_resamplers) == list(rel.head_resamplers) == [0, 0, 0, 1] and rel.neck_in_norm == rel.head_hidden_norm == 0
+    for path, value in ((("neck", "resamplers"), ["conv_transpose", "avg_pool", "conv_transpose", "bilinear"]), (("points_head", "res_block_in_norm"), "instance_norm"),
+                        (("neck", "activation"), "silu"), (("mask_head", "dim_times_res_block_hidden"), 2)):
+        bad = copy.deepcopy(cfg)
+        bad[path[0]][path[1]] = value
+        with pytest.raises(NotImplementedError):
+            M(**bad)
+    wide = copy.deepcopy(O.named_configs()["moge-2-vitl-normal"])           # GroupNorm slabs: widths 32 ... 512 only
+    wide["neck"]["res_block_in_norm"] = "layer_norm"; wide["neck"]["num_res_blocks"] = [1, 2, 2, 2, 0]
+    with pytest.raises(NotImplementedError):
+        M(**wide)
 
 
 def test_create_rejects_bad_config_without_gpu():
