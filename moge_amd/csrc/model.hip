@@ -437,11 +437,13 @@ static int compose_weights_f16(moge_handle* h, hipStream_t st) {
     const int D = c.embed_dim, c0 = c.dims[0], K4 = c.n_taps * D, co = c.dims[1];
     const size_t nscr = (size_t)c0 * c0 + (size_t)K4 * c0 + (size_t)4 * co * c0 + (size_t)c0 * c0;
     const size_t ntmp = (size_t)c0 * K4 > (size_t)4 * co * c0 ? (size_t)c0 * K4 : (size_t)4 * co * c0;
-    float *scr = nullptr, *tmp = nullptr, *wcat = nullptr, *wT = nullptr;
-    HIPCHK(hipMalloc(&scr, nscr * 4));
-    HIPCHK(hipMalloc(&tmp, ntmp * 4));
-    HIPCHK(hipMalloc(&wcat, (size_t)c0 * K4 * 4));
-    HIPCHK(hipMalloc(&wT, (size_t)4 * co * c0 * 4));
+    // one temporary arena (freed on every path below): scr | tmp | wcat | wT
+    float* arena = nullptr;
+    HIPCHK(hipMalloc(&arena, (nscr + ntmp + (size_t)c0 * K4 + (size_t)4 * co * c0) * 4));
+    float* scr = arena;
+    float* tmp = scr + nscr;
+    float* wcat = tmp + ntmp;
+    float* wT = wcat + (size_t)c0 * K4;
     int rc = 0;
     do {
         // Wout_cat [c0][n_taps * D] (fp32), then (Win0[:, :c0]) . Wout_cat
@@ -461,7 +463,7 @@ static int compose_weights_f16(moge_handle* h, hipStream_t st) {
                 }
     } while (0);
     hipError_t e = hipStreamSynchronize(st);
-    hipFree(scr); hipFree(tmp); hipFree(wcat); hipFree(wT);
+    hipFree(arena);
     if (rc) return fail(rc < 0 ? MOGE_ERR_INVALID : MOGE_ERR_HIP, "composing the level-0 linear chains failed (%d)", rc);
     HIPCHK(e);
     return 0;
