@@ -115,6 +115,25 @@ def cpu_baseline(O, cfg, sd, x1, kw, config_name, num_tokens):
                       + ", ".join(f"{t}: {calib[t]:.1f} s" for t in cands) + " (also the warm-up)"}
 
 
+def measure_sustained_mfma(seconds: float = 1.5):
+    """What a bare chain of v_mfma_f32_16x16x32_f16 (random operands, no data movement) sustains on THIS box for `seconds` (tools/mfma_power):
+    the chip clocks to its power limit and boxes of the pool differ by 10 % (1.78 ... 1.98 PFLOP/s seen).  -> (TFLOP/s, GHz) or None."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "mfma_power")
+    try:
+        if not os.path.exists(exe):
+            from moge_amd.build import build_mfma_power
+            build_mfma_power(verbose=False)
+        env = dict(os.environ, MFMA_POWER_ONLY="1,0,512", MFMA_POWER_SECONDS=str(seconds))
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
+        m = re.search(r"random data, 16x16x32, 8 waves.*?: ([0-9.]+) TF/s, shader clock ([0-9.]+) MHz", r.stdout)
+        return (float(m.group(1)), float(m.group(2)) / 1e3) if m else None
+    except Exception as e:      # noqa: BLE001 - a missing probe must not cost the bench line
+        print(f"[bench] sustained-MFMA probe unavailable ({e})", file=sys.stderr)
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +147,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pipeline leg and the blob load-time comparison")
     ap.add_argument("--no-profile", action="store_true", help="disable the per-kernel HIP-event profiler")
+    ap.add_argument("--no-autocast-pass", action="store_true", help="skip the extra steps in the reference's other fp16 form (fp32 weights + use_fp16); "
+                                                                     "rocprofv3 passes use it so that the trace holds the headline mode's kernels only")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="run only the cpu_baseline leg (no GPU needed) and print it")
     ap.add_argument("--print-launch", action="store_true", help="print the torch.distributed.run command --gpus N would re-execute as, and exit")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 (nccl = RCCL over xGMI: production; gloo: "
@@ -280,16 +301,18 @@ def main():
         lat = sorted(lat[2:])
         # the reference's OTHER fp16 form, for transparency (never `value`): fp32 weights + use_fp16=True = torch.autocast (v2.py:241), which keeps
         # the residual stream in fp32 (MOGE_FP16) - `value` above is model.half() (scripts/infer.py:83-84), whose stream is fp16 (MOGE_FP16_HALF)
-        model.float()
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(max(3, args.steps // 2)):
-            step()
-        torch.cuda.synchronize(dev)
-        autocast_rate = B * max(3, args.steps // 2) / (time.perf_counter() - t1)
-        model.half()
+        autocast_rate = None
+        if not args.no_autocast_pass:
+            model.float()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(max(3, args.steps // 2)):
+                step()
+            torch.cuda.synchronize(dev)
+            autocast_rate = B * max(3, args.steps // 2) / (time.perf_counter() - t1)
+            model.half()
         res = {
             "metric": f"images/sec (MoGeModel.infer, {args.config} {args.shape} fp16)", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -299,7 +322,7 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world} (independent shards, one-time RCCL weight broadcast)"},
             "p50_latency_ms_batch1": round(lat[len(lat) // 2], 3),
             "fp16_forms": {"value_is": "model.half(): fp16 weights and fp16 residual stream, as the reference's `--fp16` (scripts/infer.py:83-84)",
-                           "autocast_fp32_weights_images_per_s": round(autocast_rate, 3),
+                           "autocast_fp32_weights_images_per_s": round(autocast_rate, 3) if autocast_rate is not None else None,
                            "note": "infer(use_fp16=True) on fp32 weights = torch.autocast in the reference (v2.py:241): residual stream stays fp32; this rank only"},
         }
         if rccl is not None:
@@ -337,8 +360,14 @@ def main():
                     res["roofline"]["mfma_busy_at_that_clock"] = tj.get("mfma_busy_at_that_clock")
             # second ceiling: what a bare chain of the same MFMA instruction sustains on this chip under its power limit (tools/mfma_power,
             # no data movement at all) - `frac` stays against the datasheet peak
+            live = measure_sustained_mfma() if world == 1 else None
             spath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "moge_amd", "mfma_sustained.json")
-            if os.path.exists(spath):
+            if live is not None:
+                res["roofline"]["sustained_peak"] = round(live[0], 1)
+                res["roofline"]["frac_of_sustained"] = round(ach / live[0], 4)
+                res["roofline"]["sustained_source"] = (f"tools/mfma_power on this box right after the run: bare v_mfma_f32_16x16x32_f16 chains, random operands, no data "
+                                                       f"movement, held 1.5 s: {live[0]:.0f} TFLOP/s at {live[1]:.2f} GHz (boxes of the pool: 1.78 ... 1.98 PFLOP/s)")
+            elif os.path.exists(spath):
                 with open(spath) as f:
                     sj = json.load(f)
                 res["roofline"]["sustained_peak"] = sj["tflops"]

@@ -94,6 +94,21 @@ def build_tools(verbose: bool = True, experiments: bool = None) -> str:
     return out
 
 
+def build_mfma_power(verbose: bool = True) -> str:
+    """tools/mfma_power: bare-MFMA sustained-rate probe (bench.py's `roofline.sustained_peak`, measured on the box the bench runs on)."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tools", "mfma_power.cpp")
+    out = os.path.join(root, "tools", "mfma_power")
+    if _stale(out, [src]):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", src, "-o", out]
+        if verbose:
+            print("[moge_amd.build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv))
     if "--tools" in sys.argv:

@@ -48,10 +48,15 @@ int main() {
     for (int i = 0; i < 4096 * 8; i++) h[i] = (_Float16)(((rand() & 0xffff) / 32768.f - 1.f));
     CK(hipMemcpy(in, h, 4096 * 16, hipMemcpyHostToDevice));
     const double secs = getenv("MFMA_POWER_SECONDS") ? atof(getenv("MFMA_POWER_SECONDS")) : 0.0;       // > 0: hold every configuration that long (SMI power sampling)
+    // MFMA_POWER_ONLY="kind,zero,threads" (e.g. "1,0,512": 16x16x32, random operands, 8 waves per workgroup): run that one configuration (bench.py's live
+    // `roofline.sustained_peak`)
+    int only_kind = -1, only_zero = -1, only_wpb = -1;
+    if (const char* o = getenv("MFMA_POWER_ONLY")) sscanf(o, "%d,%d,%d", &only_kind, &only_zero, &only_wpb);
     for (int zero = 0; zero < 2; zero++) {
         if (zero) CK(hipMemset(in, 0, 4096 * 16));
         for (int kind = 0; kind < 2; kind++)
             for (int wpb = 256; wpb <= 512; wpb *= 2) {
+                if (only_kind >= 0 && (kind != only_kind || zero != only_zero || wpb != only_wpb)) continue;
                 const int iters = 4000;
                 hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
                 auto launch = [&]() { if (kind == 0) chain<0><<<256 * 4, wpb>>>(in, out, iters, clk); else chain<1><<<256 * 4, wpb>>>(in, out, iters, clk); };
