@@ -5,7 +5,8 @@
 A "step" is ONE infer() pass of the hot path over one batch of synthetic images that are already resident in HBM.
 Workload (BASELINE.json metric: images/sec, moge-2-vitl 518x518 fp16): configs[2] = moge-2-vitl (no normal head),
 batch 32 per GPU, torch.rand 3x518x518, default num_tokens 3600 (60x60 token grid, N=3601), fp16 weights
-(model.half()), full infer() including focal/shift recovery and masking; outputs stay on the device.
+(model.half(): what the reference's `--fp16` is, scripts/infer.py:83-84 - fp16 residual stream, MOGE_FP16_HALF), full infer() including
+focal/shift recovery and masking; outputs stay on the device.
 For N>1 there is one process per GPU (torch.distributed / RCCL): rank 0 builds the synthetic checkpoint, the fp32 master
 weight blob is broadcast once over xGMI, then every rank runs independent inference on its own shard (weak scaling:
 per-GPU batch fixed; no steady-state collective - SURVEY.md 8(e)).  `python bench.py --gpus N` launches itself: when it is
@@ -17,7 +18,11 @@ form one weak-scaling curve; `--config moge-2-vitl-normal` is BASELINE configs[3
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline        the dominant kernel, gemm_pp128p_kernel (every launch of it and nothing else: profiler class gemm_pp): algorithmic FLOPs /
                   HIP-event time on the launch stream over the same K steps run single-stream right after the timed region; `traffic` =
-                  fabric bytes per launch from the committed rocprofv3 PMC passes (moge_amd/pmc_traffic.json, default workload only)
+                  fabric bytes per launch from the committed rocprofv3 PMC passes (moge_amd/pmc_traffic.json, default workload only; flagged
+                  `traffic_stale` when csrc/gemm_pp.hip has changed since); `frac` against the 2.5 PFLOP/s datasheet peak, `frac_of_sustained`
+                  against what a bare chain of the same MFMA instruction sustains on THIS box right after the run (tools/mfma_power, N=1)
+  fp16_forms      the reference has two fp16 forms: `value` is model.half(); the rate of infer(use_fp16=True) on fp32 weights (= torch.autocast:
+                  fp32 residual stream) is reported beside it, never as `value`
   rccl            N>1: ranks RCCL saw (all-reduce of ones), bytes and seconds of the one-time weight broadcast
   kernel_classes  per-class ms/step, TFLOP/s, GB/s of that profiled pass;  whole_path: end-to-end MFMA fraction
   pcie_inclusive  images/s of the caller-side pipeline (host uint8 in, all maps back to pinned host memory) - N=1 only, never `value`
