@@ -161,8 +161,10 @@ int moge_master_ready(moge_handle* h);
  * The reference has no counterpart - it is a single-process PyTorch module (moge/model/v2.py:76-107 loads one checkpoint per process). */
 int moge_broadcast_weights(moge_handle* h, void* nccl_comm, int root, void* stream);
 
-/* replaces nn.Module.half()/.float() (scripts/infer.py:82-84): select the compute precision.  Packs the
- * kernel-layout weight set for that precision on first use (both sets may stay resident). */
+/* replaces nn.Module.half()/.float() (scripts/infer.py:82-84) and the autocast switch of infer(use_fp16=...) (v2.py:241): select the compute
+ * precision - MOGE_FP32 (.float(), use_fp16=False), MOGE_FP16 (fp32 weights + use_fp16=True: the reference runs torch.autocast, residual stream
+ * fp32) or MOGE_FP16_HALF (.half(): every tensor fp16, the residual stream included).  Packs the kernel-layout weight set of that storage type on
+ * first use (the fp32 and the fp16 set may both stay resident; the two fp16 modes share one). */
 int moge_set_precision(moge_handle* h, int precision, void* stream);
 
 /* replaces the `MoGeModel.onnx_compatible_mode` setter (v2.py:67-74, docs/onnx.md): the forward the reference exports to ONNX - the 14x
