@@ -368,28 +368,16 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
 // (per 64 queries and tile: 212 instructions instead of 256), and gives the scheduler four independent K Q^T -> exp -> P V chains per wave
 // to interleave.  Result and the reason it is / is not the default: DESIGN.md 4.3 (profiles/r03*_kbench_attn*.log).
 // ------------------------------------------------------------------------------------------------------------------------
+// The body for one workgroup: head `bh`, queries from `q_base` (this workgroup covers 64 * QB of them; wave w owns 16 * QB from q_base + 16 * QB * w).
 template <int QB>
-__global__ __launch_bounds__(256, QB > 2 ? 2 : 3) void attn_pp16mq_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
-                                                            f16* __restrict__ out, int Ntok, int nh, int xcd_remap) {
+__device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v, f16* __restrict__ out,
+                                                 int Ntok, int nh, int bh, int q_base, char* smem) {
     constexpr int NW = 4, NPW = 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * AP_STAGE
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g4 = lane >> 4;
-    // XCD-aware order: workgroups are dispatched round-robin over the 8 XCDs in linear block order, so with (x = query block, y = head) the 29
-    // query blocks of a head land on all 8 L2s and every L2 streams every head's K / V.  Remapped so that a head's query blocks run on ONE XCD
-    // (XCD x takes heads x, x + 8, ...): its K / V tiles are fetched into one L2 once.
-    int bh = blockIdx.y, qblk = blockIdx.x;
-    if (((gridDim.y & 7) == 0) && xcd_remap) {
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const int x = lin & 7, s = lin >> 3;
-        const int hs = s / (int)gridDim.x;
-        bh = x + 8 * hs;
-        qblk = s - hs * (int)gridDim.x;
-    }
     const int b = bh / nh, head = bh - b * nh;
-    const int q0 = qblk * (NW * 16 * QB) + wave * (16 * QB);
-
+    const int q0 = q_base + wave * (16 * QB);
     u32x4 qf[QB][2];
 #pragma unroll
     for (int qb = 0; qb < QB; qb++) {
@@ -631,6 +619,31 @@ __global__ __launch_bounds__(256, QB > 2 ? 2 : 3) void attn_pp16mq_kernel(const 
     }
 }
 
+template <int QB>
+__global__ __launch_bounds__(256, QB > 2 ? 2 : 3) void attn_pp16mq_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
+                                                            f16* __restrict__ out, int Ntok, int nh, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * AP_STAGE
+    // XCD-aware order: workgroups are dispatched round-robin over the 8 XCDs in linear block order, so with (x = query block, y = head) the 29
+    // query blocks of a head land on all 8 L2s and every L2 streams every head's K / V.  Remapped so that a head's query blocks run on ONE XCD
+    // (XCD x takes heads x, x + 8, ...): its K / V tiles are fetched into one L2 once.
+    int bh = blockIdx.y, qblk = blockIdx.x;
+    if (((gridDim.y & 7) == 0) && (xcd_remap & 1)) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int x = lin & 7, s = lin >> 3;
+        const int hs = s / (int)gridDim.x;
+        bh = x + 8 * hs;
+        qblk = s - hs * (int)gridDim.x;
+    }
+    const int q_base = qblk * (64 * QB);
+    if constexpr (QB == 4) if (xcd_remap & 2) {                 // (bit 1: ATTN_TAIL2, default on)
+        // The last workgroup of a head with at most 128 queries left (N = 3601: 17 of 256) runs the 32-queries-per-wave body: its one or two
+        // waves that hold real queries then compute 2 query blocks each instead of 4 (two of them clamped copies) - the same arithmetic per
+        // query (the two instantiations are bit-identical), half the work on the workgroup that decides when its slot is free again.
+        if (Ntok - q_base <= 128) { attn_pp16mq_body<2>(q, k, v, out, Ntok, nh, bh, q_base, smem); return; }
+    }
+    attn_pp16mq_body<QB>(q, k, v, out, Ntok, nh, bh, q_base, smem);
+}
+
 // (A software-pipelined variant - K Q^T of tile t issued under the softmax of tile t-1, two S buffers, four-stage ring, 2 waves per SIMD -
 // was written and measured: correct, 860 TF/s against 920 for the kernel above.  With the schedule left to the compiler the exps still
 // cluster (18 in a row between MFMAs) and the second S buffer costs register moves / spills; it needs a hand-placed instruction stream.)
@@ -648,7 +661,7 @@ static int launch_attn_pp16(const void* q, const void* k, const void* v, void* o
         // 64-query form wins (928 workgroups = 1.2 rounds against 480 = 0.94: 745-797 vs 845-879 TF/s; r03zd_kbench_attn_b1.log)
         const long wgs2 = (long)((Ntok + 127) / 128) * B * nh;
         const bool q4 = akern == 2 || (akern == 3 && wgs2 > moge_tune_get("ATTN_Q2_MAX_WGS", 3 * pp_device_cus()));
-        const int xr = moge_tune_get("ATTN_XCD", 1);
+        const int xr = (moge_tune_get("ATTN_XCD", 1) ? 1 : 0) | (moge_tune_get("ATTN_TAIL2", 1) ? 2 : 0);
         if (q4) {
             if (int rc = set_dyn_lds<attn_pp16mq_kernel<4>>(smem)) return rc;
             hipLaunchKernelGGL(attn_pp16mq_kernel<4>, dim3((Ntok + 255) / 256, B * nh), dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr);
