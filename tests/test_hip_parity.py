@@ -165,6 +165,12 @@ def test_bench_batch_of_32_distinct_images_matches_its_single_image_results(MoGe
     try:
         model.half()
         batch = model.infer(x)
+        # race screen: the same batch three more times through the two-stream production path (persistent GEMMs with prefetch across tiles,
+        # counted vmcnt waits, head / tail hand-overs): every run must reproduce the first bit for bit
+        for rep in range(3):
+            again = model.infer(x)
+            for k in batch:
+                _same(again[k], batch[k], f"{k}: run {rep + 2} of the same batch differs from run 1 (a race)")
         for i in (0, 15, 16, 31):
             single = model.infer(x[i])
             for k in single:
