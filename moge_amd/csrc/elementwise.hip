@@ -351,23 +351,33 @@ int launch_ln_raw(const float* x, void* out, float* mr, long rowsN, int D, hipSt
 }
 template int launch_ln_raw<f16>(const float*, void*, float*, long, int, hipStream_t);
 
-__global__ void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ mr, long rowsN, int NP, float invD) {
-    const long row = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (row >= rowsN) return;
-    const f32x4* p = reinterpret_cast<const f32x4*>(part + row * (long)NP * 2);
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ mr, long rowsN, int NP, float invD) {
+    // 8 lanes per row: lane j sums the 16-byte quads (two (s1, s2) pairs) j, j + 8, ... of the row's NP pairs - a row's 8 NP bytes are read as
+    // full 128-byte segments (one thread per row read 64 different lines per instruction: 13 us per launch at batch 32) - then a 1-2-4
+    // butterfly.  One fixed summation order for every batch size (this kernel is the only finaliser), so batch items stay independent of their batch.
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    const long row = gid >> 3;
+    const int j = (int)(gid & 7);
     float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < NP / 2; i++) {              // partials in column order: (s1, s2) pairs, two per 16-byte load
-        const f32x4 t = p[i];
-        s1 += t[0]; s2 += t[1];
-        s1 += t[2]; s2 += t[3];
+    if (row < rowsN) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(part + row * (long)NP * 2);
+        for (int q = j; q < NP / 2; q += 8) {
+            const f32x4 t = p[q];
+            s1 += t[0]; s2 += t[1];
+            s1 += t[2]; s2 += t[3];
+        }
     }
-    const float mean = s1 * invD;
-    const float var = fmaxf(fmaf(-mean, mean, s2 * invD), 0.f);
-    *reinterpret_cast<f32x2*>(mr + 2 * row) = f32x2{mean, rsqrtf(var + 1e-6f)};
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (row < rowsN && j == 0) {
+        const float mean = s1 * invD;
+        const float var = fmaxf(fmaf(-mean, mean, s2 * invD), 0.f);
+        *reinterpret_cast<f32x2*>(mr + 2 * row) = f32x2{mean, rsqrtf(var + 1e-6f)};
+    }
 }
 int launch_ln_finalize(const float* part, float* mr, long rowsN, int NP, int D, hipStream_t st) {
     if (NP & 1) return -1;
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rowsN + 255) / 256)), dim3(256), 0, st, part, mr, rowsN, NP, 1.f / (float)D);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rowsN * 8 + 255) / 256)), dim3(256), 0, st, part, mr, rowsN, NP, 1.f / (float)D);
     return (int)hipGetLastError();
 }
 
