@@ -759,8 +759,11 @@ __device__ __forceinline__ void pp_epi_run(const GemmArgs& g, f32x4 (&acc)[8][4]
 // tile and land while it runs; the epilogue stages through the other 64 KiB of the ring (A slots 1 and 2, 8 KiB per wave, 64-row passes).
 // Tiles: each XCD owns a contiguous range of the (grouped) tile order, its workgroups (blockIdx & 7 = XCD) take consecutive tiles of it,
 // so the A rows / W columns a round works on are shared in that XCD's L2 as in the one-tile-per-workgroup kernel.
-// Queue order of a tile's DMA: A0 W0 W1 | epilogue loads, stores | A1 A2lo | A2hi W2 A3lo ... : the steady-state vmcnt(10) of the ring
-// (leaves A(t+2)lo A(t+2)hi W(t+2) A(t+3)lo) holds from t = 0 on; the tile-head wait is vmcnt(6) (A1 A2lo stay in flight).
+// Queue order of a tile's DMA (MODE 3, the product): A0 W0 W1 | epilogue loads, stores | A1 | A2 W2 | A3 W3 ... : every K-tile's read segments request
+// A(t+2) (4 pieces per wave, first segment) and W(t+2) (4 pieces, second segment); the steady-state wait at the end of the second segment is
+// vmcnt(8) (A(t+2) and W(t+2) stay in flight, everything up to W(t+1) has landed), the tile-head wait vmcnt(4) (A1 stays in flight).
+// (Rounds 2-3 requested A_hi(t+2) | W(t+2) A_lo(t+3) = 2 + 6 pieces: the second read segment - 8 fragment reads, 6 DMA issues, the counted
+//  wait - overran the partner's 32 MFMAs; 4 + 4 is +3.3 ... +4.9 % at K = 1024 and +1.7 ... +2.6 % at K = 4096, profiles/r04n-r04r.)
 // ------------------------------------------------------------------------------------------------------------------------
 // MRG (round 3 experiment, instantiated in --experiments builds only; measured 10-17 % SLOWER, see launch_pp_any): ONE MFMA segment of 64 per
 // K-tile and wave group instead of two of 32 - half the hand-overs between the two wave groups of a SIMD (each costs ~90 clocks of barrier +
@@ -772,6 +775,17 @@ template <int EPK, int SROWS, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
     constexpr bool MRG = MODE == 1;
     constexpr bool WDMA_M = MODE == 2;         // W(t+2) requested at the head of the SECOND MFMA segment of K-tile t instead of in the read segment in front of it
+    // MODE 3 (round 4): BOTH halves of A(t+2) are requested in the FIRST read segment of K-tile t (4 pieces per wave), W(t+2) alone in the second
+    // (4 pieces) - instead of 2 + 6: the second read segment (8 fragment reads + 6 DMA issues) was the one that overran the partner's 32 MFMAs.
+    // Queue per K-tile: [L_a(t): A(t+2)] [L_b(t): W(t+2)], wait at the end of L_b(t): vmcnt(8) = everything up to W(t+1) has landed.
+    constexpr bool ALO_A = MODE == 3 || MODE == 5;
+    // MODE 6: "6 + 2" - as MODE 3, and the second half of W(t+1) is requested at the head of L_a(t) instead of in L_b(t-1):
+    // [L_a(t): W(t+1) rows 128-255, A(t+2)] [L_b(t): W(t+2) rows 0-127]; wait at the end of L_b(t): vmcnt(6)
+    constexpr bool W_SPLIT = MODE == 6;
+    constexpr bool DMA_FIRST = MODE == 5;      // MODE 5 = MODE 3 with the DMA pieces of a read segment issued BEFORE its fragment reads
+    // MODE 4: 3 + 5 - the first read segment carries 16 fragment reads, the second 8, so one more piece goes to the second:
+    // [L_a(t): A_hi(t+2), A_lo(t+2) rows 0-63] [L_b(t): W(t+2), A_lo(t+3) rows 128-191]; wait at the end of L_b(t): vmcnt(9)
+    constexpr bool SPLIT35 = MODE == 4;
     constexpr int WN = 4, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 3 * 32 KiB (A ring) + 2 * 32 KiB (W ring)
 
@@ -834,6 +848,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
         for (int k = 0; k < 2; k++)
             __builtin_amdgcn_global_load_lds(PP_GPTR(ga + offA[hi_rows * 2 + k]), PP_LPTR(base + (k * 128 + hi_rows * 64 + wave * 8) * 128), 16, 0, 0);
     };
+    auto issue_w2 = [&](int t, int part) {                    // half of a W K-tile: part 0 = pieces kw 0, 1 (rows 0-127), part 1 = kw 2, 3 (rows 128-255)
+        char* base = smem + 98304 + (t & 1) * 32768;
+        const char* gw = uniform_ptr(baseW + (size_t)t * 128);
+#pragma unroll
+        for (int kw = 2 * part; kw < 2 * part + 2; kw++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[kw]), PP_LPTR(base + (wave + 8 * kw) * 1024), 16, 0, 0);
+    };
+    auto issue_a1 = [&](int t, int slot, int k) {             // ONE piece of the "lo" rows: k = 0 rows 8w (wave group 0's), k = 1 rows 128 + 8w (group 1's)
+        char* base = smem + slot * 32768;
+        const char* ga = uniform_ptr(baseA + (size_t)t * 128);
+        __builtin_amdgcn_global_load_lds(PP_GPTR(ga + offA[k]), PP_LPTR(base + (k * 128 + wave * 8) * 128), 16, 0, 0);
+    };
     auto prefetch = [&]() {                                   // the pieces that do not touch the staging region (A slots 1, 2)
         // straight-line (K >= 192 is a launch condition): a branch in here makes the compiler wait vmcnt(0) for the epilogue's loads behind it
         issue_a(0, 0, 0); issue_a(0, 0, 1);
@@ -867,9 +892,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
             for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // tile head: the prefetched pieces (A0 W0 W1) are OLDER than the previous epilogue's last PP_TRAIL memory instructions (stores);
         // those may stay in flight
-        constexpr int PP_TRAIL = PpTrail<EPK, SROWS>::N, POST = 6;
+        constexpr int PP_TRAIL = PpTrail<EPK, SROWS>::N, POST = (ALO_A || W_SPLIT) ? 4 : (SPLIT35 ? 5 : 6);
         issue_a(1, 1, 0); issue_a(1, 1, 1);
-        issue_a(2, 2, 0);
+        if constexpr (SPLIT35) issue_a1(2, 2, 1);
+        else if constexpr (!ALO_A && !W_SPLIT) issue_a(2, 2, 0);
         if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(POST) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(POST + PP_TRAIL) : "memory");
         first = false;
@@ -996,6 +1022,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
             const int sa2 = sa == 0 ? 2 : sa - 1;
 #pragma unroll
             for (int half = 0; half < 2; half++) {
+                if constexpr (DMA_FIRST) {
+                    if (t + 2 < nkt) {
+                        if (half == 0) { issue_a(t + 2, sa2, 0); issue_a(t + 2, sa2, 1); }
+                        else issue_w(t + 2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if (half == 0) {
 #pragma unroll
                     for (int j = 0; j < 4; j++)
@@ -1007,9 +1040,30 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int ks = 0; ks < 2; ks++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 64)) + (half * 4 + i) * 2048);
                 if (half == 0) {
-                    if (t + 2 < nkt) issue_a(t + 2, sa2, 1);
+                    if constexpr (W_SPLIT) {
+                        if (t >= 1 && t + 1 < nkt) issue_w2(t + 1, 1);
+                        if (t + 2 < nkt) { issue_a(t + 2, sa2, 0); issue_a(t + 2, sa2, 1); }
+                    } else
+                    if (!DMA_FIRST && t + 2 < nkt) {
+                        if constexpr (ALO_A) issue_a(t + 2, sa2, 0);
+                        issue_a(t + 2, sa2, 1);
+                        if constexpr (SPLIT35) issue_a1(t + 2, sa2, 0);
+                    }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 } else {
+                    if constexpr (W_SPLIT) {
+                        if (t + 2 < nkt) { issue_w2(t + 2, 0); asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); }
+                        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    } else
+                    if constexpr (SPLIT35) {
+                        if (t + 3 < nkt) { issue_w(t + 2); issue_a1(t + 3, sa, 1); asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); }
+                        else if (t + 2 < nkt) { issue_w(t + 2); asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
+                        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    } else
+                    if constexpr (ALO_A) {
+                        if (t + 2 < nkt) { if constexpr (!DMA_FIRST) issue_w(t + 2); asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
+                        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    } else
                     if constexpr (WDMA_M) {
                         // queue (oldest first): A_lo(t+2) | W(t+1) [head of M_b(t-1)] | A_hi(t+2) [L_a(t)] | A_lo(t+3) [here]: W(t+1) must have landed
                         if (t + 3 < nkt) { issue_a(t + 3, sa, 0); asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
@@ -1213,16 +1267,21 @@ static int launch_pp_any(const GemmArgs& g, hipStream_t st) {
 #endif
     int kern = moge_tune_get("PP_KERN", -1);
     if (kern < 0) kern = 2;
-    if (kern == 2 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64>(g, st);
+    // The product's persistent kernel is MODE 3 (round 4): the DMA pieces of a K-tile split 4 + 4 over the wave's two read segments (A(t+2) whole
+    // in the first, W(t+2) in the second).  Same MFMAs in the same order as every other schedule: bit-identical results.
+    if (kern == 2 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64, 3>(g, st);
 #ifdef MOGE_EXPERIMENTS
-    // merged MFMA segments (see the kernel): bit-identical, 10-17 % SLOWER on every hot-path shape (profiles/r03r_kbench_gemm_merged_segments.log:
-    // fc2 1117 -> 941, fc1 1023 -> 916, out-proj 1243 -> 1025 TF/s) - tools/kbench A-B builds only
+    // the other DMA schedules and loop shapes that were measured (tools/kbench A-B builds only; profiles/r04n ... r04r, r03r, r03u):
+    //   5: MODE 0, rounds 2-3's 2 + 6 schedule (A_hi(t+2) | W(t+2), A_lo(t+3)): 3-5 % slower at K = 1024, 2-3 % at K = 4096
+    //   6: MODE 4, 3 + 5: between the two        7: MODE 5, 4 + 4 with the DMA issued before the fragment reads: 0-1.3 % slower
+    //   8: MODE 6, 6 + 2 (half of W(t+1) requested a read segment later): equal at K = 1024, slower than MODE 0 at K = 4096
+    //   3: MODE 1, merged 64-MFMA segments: 10-17 % slower        4: MODE 2, W(t+2) requested inside the MFMA segment: 0.5-3 % slower
+    if (kern == 5 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64, 0>(g, st);
+    if (kern == 6 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64, 4>(g, st);
+    if (kern == 7 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64, 5>(g, st);
+    if (kern == 8 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64, 6>(g, st);
     if (kern == 3 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64, 1>(g, st);
-    // W(t+2) requested at the head of the second MFMA segment instead of in the read segment (LDS-DMA issue is cheaper among MFMAs, cdna guide
-    // constants): bit-identical, 0.5-3 % slower (profiles/r03u_kbench_gemm_wdma_in_mfma_segment.log: out-proj 1270 -> 1217, fc1 1043 -> 1028 TF/s)
     if (kern == 4 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64, 2>(g, st);
-#endif
-#ifdef MOGE_EXPERIMENTS
     if (kern == 1) return launch_pp4w16<EPK>(g, st);
 #endif
     return launch_pp128m16<EPK>(g, st);
