@@ -55,6 +55,19 @@ __device__ __forceinline__ void mma16<f16>(f32x4& acc, const u32x4& a, const u32
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 
+// cross-lane moves on the VALU (DPP): lane ^ 1 and lane ^ 2 inside a quad, lane -> 7 - lane inside 8 lanes (all lanes active)
+__device__ __forceinline__ float dpp_quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_half_mirror(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)); }
+
+// the first MFMA of an accumulation chain: C = the inline constant 0 (no zero fill of the accumulator registers)
+template <typename T>
+__device__ __forceinline__ f32x4 mma16_first(const u32x4& a, const u32x4& b);
+template <>
+__device__ __forceinline__ f32x4 mma16_first<f16>(const u32x4& a, const u32x4& b) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+}
+
 // row of the 32x32 accumulator tile held in register r by a lane of half `hi`
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

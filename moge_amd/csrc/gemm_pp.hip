@@ -22,6 +22,7 @@
 //     wave's 128x64 (or 64x64) sub-tile through its private LDS region and writes / read-modify-writes global memory
 //     in full 128-byte row segments (row-per-lane stores cost one cache-line lookup per lane on this chip).
 #include "common.h"
+#include <type_traits>
 
 #define PP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define PP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -94,12 +95,14 @@ __device__ __forceinline__ void pp_resid_store(const ResidBufs& rb, bool fold, i
             const u32x2 mine = __builtin_bit_cast(u32x2, h4);
             u32x4 pk;
             pk[0] = mine[0]; pk[1] = mine[1];
-            pk[2] = (unsigned)__shfl_xor((int)mine[0], 1); pk[3] = (unsigned)__shfl_xor((int)mine[1], 1);
+            pk[2] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine[0], 0xB1, 0xF, 0xF, true);          // lane ^ 1's halves (DPP quad_perm [1,0,3,2])
+            pk[3] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine[1], 0xB1, 0xF, 0xF, true);
             __builtin_amdgcn_raw_buffer_store_b128(pk, rb.x16, (int)((cc & 1) ? h0 : h0 + (unsigned)it * 8u * rb.ldc2), 0, 0);
             float s1, s2;
             ln_quad_sums(xnew, s1, s2);
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            s1 += dpp_quad_xor1(s1); s2 += dpp_quad_xor1(s2);      // __shfl_xor(., 1 / 2 / 4) on the VALU: the quads are uniform before the last step,
+            s1 += dpp_quad_xor2(s1); s2 += dpp_quad_xor2(s2);      // where lane i takes lane 7 - i's value (the other quad's sum)
+            s1 += dpp_half_mirror(s1); s2 += dpp_half_mirror(s2);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{s1, s2}), rb.part, (int)(cc ? p0 : p0 + (unsigned)it * 8u * rb.npart8), 0, 0);
         }
     }
@@ -164,8 +167,8 @@ __device__ __forceinline__ void pp_resid16_store(const Resid16Bufs& rb, bool fol
             ln_quad_sums(a, a1, a2);
             ln_quad_sums(b, b1, b2);
             float s1 = a1 + b1, s2 = a2 + b2;
-#pragma unroll
-            for (int o = 1; o < 4; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            s1 += dpp_quad_xor1(s1); s2 += dpp_quad_xor1(s2);      // (what __shfl_xor(., 1 / 2) computes, on the VALU instead of ds_bpermute + wait)
+            s1 += dpp_quad_xor2(s1); s2 += dpp_quad_xor2(s2);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{s1, s2}), rb.part, (int)((cc & 3) ? p0 : p0 + (unsigned)it * 8u * rb.npart8), 0, 0);
         }
     }
@@ -237,22 +240,32 @@ __device__ __forceinline__ void pp_store_rows(const GemmArgs& g, const char* R, 
 }
 
 // the per-quad arithmetic shared by both accumulator layouts: 4 consecutive columns n .. n+3 of one output row
+// Written on PAIRS of columns: v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32 and one v_cvt_pk_f16_f32 per pair (the scalar form compiled to one VALU
+// instruction per element and, in the plain-store flavour, to v_cvt_f16_f32 x 2 + v_pack + v_alignbit per pair: the epilogue runs with the matrix pipe
+// idle, 2 waves per SIMD, 4 clocks per instruction).  Per element the operations and their order are those of gemm.hip's scalar epilogues
+// (bit-identical: packed fp32 instructions round like their scalar forms).
 template <int EPK, bool FOLD = false>
 __device__ __forceinline__ f16x4 pp_quad_f16(const f32x4& a, const f32x4& b, float scale, const f32x4& wu, float u, const f32x4& wv, float vv,
                                              float mean = 0.f, float rstd = 1.f, const f32x4& lc = f32x4{0.f, 0.f, 0.f, 0.f}) {
-    float v[4];
+    f32x2 v[2];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        v[e] = FOLD ? ln_fold_term(a[e], mean, rstd, lc[e], b[e]) : a[e] + b[e];
-        if constexpr (EPK == EPK_QKV) v[e] = q_scaled(v[e], scale);
-        if constexpr (EPK == EPK_UV) v[e] = uv_term_add(v[e], wu[e], u, wv[e], vv);
-        if constexpr (EPK == EPK_RELU) v[e] = fmaxf(v[e], 0.f);
+    for (int h = 0; h < 2; h++) {
+        const f32x2 ah = {a[2 * h], a[2 * h + 1]}, bh = {b[2 * h], b[2 * h + 1]};
+        if constexpr (FOLD) {
+            const f32x2 ch = {lc[2 * h], lc[2 * h + 1]};
+            v[h] = __builtin_elementwise_fma(f32x2{rstd, rstd}, __builtin_elementwise_fma(f32x2{-mean, -mean}, ch, ah), bh);      // ln_fold_term
+        } else {
+            v[h] = ah + bh;
+        }
+        if constexpr (EPK == EPK_QKV) { v[h] = v[h] * f32x2{scale, scale}; asm volatile("" : "+v"(v[h])); }                        // q_scaled
+        if constexpr (EPK == EPK_UV)
+            v[h] = __builtin_elementwise_fma(f32x2{wu[2 * h], wu[2 * h + 1]}, f32x2{u, u},
+                                             __builtin_elementwise_fma(f32x2{wv[2 * h], wv[2 * h + 1]}, f32x2{vv, vv}, v[h]));    // uv_term_add
+        if constexpr (EPK == EPK_RELU) v[h] = f32x2{fmaxf(v[h][0], 0.f), fmaxf(v[h][1], 0.f)};
+        if constexpr (EPK == EPK_GELU) v[h] = gelu_fast2(v[h]);
     }
-    if constexpr (EPK == EPK_GELU) {
-        const f32x2 g0 = gelu_fast2(f32x2{v[0], v[1]}), g1 = gelu_fast2(f32x2{v[2], v[3]});
-        v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
-    }
-    return f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    const f16x2 h0 = __builtin_convertvector(v[0], f16x2), h1 = __builtin_convertvector(v[1], f16x2);
+    return __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
 }
 
 #ifdef MOGE_EXPERIMENTS
@@ -539,7 +552,9 @@ template <int EPKX, int SROWS> struct PpEpiPre {
     float mu[8], rs[8], u[8], vv[8];
     f32x4 x0[SROWS / 8];
     ResidBufs rb;
-    u32x4 h0[SROWS / 16];               // EPK_RESID16: first pass of SROWS / 2 rows x 64 columns
+    u32x4 h[256 / SROWS][SROWS / 16];   // EPK_RESID16: the wave's residual tile (128 rows x 64 fp16 columns = 64 registers), requested in two halves - passes 0, 1 in
+                                        // pp_epi_pre (into the registers the A / W fragments have left), passes 2, 3 once the LayerScale / bias vectors are dead -
+                                        // instead of one pass ahead: the load latency is exposed once per tile, not once per pass
     Resid16Bufs rb16;
     __amdgpu_buffer_rsrc_t ob;
     float scale;
@@ -556,7 +571,8 @@ __device__ __forceinline__ void pp_epi_pre(const GemmArgs& g, PpEpiPre<EPKX, SRO
     if constexpr (EPK == EPK_RESID16) {
         P.rb16 = pp_resid16_bufs(g);
         P.fold = g.ln_part != nullptr;
-        pp_resid16_load<SROWS / 2>(P.rb16, lane, mw, nw, P.h0);
+#pragma unroll
+        for (int p = 0; p < 1; p++) pp_resid16_load<SROWS / 2>(P.rb16, lane, mw + p * (SROWS / 2), nw, P.h[p]);
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
             const int n = nw + jj * 16 + 4 * g4;
@@ -692,21 +708,22 @@ __device__ __forceinline__ void pp_epi_run(const GemmArgs& g, f32x4 (&acc)[8][4]
     if constexpr (EPK == EPK_RESID16) {
         // 128 / PROWS passes of PROWS = SROWS / 2 rows x all 64 columns (256-byte staging rows fill the wave's SROWS x 128 B region)
         constexpr int PROWS = SROWS / 2, NPASS = 128 / PROWS;
-        u32x4 h1[PROWS / 8];
 #pragma unroll
         for (int jj = 0; jj < 4; jj++)
 #pragma unroll
             for (int i = 0; i < 8; i++)
 #pragma unroll
                 for (int e = 0; e < 4; e++) acc[i][jj][e] = resid_term(P.lq[jj][e], acc[i][jj][e], P.bq[jj][e]);
+        __builtin_amdgcn_sched_barrier(0);                     // (not above the loop: with lq / bq still live the second half does not fit 256 registers)
+#pragma unroll
+        for (int p = 1; p < NPASS; p++) pp_resid16_load<PROWS>(P.rb16, lane, mw + p * PROWS, nw, P.h[p]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < NPASS; p++) {
-            u32x4 (&xc)[PROWS / 8] = (p & 1) ? h1 : P.h0;
-            u32x4 (&xn)[PROWS / 8] = (p & 1) ? P.h0 : h1;
+            u32x4 (&xc)[PROWS / 8] = P.h[p];
             pp_resid16_stage<PROWS, 4>(R, acc, 0, p * (PROWS / 16), lane);
             pp_resid16_add<PROWS>(R, lane, xc);
-            if (p + 1 < NPASS) pp_resid16_load<PROWS>(P.rb16, lane, mw + (p + 1) * PROWS, nw, xn);
-            else mid();
+            if (p + 1 == NPASS) mid();
             pp_resid16_store<PROWS>(P.rb16, true, lane, mw + p * PROWS, nw, xc);       // (statistics stores always issued: see PpTrail)
         }
     } else if constexpr (EPK == EPK_RESID) {
@@ -885,11 +902,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
     for (;;) {
         const int m0 = m0n, n0 = n0n;
         PP_STAMP(0);
+        // (no zero fill in the product form: the first K-tile is peeled and its first 64 MFMAs take the constant 0 as their C operand - 128 v_mov per
+        //  wave and tile less, with the matrix pipe idle while they would run)
         f32x4 acc[8][4];
+        if constexpr (MRG) {
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+            for (int i = 0; i < 8; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         // tile head: the prefetched pieces (A0 W0 W1) are OLDER than the previous epilogue's last PP_TRAIL memory instructions (stores);
         // those may stay in flight
         constexpr int PP_TRAIL = PpTrail<EPK, SROWS>::N, POST = (ALO_A || W_SPLIT) ? 4 : (SPLIT35 ? 5 : 6);
@@ -1015,8 +1036,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
                 }
                 mfma64(sa == 0 ? 2 : sa - 1, true);            // the last K-tile (group 0 is in its epilogue)
             }
-        } else
-        for (int t = 0; t < nkt; t++) {
+        } else {
+        auto ktile = [&](int t, auto first_tile) {
+            constexpr bool FIRST = decltype(first_tile)::value;
             const char* sl = smem + sa * 32768;
             const char* slw = smem + 98304 + (t & 1) * 32768;
             const int sa2 = sa == 0 ? 2 : sa - 1;
@@ -1094,7 +1116,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
 #pragma unroll
-                        for (int j = 0; j < 4; j++) mma16<f16>(acc[half * 4 + i][j], wf[j][ks], af[i][ks]);
+                        for (int j = 0; j < 4; j++) {
+                            if (FIRST && ks == 0) acc[half * 4 + i][j] = mma16_first<f16>(wf[j][ks], af[i][ks]);
+                            else mma16<f16>(acc[half * 4 + i][j], wf[j][ks], af[i][ks]);
+                        }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("" ::: "memory");
@@ -1103,6 +1128,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             sa = sa == 2 ? 0 : sa + 1;
+        };
+        ktile(0, std::true_type{});
+        for (int t = 1; t < nkt; t++) ktile(t, std::false_type{});
         }
         // every LDS read of the ring is complete (the other group's last load segment ended before the barrier this wave has passed)
         PP_STAMP(2);

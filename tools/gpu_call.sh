@@ -13,6 +13,10 @@ for what in "$@"; do
     kb_resid)   KB_PP=1 KB_ROUNDS=3 timeout 400 ./tools/kbench gemm proj 10 > $out/${tag}_kbench_resid.log 2>&1; KB_PP=1 KB_ROUNDS=3 timeout 400 ./tools/kbench gemm fc2 10 >> $out/${tag}_kbench_resid.log 2>&1; grep -v "^ " $out/${tag}_kbench_resid.log | grep -v "vit\|b1\.\|b4\." | head -60 ;;
     tests_half) timeout 900 python -m pytest tests/test_hip_gemm_pp.py tests/test_hip_parity.py tests/test_hip_v1.py tests/test_hip_kernels.py -m gpu -q -p no:cacheprovider -s -x > $out/${tag}_pytest_half.log 2>&1; grep "passed\|failed\|error" $out/${tag}_pytest_half.log | tail -5; grep "^FAILED\|^ERROR\|Error\|assert" $out/${tag}_pytest_half.log | head -20 ;;
     tests_gemm) timeout 900 python -m pytest tests/test_hip_gemm_pp.py -m gpu -q -p no:cacheprovider > $out/${tag}_pytest_gemm.log 2>&1; tail -3 $out/${tag}_pytest_gemm.log ;;
+    kb_ab)      # two library builds on one box, alternating: tools/_ab/old = the previous commit's build (same tree layout), ./ = this tree
+                for r in 1 2; do for f in ${KB_AB_SHAPES:-qkv proj.h16 fc1 fc2.h16 outproj proj+fold}; do
+                  for w in tools/_ab/old .; do echo "== $w round $r"; (cd $w && KB_P=1 KB_ROUNDS=2 timeout 120 ./tools/kbench gemm $f 10) | grep "interleaved\|bad [1-9]" | grep -v "b1\.\|b4\.\|vit"; done
+                done; done > $out/${tag}_kbench_gemm_ab.log 2>&1; cat $out/${tag}_kbench_gemm_ab.log ;;
     kb_m3)      for f in qkv proj fc1 fc2 outproj; do KB_M3=1 KB_ROUNDS=3 timeout 300 ./tools/kbench gemm $f 10; done > $out/${tag}_kbench_gemm_m3.log 2>&1; grep -v "^   ts" $out/${tag}_kbench_gemm_m3.log | grep -v "b1\.\|b4\.\|vit" ;;
     tests_model) timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_v1.py tests/test_hip_multiproc.py -m gpu -q -p no:cacheprovider -s > $out/${tag}_pytest_model.log 2>&1; grep "passed\|failed\|error" $out/${tag}_pytest_model.log | tail -5; grep "^FAILED\|^ERROR\|Error\|assert" $out/${tag}_pytest_model.log | head -20 ;;
     tests)      timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $out/${tag}_pytest.log 2>&1; tail -25 $out/${tag}_pytest.log ;;

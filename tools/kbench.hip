@@ -186,6 +186,7 @@ static int bench_gemm(const char* filter, int iters) {
                                       {"128x128 ns2", 0, 2, 0, 0, 0, 2, 0}, {"128x128 ns3", 0, 4, 0, 0, 0, 2, 0}, {"128x128 ns4", 0, 5, 0, 0, 0, 2, 0}, {"pp128p", 1, 2, 0, 2, 0}};
     if (getenv("KB_PP")) variants = {{"pp128-m16", 1, 2, 0, 0, 0}, {"pp128p", 1, 2, 0, 2, 0}};
     if (getenv("KB_M3")) variants = {{"pp128p 4+4", 1, 2, 0, 2, 0}, {"x:2+6", 1, 2, 0, 5, 0}, {"x:3+5", 1, 2, 0, 6, 0}, {"x:dma1st", 1, 2, 0, 7, 0}, {"x:6+2", 1, 2, 0, 8, 0}};      // DMA schedules of the persistent GEMM (--experiments builds)
+    if (getenv("KB_P")) variants = {{"pp128p", 1, 2, 0, 2, 0}};      // the product kernel alone (A-B of two library builds: tools/gpu_call.sh kb_ab)
     if (getenv("KB_PPX")) variants = {{"pp128p", 1, 2, 0, 2, 0}, {"x:pp128p-mrg", 1, 2, 0, 3, 0}, {"x:pp128p-wm", 1, 2, 0, 4, 0}};      // --experiments builds
     int fails = 0;
     for (const Shape& s : shapes) {
