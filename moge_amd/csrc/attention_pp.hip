@@ -580,14 +580,29 @@ __device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, cons
             if (__builtin_expect(__any(trig), 0)) { hit = true; break; }
 #pragma unroll
             for (int qb = 0; qb < QB; qb++) l_run[qb] += lt[qb][0];
+            {
+                // V^T operand reads AHEAD groups in front of the MFMAs that use them (group = one 16-row block of d x one 32-key step: 2 transposed
+                // reads, QB MFMAs; QB = 4: 20 registers in flight - what the compiler's own order held - 256 VGPRs and one spill outside the loop;
+                // QB = 2: 161 as before).  Left alone the compiler reads a group, waits lgkmcnt(0), issues its QB MFMAs, four times over (it never
+                // counts lgkmcnt here): LDS latency in front of every fourth MFMA.  Same MFMAs in the same order (bit-identical).  kbench, old / new
+                // library alternating on one box, 30-100 launches per sample (profiles/r04z*_kbench_attn_ab.log): batch 32 1.590 -> 1.556-1.568 ms
+                // and 1.602-1.626 -> 1.561-1.584, batch 16 0.806 -> 0.794, QB = 2 at one / two images 0.067 -> 0.066 / 0.125 -> 0.122.
+                // (Tried with it, r04x / r04y: s_setprio 1 around the P V or the K Q^T segment, everywhere but the P V segment, or static by
+                //  workgroup - +2 % in 10-launch samples at boost clock, nothing at the clock the chip holds under sustained load.)
+                constexpr int AHEAD = QB == 4 ? 5 : 4;
+                u32x4 vf[8];
+                auto ld = [&](int gi) { vf[gi] = tr_pair(va[gi & 3] + (32 * (gi >> 2)) * 128, va[gi & 3] + (32 * (gi >> 2) + 4) * 128); };
 #pragma unroll
-            for (int s2 = 0; s2 < 2; s2++)
+                for (int gi = 0; gi < AHEAD; gi++) ld(gi);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int db = 0; db < 4; db++) {
-                    const u32x4 vf = tr_pair(va[db] + (32 * s2) * 128, va[db] + (32 * s2 + 4) * 128);
+                for (int gi = 0; gi < 8; gi++) {
+                    if (gi + AHEAD < 8) ld(gi + AHEAD);
 #pragma unroll
-                    for (int qb = 0; qb < QB; qb++) mma16<f16>(o[db][qb], vf, pf[qb][s2]);
+                    for (int qb = 0; qb < QB; qb++) mma16<f16>(o[gi & 3][qb], vf[gi], pf[qb][gi >> 2]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            }
         }
         if (!hit) break;
         // The decision is per 16-QUERY BLOCK, not per wave: a block whose own row sums stayed below the limit takes exactly the fast path's
