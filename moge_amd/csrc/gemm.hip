@@ -473,24 +473,37 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
         const char* cA = sA + buf * BM * 128;
         const char* cW = sW + buf * BN * 128;
         if constexpr (M16) {
+            // NSTAGE >= 3 (the counted-wait ring; the latency-regime dispatch): the fragments of BOTH K-steps are requested before the first MFMA.
+            // The compiler waits lgkmcnt(0) in front of each K-step's MFMAs whatever is in flight (it does not count LDS reads in these kernels),
+            // so read / wait / MFMAs twice per slab exposed the LDS latency twice.  Same MFMAs in the same order (bit-identical).  Old / new
+            // library alternating on one box (profiles/r04zd_kbench_gemm_lat_ab.log): fc2 of one image 628 -> 675 TF/s, proj 409 -> 426,
+            // ViT-B fc2 490 -> 517.  The one- and two-stage forms (__syncthreads() per slab) measured 3-12 % SLOWER that way and keep the
+            // per-K-step order.
+            constexpr int NKS = NSTAGE >= 3 ? 2 : 1;              // K-steps per request group
+            u32x4 af[NKS][2 * TM], wf[NKS][2 * TN];
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const int cs = 4 * ks + g4;
-                u32x4 af[2 * TM], wf[2 * TN];
+            for (int k0 = 0; k0 < 2; k0 += NKS) {
 #pragma unroll
-                for (int i = 0; i < 2 * TM; i++) {
-                    const int row = (wm * 2 * TM + i) * 16 + l15;
-                    af[i] = *reinterpret_cast<const u32x4*>(cA + row * 128 + (swz<8>(row, cs) << 4));
+                for (int kk = 0; kk < NKS; kk++) {
+                    const int cs = 4 * (k0 + kk) + g4;
+#pragma unroll
+                    for (int i = 0; i < 2 * TM; i++) {
+                        const int row = (wm * 2 * TM + i) * 16 + l15;
+                        af[kk][i] = *reinterpret_cast<const u32x4*>(cA + row * 128 + (swz<8>(row, cs) << 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2 * TN; j++) {
+                        const int row = (wn * 2 * TN + j) * 16 + l15;
+                        wf[kk][j] = *reinterpret_cast<const u32x4*>(cW + row * 128 + (swz<8>(row, cs) << 4));
+                    }
                 }
+                if constexpr (NKS == 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 2 * TN; j++) {
-                    const int row = (wn * 2 * TN + j) * 16 + l15;
-                    wf[j] = *reinterpret_cast<const u32x4*>(cW + row * 128 + (swz<8>(row, cs) << 4));
-                }
+                for (int kk = 0; kk < NKS; kk++)
 #pragma unroll
-                for (int i = 0; i < 2 * TM; i++)
+                    for (int i = 0; i < 2 * TM; i++)
 #pragma unroll
-                    for (int j = 0; j < 2 * TN; j++) mma16<f16>(acc16[i][j], wf[j], af[i]);
+                        for (int j = 0; j < 2 * TN; j++) mma16<f16>(acc16[i][j], wf[kk][j], af[kk][i]);
             }
             return;
         }

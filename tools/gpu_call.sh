@@ -19,6 +19,8 @@ for what in "$@"; do
                 done; done > $out/${tag}_kbench_gemm_ab.log 2>&1; cat $out/${tag}_kbench_gemm_ab.log ;;
     kb_ab_attn) # attention A/B over library builds on one box, alternating: tools/_ab/old (the previous build, same tree layout) and ./
                 for r in 1 2; do for w in ${KB_AB_DIRS:-tools/_ab/old .}; do echo "== $w round $r"; (cd $w && timeout 120 ./tools/kbench attn "${KB_ATTN_CASE:-vitl b}" ${KB_ITERS:-30}) | grep -v "pp16 "; done; done > $out/${tag}_kbench_attn_ab.log 2>&1; cat $out/${tag}_kbench_attn_ab.log ;;
+    kb_ab_lat)  # latency-regime GEMMs, old / new library alternating on one box
+                for r in 1 2; do for f in ${KB_AB_SHAPES:-b1.proj b1.fc2 vitb1.}; do for w in ${KB_AB_DIRS:-tools/_ab/old .}; do echo "== $w round $r"; (cd $w && KB_LAT=1 KB_ROUNDS=2 timeout 120 ./tools/kbench gemm $f 20) | grep "interleaved\|bad [1-9]"; done; done; done > $out/${tag}_kbench_gemm_lat_ab.log 2>&1; cat $out/${tag}_kbench_gemm_lat_ab.log ;;
     kb_m3)      for f in qkv proj fc1 fc2 outproj; do KB_M3=1 KB_ROUNDS=3 timeout 300 ./tools/kbench gemm $f 10; done > $out/${tag}_kbench_gemm_m3.log 2>&1; grep -v "^   ts" $out/${tag}_kbench_gemm_m3.log | grep -v "b1\.\|b4\.\|vit" ;;
     tests_model) timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_v1.py tests/test_hip_multiproc.py -m gpu -q -p no:cacheprovider -s > $out/${tag}_pytest_model.log 2>&1; grep "passed\|failed\|error" $out/${tag}_pytest_model.log | tail -5; grep "^FAILED\|^ERROR\|Error\|assert" $out/${tag}_pytest_model.log | head -20 ;;
     tests)      timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $out/${tag}_pytest.log 2>&1; tail -25 $out/${tag}_pytest.log ;;
