@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
         for (int j = 0; j < 2 * TN; j++) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int l15 = lane & 15, g4 = lane >> 4;
 
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, auto&& mid) {             // mid(): issued between the fragment reads and the MFMAs (the ring form's DMA requests)
         const char* cA = sA + buf * BM * 128;
         const char* cW = sW + buf * BN * 128;
         if constexpr (M16) {
@@ -497,7 +497,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
                         wf[kk][j] = *reinterpret_cast<const u32x4*>(cW + row * 128 + (swz<8>(row, cs) << 4));
                     }
                 }
-                if constexpr (NKS == 2) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NKS == 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    mid();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int kk = 0; kk < NKS; kk++)
 #pragma unroll
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
         for (int kt = 0; kt < nkt; kt++) {
             issue(kt, 0);
             __syncthreads();
-            compute(0);
+            compute(0, [] {});
             __syncthreads();
         }
     } else if constexpr (NSTAGE == 2) {
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
         for (int kt = 0; kt < nkt; kt++) {
             const int buf = kt & 1;
             if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
-            compute(buf);
+            compute(buf, [] {});
             __syncthreads();          // drains the DMA (vmcnt(0)) and orders it against the next slab's reads
         }
     } else {
@@ -562,8 +566,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();        // slab kt landed for every wave; every wave is done reading slab kt-1
-            if (kt + AHEAD < nkt) issue(kt + AHEAD, nxt);
-            compute(cur);
+            // the slab's DMA requests go BEHIND its fragment reads (fp16 form): a piece costs tens of issue clocks, and in front of the reads that
+            // time sat between the barrier and the first MFMA of every slab
+            if constexpr (M16) {
+                compute(cur, [&] { if (kt + AHEAD < nkt) issue(kt + AHEAD, nxt); });
+            } else {
+                if (kt + AHEAD < nkt) issue(kt + AHEAD, nxt);
+                compute(cur, [] {});
+            }
             cur = cur == NSTAGE - 1 ? 0 : cur + 1;
             nxt = nxt == NSTAGE - 1 ? 0 : nxt + 1;
         }
