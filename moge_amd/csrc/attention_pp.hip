@@ -443,12 +443,12 @@ __device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, cons
     const char* va[4];
     f32x4 sc[4][QB];
     float psum[QB];
-    auto tile_head = [&](int t) {
+    auto tile_head = [&](int t, bool with_issue = true) {
         if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 2 < ntiles) issue(t + 2);
+        if (with_issue && t + 2 < ntiles) issue(t + 2);
         const int so = stage * AP_STAGE;
         stage = stage == 2 ? 0 : stage + 1;
 #pragma unroll
@@ -554,7 +554,7 @@ __device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, cons
     for (;;) {
         bool hit = false;
         for (; t < ntiles - 1; t++) {                // ---- hot loop ----
-            tile_head(t);
+            tile_head(t, false);
             u32x4 kf[4][2];
 #pragma unroll
             for (int kb = 0; kb < 4; kb++) {
@@ -562,6 +562,10 @@ __device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, cons
                 kf[kb][0] = *reinterpret_cast<const u32x4*>(ka[0] + koff);
                 kf[kb][1] = *reinterpret_cast<const u32x4*>(ka[1] + koff);
             }
+            // tile t + 2's DMA requests BEHIND the K fragment reads: in front of them the four pieces' issue time sat between the barrier and the first MFMA
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < ntiles) issue(t + 2);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int qb = 0; qb < QB; qb++) qk_block(qb, kf);
 #pragma unroll
