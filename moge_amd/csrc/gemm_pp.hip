@@ -552,9 +552,9 @@ template <int EPKX, int SROWS> struct PpEpiPre {
     float mu[8], rs[8], u[8], vv[8];
     f32x4 x0[SROWS / 8];
     ResidBufs rb;
-    u32x4 h[256 / SROWS][SROWS / 16];   // EPK_RESID16: the wave's residual tile (128 rows x 64 fp16 columns = 64 registers), requested in two halves - passes 0, 1 in
-                                        // pp_epi_pre (into the registers the A / W fragments have left), passes 2, 3 once the LayerScale / bias vectors are dead -
-                                        // instead of one pass ahead: the load latency is exposed once per tile, not once per pass
+    u32x4 h[256 / SROWS][SROWS / 16];   // EPK_RESID16: the wave's residual tile (128 rows x 64 fp16 columns = 64 registers), requested in two steps - pass 0 in
+                                        // pp_epi_pre (into registers the A / W fragments have left), passes 1 ... 3 together once the LayerScale / bias vectors are
+                                        // dead (pp_epi_run) - instead of one pass ahead: the load latency is exposed once per tile, not once per pass
     Resid16Bufs rb16;
     __amdgpu_buffer_rsrc_t ob;
     float scale;
