@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call of round 3: tools/gpu_call.sh <tag> <what...>   (what: tests kb_rb kb_conv kb_gemm kb_attn bench ab_conv ...)
+# One gpurun call: tools/gpu_call.sh <tag> <what...>   (what: tests kb_rb kb_conv kb_gemm kb_attn bench ab_conv ...)
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
