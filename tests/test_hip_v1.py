@@ -113,3 +113,25 @@ def test_panorama_view_batching_matches_per_view_infer(tmp_path_factory):
         x = torch.tensor(views[i] / 255, dtype=torch.float32).permute(2, 0, 1)
         one = model.infer(x, fov_x=float(intrinsics_to_fov_x_deg(Ks[i])[0]), apply_mask=False, num_tokens=64)
         assert np.array_equal(one["points"].norm(dim=-1).cpu().numpy(), dist[i]) and np.array_equal(one["mask"].cpu().numpy(), masks[i])
+
+
+def test_panorama_pipeline_runs_end_to_end_on_the_gpu(tmp_path_factory):
+    """scripts/infer_panorama.py:86-121 through moge_amd.panorama.infer_panorama with the real (tiny, synthetic) v1 model on the GPU: 12 views
+    in batches of 5, merge, resize.  The synthetic weights make the geometry meaningless; what is checked is the plumbing - the per-view maps
+    are what infer() returns for those views, and the merged map is finite, positive and at the panorama's size (the merge itself is pinned
+    against an analytic scene in tests/test_panorama_cpu.py)."""
+    import numpy as np
+    from moge_amd import panorama as P
+    model = get_model(CASE_BY_NAME["v1_tiny_b2"], tmp_path_factory)
+    H, W = 96, 192
+    d = P.spherical_uv_to_directions(P._uv_grid(H, W))
+    pano = np.clip((d * 0.5 + 0.5) * 255, 0, 255).astype(np.uint8)
+    out = P.infer_panorama(model, pano, resolution=64, batch_size=5, merge_size=(128, 64), num_tokens=64)
+    assert out["distance"].shape == (H, W) and out["distance"].dtype == np.float32 and out["points"].shape == (H, W, 3)
+    assert out["mask"].shape == (H, W) and out["mask"].dtype == bool
+    assert np.isfinite(out["distance"]).all() and (out["distance"] > 0).all()
+    assert len(out["views"]) == len(out["view_distance"]) == len(out["view_mask"]) == 12
+    E, Ks = P.get_panorama_cameras()
+    x = torch.tensor(out["views"][7] / 255, dtype=torch.float32).permute(2, 0, 1)
+    one = model.infer(x, fov_x=90.0, apply_mask=False, num_tokens=64)
+    assert np.array_equal(one["points"].norm(dim=-1).cpu().numpy(), out["view_distance"][7])
