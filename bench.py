@@ -229,7 +229,13 @@ def main():
                 "weight_broadcast_seconds": round(tb, 4)}
         if args.single_device:
             rccl["single_device"] = True
-    model.half()
+    torch.cuda.synchronize(dev)
+    tp = time.perf_counter()
+    model.half()                                         # per-rank repack of the fp32 master into the fp16 kernel layouts, on the device
+    torch.cuda.synchronize(dev)
+    pack_s = time.perf_counter() - tp
+    if rccl is not None:
+        rccl["pack_seconds_this_rank"] = round(pack_s, 4)
 
     B = args.batch
     default_workload = (args.batch == BATCH_PER_GPU and args.config == WORKLOAD_CONFIG and args.num_tokens is None and args.shape == f"{IMG}x{IMG}")
@@ -287,8 +293,11 @@ def main():
         t = torch.tensor([elapsed, startup_s], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, startup_max = float(t[0].item()), float(t[1].item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, round(startup_s, 2))
         if rccl is not None:
             rccl["startup_seconds_max_over_ranks"] = round(startup_max, 2)
+            rccl["startup_seconds_per_rank"] = per_rank
     assert bool(torch.isfinite(out["intrinsics"]).all())
 
     if rank == 0:
@@ -434,8 +443,9 @@ def main():
                 del m_pt
                 t1 = time.perf_counter(); m_bl = MoGeModel.from_blob(blob).to(dev); torch.cuda.synchronize(); t_bl = time.perf_counter() - t1
                 del m_bl
-            res["load_seconds"] = {"checkpoint_pt": round(t_pt, 3), "master_blob": round(t_bl, 3),
-                                   "note": "from_pretrained(.pt) vs from_blob(packed fp32 master blob) to a ready fp32 model on the device, page cache warm"}
+            res["load_seconds"] = {"checkpoint_pt": round(t_pt, 3), "master_blob": round(t_bl, 3), "pack_fp16_on_device": round(pack_s, 4),
+                                   "note": "from_pretrained(.pt) vs from_blob(packed fp32 master blob) to a ready fp32 model on the device, page cache warm; pack_fp16_on_device = "
+                                           "model.half() of the resident fp32 master (what every rank does after the one-time broadcast)"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(O, cfg, sd, x[:1].float().cpu(), kw, args.config, num_tokens)
         print(json.dumps(res), flush=True)

@@ -158,6 +158,10 @@ int moge_master_ready(moge_handle* h);
  * created by the host with ncclCommInitRank), passed as void* so that this header needs no RCCL include.  Rank `root` must hold loaded
  * weights; every rank calls this once: ncclBroadcast of the fp32 master blob over xGMI on `stream`, then (non-root ranks) moge_master_ready.
  * RCCL is bound at call time (dlopen of the librccl.so.1 already in the process, else the system one): no link-time dependency.
+ * Failure behaviour: before any payload moves, the ranks all-reduce a status record (ready flag, blob size, root); if ANY rank is not ready
+ * (root without weights, allocation failure) or the ranks disagree on the blob size (different configs) or on the root, EVERY rank returns
+ * an error and nothing is sent - no rank is left blocked inside the collective.  Only a rank that cannot reach RCCL at all (or holds a broken
+ * communicator) returns alone; the host must then abort the communicator on the others.
  * The reference has no counterpart - it is a single-process PyTorch module (moge/model/v2.py:76-107 loads one checkpoint per process). */
 int moge_broadcast_weights(moge_handle* h, void* nccl_comm, int root, void* stream);
 

@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmoge_hip.so")
-SOURCES = ["gemm.hip", "gemm_pp.hip", "conv_pp.hip", "conv_rb.hip", "attention.hip", "attention_pp.hip", "elementwise.hip", "post.hip", "alignment.hip", "model.hip", "test_api.hip"]
+SOURCES = ["gemm.hip", "gemm_pp.hip", "conv_pp.hip", "attention.hip", "attention_pp.hip", "elementwise.hip", "post.hip", "alignment.hip", "model.hip", "test_api.hip"]
+EXPERIMENT_SOURCES = ["conv_rb.hip"]      # tools/experiments/: the fused residual block (slower than the two conv_pp launches; kbench / A-B only)
 HEADERS = ["common.h", "launchers.h", os.path.join("..", "..", "include", "moge_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
@@ -51,15 +52,17 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     if experiments:
         exp = os.path.join(os.path.dirname(HERE), "tools", "experiments")
-        hdrs += [os.path.join(exp, f) for f in os.listdir(exp)]
+        hdrs += [os.path.join(exp, f) for f in os.listdir(exp) if f.endswith(".inc")]
     jobs = []
     objs = []
-    for src in SOURCES:
-        s = os.path.join(CSRC, src)
-        o = os.path.join(objdir, src.replace(".hip", ".o"))
+    srcs = [os.path.join(CSRC, src) for src in SOURCES]
+    if experiments:                                          # whole-file experiments (default-off two rounds running: out of the product library)
+        srcs += [os.path.join(os.path.dirname(HERE), "tools", "experiments", f) for f in EXPERIMENT_SOURCES]
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s).replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + flags + ["-c", s, "-o", o])
+            jobs.append([hipcc] + flags + ["-I" + CSRC, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -85,7 +88,7 @@ def build_tools(verbose: bool = True, experiments: bool = None) -> str:
     src = os.path.join(root, "tools", "kbench.hip")
     out = os.path.join(root, "tools", "kbench")
     if _stale(out, [src, lib]):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", src, "-o", out, "-L" + LIBDIR, "-lmoge_hip", "-Wl,-rpath,$ORIGIN/../moge_amd/lib"]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17"] + (["-DMOGE_EXPERIMENTS"] if experiments else []) + [src, "-o", out, "-L" + LIBDIR, "-lmoge_hip", "-Wl,-rpath,$ORIGIN/../moge_amd/lib"]
         if verbose:
             print("[moge_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

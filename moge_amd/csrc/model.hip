@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -741,7 +742,7 @@ static int convT2(moge_handle* h, const T* in, const T* w, const float* biasT, T
 }
 
 // n residual blocks x = x + conv2(relu(conv1(relu(x))))   (modules.py:47-68 with norms = Identity) on x, tmp = scratch of the same size.
-// Returns the result in *res: x, or tmp when `may_swap` and an odd number of blocks ran FUSED - the fused kernel (conv_rb.hip: both convs in one
+// Returns the result in *res: x, or tmp when `may_swap` and an odd number of blocks ran FUSED - the fused kernel (tools/experiments/conv_rb.hip, -DMOGE_EXPERIMENTS builds only: both convs in one
 // launch, the intermediate map never leaves LDS) cannot run in place, a neighbouring tile still needs the input pixels it would overwrite.
 template <typename T>
 static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* x, T* tmp, int B, int Hh, int Ww, int C, hipStream_t st, bool may_swap = false,
@@ -777,6 +778,7 @@ static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* 
             CHK(conv3x3<T>(h, in2, w2, b2, cur, B, Hh, Ww, C, C, 0, ACT_NONE, cur, nullptr, st));
             continue;
         }
+#ifdef MOGE_EXPERIMENTS   // tools/experiments/conv_rb.hip: not part of the product library (python -m moge_amd.build --experiments)
         // CONV_RB (default OFF): measured on MI355X the fused launch is 5-10 % SLOWER than the two conv_pp launches at the bench's level-3 shape
         // (1.44-1.46 vs 1.37-1.38 ms at batch 32, profiles/r03a_kbench_rb.log, timeline r03j: one 130 KiB workgroup per CU exposes every
         // latency the two-per-CU conv_pp form hides, and the MFMA segments run at 21.7 clocks per MFMA beside the partner's read segment)
@@ -794,6 +796,7 @@ static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* 
                 continue;
             }
         }
+#endif
         if (cur != x) return fail(MOGE_ERR_INVALID, "res_blocks: internal buffer order");      // (unreachable: an unfused block only follows an even number of fused ones)
         CHK(conv3x3<T>(h, cur, w1, b1, oth, B, Hh, Ww, C, C, 1, ACT_RELU, nullptr, nullptr, st));
         CHK(conv3x3<T>(h, oth, w2, b2, cur, B, Hh, Ww, C, C, 0, ACT_NONE, cur, nullptr, st));
@@ -1531,45 +1534,82 @@ int moge_master_ready(moge_handle* h) {
 namespace {
 struct RcclApi {
     int (*bcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;      // ncclBroadcast(sendbuff, recvbuff, count, datatype, root, comm, stream)
+    int (*allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;  // ncclAllReduce(sendbuff, recvbuff, count, datatype, op, comm, stream)
     int (*user_rank)(void*, int*) = nullptr;                                               // ncclCommUserRank
     int (*count)(void*, int*) = nullptr;                                                   // ncclCommCount
     const char* (*errstr)(int) = nullptr;                                                  // ncclGetErrorString
     bool ok = false;
 };
-RcclApi& rccl_api() {
+// Only SUCCESS is cached: a host that asks before RCCL is loadable (or that loads torch's librccl later) gets another dlopen on its next call.
+// Mutex-guarded (two host threads may call at once); the dlerror() text of the failing dlopen is captured at that dlopen.
+const RcclApi* rccl_api(std::string& why) {
+    static std::mutex mu;
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return api;
-    tried = true;
+    std::lock_guard<std::mutex> lock(mu);
+    if (api.ok) return &api;
+    dlerror();
     void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) return api;
-    api.bcast = reinterpret_cast<decltype(api.bcast)>(dlsym(lib, "ncclBroadcast"));
-    api.user_rank = reinterpret_cast<decltype(api.user_rank)>(dlsym(lib, "ncclCommUserRank"));
-    api.count = reinterpret_cast<decltype(api.count)>(dlsym(lib, "ncclCommCount"));
-    api.errstr = reinterpret_cast<decltype(api.errstr)>(dlsym(lib, "ncclGetErrorString"));
-    api.ok = api.bcast && api.user_rank && api.count;
-    return api;
+    if (!lib) {
+        const char* e = dlerror();
+        why = e ? e : "dlopen failed";
+        lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return nullptr;
+    }
+    RcclApi a;
+    a.bcast = reinterpret_cast<decltype(a.bcast)>(dlsym(lib, "ncclBroadcast"));
+    a.allreduce = reinterpret_cast<decltype(a.allreduce)>(dlsym(lib, "ncclAllReduce"));
+    a.user_rank = reinterpret_cast<decltype(a.user_rank)>(dlsym(lib, "ncclCommUserRank"));
+    a.count = reinterpret_cast<decltype(a.count)>(dlsym(lib, "ncclCommCount"));
+    a.errstr = reinterpret_cast<decltype(a.errstr)>(dlsym(lib, "ncclGetErrorString"));
+    if (!(a.bcast && a.allreduce && a.user_rank && a.count)) { why = "ncclBroadcast / ncclAllReduce / ncclCommUserRank / ncclCommCount not exported"; return nullptr; }
+    a.ok = true;
+    api = a;
+    return &api;
 }
 }  // namespace
 
+// Every rank of the communicator must call this.  A rank whose LOCAL preconditions fail (the root has no weights, bad root, allocation failure) does
+// not return early - the others would already sit in ncclBroadcast - but takes part in a 5-word status all-reduce first: all ranks learn that someone
+// is not ready, or that the ranks disagree on the blob size (different model configs) or on the root, and ALL return an error before any payload moves.
+// (A rank that cannot reach RCCL at all, or whose communicator is broken, still returns alone: then abort the communicator on the other ranks.)
 int moge_broadcast_weights(moge_handle* h, void* nccl_comm, int root, void* stream) {
     if (!h || !nccl_comm) return fail(MOGE_ERR_INVALID, "null argument");
-    RcclApi& api = rccl_api();
-    if (!api.ok) {
-        const char* why = dlerror();                            // (one call: dlerror() clears the message it returns)
-        return fail(MOGE_ERR_INVALID, "RCCL not available: librccl.so.1 could not be loaded (%s)", why ? why : "symbols missing");
-    }
+    std::string why;
+    const RcclApi* apip = rccl_api(why);
+    if (!apip) return fail(MOGE_ERR_INVALID, "RCCL not available: librccl.so.1 could not be loaded (%s)", why.c_str());
+    const RcclApi& api = *apip;
     HIPCHK(hipSetDevice(h->device));
     int rank = -1, n = 0;
     int rc = api.user_rank(nccl_comm, &rank);
     if (rc == 0) rc = api.count(nccl_comm, &n);
     if (rc != 0) return fail(MOGE_ERR_INVALID, "RCCL communicator query failed: %s", api.errstr ? api.errstr(rc) : "?");
-    if (root < 0 || root >= n) return fail(MOGE_ERR_INVALID, "root %d is not a rank of a %d-rank communicator", root, n);
-    if (rank == root && !h->master_ready) return fail(MOGE_ERR_NOT_LOADED, "the root rank has no weights to broadcast (moge_load_weights first)");
-    CHK(moge_alloc_master(h));
     hipStream_t st = (hipStream_t)stream;
+    // ---- local checks, recorded instead of returned
+    int local_status = 0;
+    std::string local_msg;
+    if (root < 0 || root >= n) { local_status = MOGE_ERR_INVALID; local_msg = "root " + std::to_string(root) + " is not a rank of a " + std::to_string(n) + "-rank communicator"; }
+    else if (rank == root && !h->master_ready) { local_status = MOGE_ERR_NOT_LOADED; local_msg = "the root rank has no weights to broadcast (moge_load_weights first)"; }
+    else if (moge_alloc_master(h) != 0) { local_status = MOGE_ERR_HIP; local_msg = std::string("master blob allocation failed: ") + moge_last_error(); }
+    // ---- agreement: min over ranks of {ok, floats, -floats, root, -root}
+    long long rec[5] = {local_status == 0 ? 1 : 0, (long long)h->master_floats, -(long long)h->master_floats, root, -(long long)root};
+    long long* drec = nullptr;
+    HIPCHK(hipMalloc(&drec, sizeof(rec)));
+    const int NCCL_INT64 = 4, NCCL_MIN = 3;                     // rccl.h ncclDataType_t / ncclRedOp_t
+    hipError_t he = hipMemcpyAsync(drec, rec, sizeof(rec), hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) {
+        rc = api.allreduce(drec, drec, 5, NCCL_INT64, NCCL_MIN, nccl_comm, st);
+        if (rc == 0) he = hipMemcpyAsync(rec, drec, sizeof(rec), hipMemcpyDeviceToHost, st);
+        if (rc == 0 && he == hipSuccess) he = hipStreamSynchronize(st);
+    }
+    hipFree(drec);
+    if (rc != 0) return fail(MOGE_ERR_HIP, "ncclAllReduce (status agreement) failed: %s", api.errstr ? api.errstr(rc) : "?");
+    HIPCHK(he);
+    if (local_status != 0) return fail(local_status, "%s", local_msg.c_str());
+    if (rec[0] != 1) return fail(MOGE_ERR_INVALID, "another rank of the communicator is not ready to broadcast / receive weights (its own call reports why); nothing was sent");
+    if (rec[1] != -rec[2]) return fail(MOGE_ERR_INVALID, "ranks disagree on the master blob size (%lld ... %lld floats, this rank %lld): different model configs; nothing was sent",
+                                       rec[1], -rec[2], (long long)h->master_floats);
+    if (rec[3] != -rec[4]) return fail(MOGE_ERR_INVALID, "ranks disagree on the root rank (%lld ... %lld); nothing was sent", rec[3], -rec[4]);
     const int NCCL_FLOAT32 = 7;                                  // ncclFloat (rccl.h ncclDataType_t)
     rc = api.bcast(h->master, h->master, h->master_floats, NCCL_FLOAT32, root, nccl_comm, st);
     if (rc != 0) return fail(MOGE_ERR_HIP, "ncclBroadcast failed: %s", api.errstr ? api.errstr(rc) : "?");

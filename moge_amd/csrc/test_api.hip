@@ -218,8 +218,12 @@ static int t_conv_ex(const moge_test_conv_args& a, hipStream_t st) {
         TL(launch_repack<T>(a.w2, w2b.p, Cout, 9, 1, Cin, (long)Cin * 9, 1, 0, 9, (long)9 * Cin, Cin, 0, st));
         GemmArgs r = g;
         r.relu_in = 1; r.act = ACT_NONE; r.rb_w2 = w2b.p; r.rb_bias2 = a.bias2; r.add = xb.p; r.ldadd = Cin;
+#ifdef MOGE_EXPERIMENTS
         if (!conv_rb_eligible(r)) return MOGE_ERR_INVALID;
         TL(launch_conv_rb(r, st));
+#else
+        return MOGE_ERR_INVALID;                     // the fused residual block lives in tools/experiments/ (experiments builds only)
+#endif
     } else {
         TL(launch_gemm<T>(g, AMODE_CONV3, st));
     }

@@ -15,8 +15,11 @@ there); what differs is forced by what this image ships:
     integer coordinates, BORDER_CONSTANT 0 for the image split, BORDER_REPLICATE for the merge, half-pixel-centre resize);
   * utils3d is not installed (un-vendored dependency, pyproject.toml:23): the icosahedron, the look-at extrinsics (OpenCV camera: x right,
     y down, z forward; world up = +z) and the uv / pixel conventions (pixel-centre uv in [0, 1], pixel = uv * size - 0.5) are restated.
-    "Parity unpinned" for both, like the other utils3d call sites (README): the pipeline is self-consistent - split and merge share the
-    cameras - and is tested against an analytic scene (tests/test_panorama_cpu.py), not against the reference's output.
+    Pinned to the reference's own module all the same: oracle/make_panorama_golden.py runs the unmodified moge/utils/panorama.py with cv2 / utils3d
+    stand-ins built from the helpers below and stores its outputs (tests/golden/panorama_ref.npz); tests/test_panorama_reference.py holds this file
+    to them - merged log-distance within 5e-5 (observed 1e-5 ... 1e-6), masks equal, the uint8 split within 1 LSB - and re-runs the reference live
+    where /root/reference exists.  What stays unpinned is the utils3d CONVENTION itself (the same stand-in serves both sides), as for the other
+    utils3d call sites (README); tests/test_panorama_cpu.py additionally checks the pipeline against an analytic scene.
 """
 from __future__ import annotations
 

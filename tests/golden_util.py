@@ -49,12 +49,18 @@ def rel_err(a, b, floor=1.0):
 # ---- parity gates (north_star) ----------------------------------------------------------------------------------------
 FP32_TOL = 1e-3            # fp32 mode: every pixel within 1e-3 relative (oracle.metrics: per-pixel, norm-relative), mask bit-exact
 ILL_TOL = 5e-2             # ill-posed checkpoint: p99.9 (the LM trajectory amplifies 1e-7 forward noise; so does the reference between thread counts)
-FP16_FACTOR = 2.0          # fp16 mode: at most 2x the drift of the reference's OWN fp16 path against its fp32 path on the same case
+# fp16 modes: the library's error against the fp32 reference output may be at most FP16_FACTOR x the drift of the reference's OWN fp16 path against its
+# fp32 path on the same case (p99.9 of the per-pixel error).  Round 5 tightened the per-pixel outputs from 2.0 to 1.6: observed over every fixture and
+# both fp16 forms (profiles/r04fin2_pytest_gpu_s.log) the worst p99.9 is 1.38 x the reference's own drift (tiny_b2_up; the BASELINE-size fixtures sit at
+# 0.7-0.9 x: the library's fp16 path is CLOSER to fp32 than the reference's, one rounding per residual update where the reference rounds three times).
+# Outputs that are ONE number per image (intrinsics, metric scale) and the mask (a handful of discrete flips on a 25 k-pixel fixture) are single random
+# draws of the reference's drift, not a p99.9 over pixels: they keep 2.0 (worst observed 1.68 x, v1_tiny_b2 intrinsics).
+FP16_FACTOR = 1.6
+FP16_FACTOR_BY_KEY = dict(intrinsics=2.0, metric_scale=2.0, mask=2.0)
 # ... and NO pixel further than a small multiple of that band (the p99.9 gate alone would let 0.1 % of the pixels - a tile corner, a border row - be
-# arbitrarily wrong).  Observed max / band over all fixtures, both fp16 forms (profiles/r04c_pytest_gpu_half_resid.log): points / depth <= 0.61,
-# intrinsics <= 0.60, normals <= 4.7 (unit vectors of a random tiny net: a pixel whose raw normal is nearly 0 turns by a large angle) - the
-# reference's own fp16 outputs show max / band <= 3.2.  Gates at ~3x what is seen for the geometry outputs:
-FP16_MAX_FACTOR = dict(points=2.0, depth=2.0, intrinsics=2.0, metric_scale=2.0, normal=8.0)
+# arbitrarily wrong).  Observed max / reference drift over all fixtures, both fp16 forms: points / depth <= 1.9, normals <= 12 (unit vectors of a random
+# tiny net: a pixel whose raw normal is nearly 0 turns by a large angle; the reference's own fp16 outputs show <= 6.4 there).  In units of the band:
+FP16_MAX_FACTOR = dict(points=2.0, depth=2.0, intrinsics=2.0, metric_scale=2.0, normal=11.0)
 FLIP_SLACK = 4              # pixels
 FP16_FLOOR = dict(points=5e-4, depth=5e-4, normal=2e-3, intrinsics=1e-4, metric_scale=5e-4, mask=1e-4)   # where the reference's drift is ~0 (e.g. fov_x given)
 
@@ -113,12 +119,12 @@ def fp16_band(meta: dict, gold: dict = None, form: str = "autocast") -> dict:
         for k, v in reference_drift16(gold, prefix).items():
             drift[k] = max(drift.get(k, 0.0), v)
     for k, own in drift.items():
-        band[k] = FP16_FACTOR * max(own, FP16_FLOOR.get(k, 5e-4))
+        band[k] = FP16_FACTOR_BY_KEY.get(k, FP16_FACTOR) * max(own, FP16_FLOOR.get(k, 5e-4))
     # intrinsics are ONE number per image (the focal; a least-squares functional of the point map), so the reference's own drift on a case
     # is a single random draw - it ranges 5e-5 ... 1.5e-3 over the fixtures at the same point-map drift.  Floor it at a quarter of the
     # case's point-map drift (the focal's relative error is bounded by the point map's).
     if "intrinsics" in band and "points" in drift:
-        band["intrinsics"] = max(band["intrinsics"], FP16_FACTOR * 0.25 * drift["points"])
+        band["intrinsics"] = max(band["intrinsics"], FP16_FACTOR_BY_KEY["intrinsics"] * 0.25 * drift["points"])
     return band
 
 
@@ -126,7 +132,7 @@ def check_fp16(out: dict, ref32: dict, band: dict) -> dict:
     """fp16 mode against the fp32 reference outputs, inside `band` (p99.9 of the per-pixel error <= band, EVERY pixel <= FP16_MAX_FACTOR x band;
     mask flips and non-finite-pattern differences as a fraction of the pixels)."""
     assert set(out.keys()) == set(ref32.keys()), (sorted(out), sorted(ref32))
-    flips_allowed = band.get("mask", FP16_FACTOR * FP16_FLOOR["mask"])
+    flips_allowed = band.get("mask", FP16_FACTOR_BY_KEY["mask"] * FP16_FLOOR["mask"])
     seen = {}
     for k in ref32:
         a, b = _arr(out[k]), _arr(ref32[k])
@@ -144,6 +150,20 @@ def check_fp16(out: dict, ref32: dict, band: dict) -> dict:
         seen[k] = val
         seen[k + ".max"] = float(e.max())
         seen[k + ".max/band"] = float(e.max()) / band[k]
+        seen[k + ".p999/band"] = val / band[k]
         assert val <= band[k], (k, val, band[k])
         assert float(e.max()) <= FP16_MAX_FACTOR.get(k, 8.0) * band[k], (k, "max", float(e.max()), FP16_MAX_FACTOR.get(k, 8.0) * band[k])
     return seen
+
+
+def gate_line(seen: dict, band: dict) -> str:
+    """One line per fixture for profiles/: p99.9 / band and max / (max-factor x band) of every output - 1.00 = at the gate."""
+    parts = []
+    for k in band:
+        if k == "mask":
+            if k in seen:
+                parts.append(f"mask flips={seen[k]:.1e}/{band[k]:.1e}")
+            continue
+        if k + ".p999/band" in seen:
+            parts.append(f"{k} p999/band={seen[k + '.p999/band']:.2f} max/maxgate={seen[k + '.max/band'] / FP16_MAX_FACTOR.get(k, 8.0):.2f}")
+    return " | ".join(parts)

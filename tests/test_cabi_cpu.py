@@ -97,7 +97,10 @@ def test_eval_plugin_exposes_the_reference_baseline_interface():
     B = mod.Baseline
     assert isinstance(B.load, click.Command)
     names = {p.name for p in B.load.params}
-    assert {"num_tokens", "resolution_level", "pretrained_model_name_or_path", "use_fp16", "device"} <= names
+    assert names == {"num_tokens", "resolution_level", "pretrained_model_name_or_path", "use_fp16", "device", "version"}       # baselines/moge.py:29-35
+    defaults = {p.name: p.default for p in B.load.params}
+    assert defaults["version"] == "v1" and defaults["resolution_level"] == 9 and defaults["pretrained_model_name_or_path"] == "Ruicheng/moge-vitl"
+    assert defaults["num_tokens"] is None and defaults["device"] == "cuda:0"
     assert callable(B.infer) and callable(B.infer_for_evaluation)
     K = torch.tensor([[[0.8, 0.0, 0.5], [0.0, 1.1, 0.5], [0.0, 0.0, 1.0]]])
     fov = mod._fov_x_degrees(K)

@@ -1,12 +1,17 @@
 """GPU: every flavour of conv_pp_kernel the decoder runs (residual add, fused 1x1 side input - both the two-halo-buffer form and the
-register form of the 64-channel level -, uv term, bilinear x2 + 3x3 pixel-shuffle resampler) and the fused residual block of conv_rb.hip,
+register form of the 64-channel level -, uv term, bilinear x2 + 3x3 pixel-shuffle resampler) and - in `--experiments` builds of the library
+only - the fused residual block of tools/experiments/conv_rb.hip (default-off for two rounds because it is slower: out of the product build),
 each against F.conv2d / F.interpolate in fp32 on the SAME fp16-rounded operands, at tile-border sizes and at the decoder's own 480 / 240
 maps.  Tolerance as tests/test_hip_gemm_pp.close(): max |err| <= 1e-3 max|ref|, mean |err| <= 1e-4 max|ref| (+ the fp16 output rounding)."""
 import pytest
 import torch
 import torch.nn.functional as F
 
+import os
+
 pytestmark = pytest.mark.gpu
+EXPERIMENTS = os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "moge_amd", "lib", "obj", ".experiments"))
+needs_experiments = pytest.mark.skipif(not EXPERIMENTS, reason="tools/experiments/conv_rb.hip is compiled by `python -m moge_amd.build --experiments` only")
 
 
 @pytest.fixture(scope="module")
@@ -143,6 +148,7 @@ def resblock_ref(x, w1, b1, w2, b2):
     return r16(y) + x.cuda()
 
 
+@needs_experiments
 @pytest.mark.parametrize("B,Hh,Ww", [(2, 23, 45), (1, 16, 16), (3, 17, 70), (1, 5, 3), (2, 32, 48), (1, 50, 37), (1, 1, 1)])
 def test_fused_residual_block(H, B, Hh, Ww):
     """conv_rb.hip: x + conv2(relu(conv1(relu(x)) + b1)) + b2 in ONE launch, the intermediate tile in LDS.  Against fp32 F.conv2d with the
@@ -156,6 +162,7 @@ def test_fused_residual_block(H, B, Hh, Ww):
     close(out, ref, "resblock")
 
 
+@needs_experiments
 @pytest.mark.parametrize("grid", [3, 13])
 def test_fused_residual_block_equals_two_launch_path_bitwise(H, grid):
     """The fused kernel accumulates each conv in the two-launch kernels' order (same MFMA form, taps 0..8, two K-steps of 32) and rounds the
@@ -192,6 +199,8 @@ def test_decoder_sized_maps(H, what):
         sw = r16(torch.randn(64, 64, generator=g) / 8)
         close(H.conv_ex(x, w, b, side=side, side_w=sw), conv_ref(x, w, b) + torch.einsum("bhwc,oc->bhwo", side.cuda(), sw.cuda()), what)
     elif what == "resblock":
+        if not EXPERIMENTS:
+            pytest.skip("fused residual block: --experiments builds only")
         w2 = r16(torch.randn(64, 64, 3, 3, generator=g) / 24)
         b2 = torch.randn(64, generator=g)
         close(H.conv_ex(x, w, b, w2=w2, bias2=b2), resblock_ref(x, w, b, w2, b2), what)

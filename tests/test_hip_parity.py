@@ -5,15 +5,15 @@ and - at the BASELINE sizes - through size-independent properties.
 Gates (north_star; tests/golden_util.py, metric = oracle/metrics.py: per pixel, relative to that pixel's own norm):
   FP32 mode  points / depth / normal / intrinsics: EVERY pixel within 1e-3; validity mask bit-exact; same +inf pattern.
   FP16 mode  judged against the reference's fp32 output with the band the reference's OWN fp16 path (infer(use_fp16=True), run on the
-             same case when the fixture was made) shows against its fp32 path: p99.9 of the per-pixel error <= 2 x the reference's,
-             mask flips <= 2 x the reference's.  Every fixture carries those numbers (meta.drift16)."""
+             same case when the fixture was made) shows against its fp32 path: p99.9 of the per-pixel error <= 1.6 x the reference's
+             (per-image numbers and mask flips: 2 x; tests/golden_util.py FP16_FACTOR).  Every fixture carries those numbers (meta.drift16)."""
 import os
 
 import numpy as np
 import pytest
 import torch
 
-from tests.golden_util import CASE_BY_NAME, FP32_TOL, SLOW_CASES, check_fp16, check_fp32, fp16_band, load_case, rel_err, subsample
+from tests.golden_util import gate_line, CASE_BY_NAME, FP32_TOL, SLOW_CASES, check_fp16, check_fp32, fp16_band, load_case, rel_err, subsample
 
 pytestmark = pytest.mark.gpu
 
@@ -89,7 +89,7 @@ BIG = [n for n in SANE if n in SLOW_CASES and n != "vits_house518"]
 @pytest.mark.parametrize("name", SANE)
 def test_fp16_mode_within_reference_fp16_band(MoGeModel, name, tmp_path_factory):
     """fp16 mode, both forms the reference has (.half() weights; fp32 weights + use_fp16=True), against the reference's fp32 golden inside
-    2x the reference's own fp16 drift on that case."""
+    1.6x (per-image numbers, mask flips: 2x) the reference's own fp16 drift on that case."""
     case, cfg, sd, x, gold, meta = load_case(name)
     model, _, _ = get_model(MoGeModel, None, None, None, tmp_path_factory, case=case)
     kw = dict(case["kwargs"]); kw["use_fp16"] = True
@@ -105,8 +105,7 @@ def test_fp16_mode_within_reference_fp16_band(MoGeModel, name, tmp_path_factory)
         model.onnx_compatible_mode = False
     for tag, o in (("autocast", out), ("half", out_h)):
         seen = check_fp16(sub(o, st), g, band[tag])
-        print(f"[parity fp16 {tag}] {name}: " + " ".join(f"{k}={v:.1e}/{band[tag].get(k, 0):.1e}" for k, v in seen.items() if "/" not in k)
-              + " | max/band " + " ".join(f"{k[:-9]}={v:.2f}" for k, v in seen.items() if k.endswith(".max/band")))
+        print(f"[gate fp16 {tag}] {name}: " + gate_line(seen, band[tag]))
     # the reference's own fp16 outputs are inside the same bands by construction; ours must not be further from them than 2 bands
     check_fp16(sub(out, st), golden_infer(gold, "infer16."), {k: 2 * v for k, v in band["autocast"].items()})
     check_fp16(sub(out_h, st), golden_infer(gold, "infer16half."), {k: 2 * v for k, v in band["half"].items()})
@@ -360,14 +359,46 @@ def test_eval_plugin_runs_through_the_click_loader(tmp_path_factory):
     spec = importlib.util.spec_from_file_location("moge_mi355x_plugin", plug)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    base = mod.Baseline.load.main(["--pretrained", path, "--num_tokens", "108", "--device", "cuda:0"], standalone_mode=False)
+    base = mod.Baseline.load.main(["--pretrained", path, "--num_tokens", "108", "--device", "cuda:0", "--version", "v2"], standalone_mode=False)
     x = torch.rand(3, 84, 112, generator=torch.Generator().manual_seed(5)).cuda()
     K = torch.tensor([[0.9, 0.0, 0.5], [0.0, 1.2, 0.5], [0.0, 0.0, 1.0]], device="cuda")
     out = base.infer_for_evaluation(x, K)
-    assert set(out) >= {"points_metric", "depth_metric", "intrinsics"}
+    assert set(out) == {"points_metric", "depth_metric", "intrinsics"}                          # baselines/moge.py:77-82: exactly these keys
     ref = O.infer(cfg, sd, x.cpu(), num_tokens=108, fov_x=float(mod._fov_x_degrees(K.cpu())), apply_mask=False)
     assert rel_err(out["depth_metric"].cpu().numpy(), ref["depth"].numpy()) < FP32_TOL
     assert rel_err(out["intrinsics"].cpu().numpy(), ref["intrinsics"].numpy()) < FP32_TOL
+    # `--fp16` is autocast on fp32 weights in the plugin (baselines/moge.py:69), never model.half(); infer() ignores the flag (:47)
+    base16 = mod.Baseline.load.main(["--pretrained", path, "--num_tokens", "108", "--version", "v2", "--fp16"], standalone_mode=False)
+    assert base16.use_fp16 and base16.model.dtype == torch.float32
+    same = base16.model.infer(x, fov_x=mod._fov_x_degrees(K), apply_mask=False, num_tokens=108, use_fp16=True)
+    got = base16.infer_for_evaluation(x, K)
+    assert torch.equal(got["depth_metric"], same["depth"])
+    masked = base.infer(x, K)                                                                   # apply_mask=True, the model's default use_fp16=True
+    want = base.model.infer(x, fov_x=mod._fov_x_degrees(K), apply_mask=True, num_tokens=108)
+    assert torch.equal(torch.nan_to_num(masked["depth_metric"], posinf=-1.0), torch.nan_to_num(want["depth"], posinf=-1.0))
+
+
+def test_eval_plugin_defaults_to_the_v1_model_like_the_reference(tmp_path_factory):
+    """baselines/moge.py:35 - `--version` defaults to v1 and v1 reports the scale-invariant keys (:49-54, :71-76)."""
+    import importlib.util
+    from oracle import moge_oracle_v1 as O1
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    cfg = O1.named_configs()["tiny-v1-vits"]
+    sd = O1.synth_state_dict(cfg, 1, True)
+    path = os.path.join(str(tmp_path_factory.mktemp("ckpt1")), "model.pt")
+    O1.save_checkpoint(path, cfg, sd)
+    plug = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "baselines", "moge_mi355x.py")
+    spec = importlib.util.spec_from_file_location("moge_mi355x_plugin", plug)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    base = mod.Baseline.load.main(["--pretrained", path, "--num_tokens", "108"], standalone_mode=False)
+    assert base.version == "v1" and type(base.model).__module__.endswith("model.v1")
+    x = torch.rand(3, 84, 112, generator=torch.Generator().manual_seed(6)).cuda()
+    out = base.infer_for_evaluation(x)
+    assert set(out) == {"points_scale_invariant", "depth_scale_invariant", "intrinsics"}
+    ref = O1.infer(cfg, sd, x.cpu(), num_tokens=108, apply_mask=False)
+    assert rel_err(out["depth_scale_invariant"].cpu().numpy(), ref["depth"].numpy()) < FP32_TOL
 
 
 def test_master_blob_cache_is_bit_identical_to_the_checkpoint_load(MoGeModel, tmp_path_factory):

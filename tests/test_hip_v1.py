@@ -1,13 +1,13 @@
 """GPU: MoGe-1 (`moge.model.v1.MoGeModel`) through the v1 mirror -> `moge_create_v1 / moge_v1_forward / moge_v1_infer`
 against the committed fixtures of the REAL reference v1 class (tests/golden/v1_*.npz) and the live CPU oracle (oracle/moge_oracle_v1.py).
-Same gates as the MoGe-2 parity tests: fp32 mode every pixel within 1e-3 and the mask bit-exact; fp16 mode inside 2x the reference's own
+Same gates as the MoGe-2 parity tests: fp32 mode every pixel within 1e-3 and the mask bit-exact; fp16 mode inside 1.6x (per-image numbers, mask flips: 2x) the reference's own
 fp16-vs-fp32 drift."""
 import os
 
 import pytest
 import torch
 
-from tests.golden_util import CASE_BY_NAME, SLOW_CASES, check_fp16, check_fp32, fp16_band, load_case, rel_err, subsample
+from tests.golden_util import gate_line, CASE_BY_NAME, SLOW_CASES, check_fp16, check_fp32, fp16_band, load_case, rel_err, subsample
 
 pytestmark = pytest.mark.gpu
 V1 = [n for n, c in CASE_BY_NAME.items() if c.get("version") == "v1"]
@@ -72,7 +72,7 @@ def test_v1_fp16_mode_within_reference_fp16_band(name, tmp_path_factory):
     for tag, o in (("autocast", out), ("half", out_h)):
         band = bands[tag]
         seen = check_fp16(sub(o, st), g, band)
-        print(f"[parity v1 fp16 {tag}] {name}: " + " ".join(f"{k}={v:.1e}/{band.get(k, 0):.1e}" for k, v in seen.items() if "/" not in k))
+        print(f"[gate v1 fp16 {tag}] {name}: " + gate_line(seen, band))
 
 
 def test_v1_properties_and_errors(tmp_path_factory):

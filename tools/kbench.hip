@@ -573,6 +573,7 @@ __global__ void cmp_bits(const f16* a, const f16* b, size_t n, int* nbad) {
         if (x != y) atomicAdd(nbad, 1);
     }
 }
+#ifdef MOGE_EXPERIMENTS
 static int bench_rb(int iters) {
     hipStream_t st;
     CK(hipStreamCreate(&st));
@@ -642,6 +643,9 @@ static int bench_rb(int iters) {
     }
     return fails;
 }
+#else
+static int bench_rb(int) { printf("rb: the fused residual block is compiled in --experiments builds only (python -m moge_amd.build --experiments --tools)\n"); return 0; }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // co-residency probe: a GEMM stream and an attention stream side by side.  The production GEMM (gemm_pp128p_kernel:
