@@ -85,6 +85,37 @@ def test_attention_64_queries_per_wave_is_bit_identical(H, B, nh, N):
     assert torch.equal(outs[1], outs[2])
 
 
+@pytest.mark.parametrize("prio", [0, 1])
+@pytest.mark.parametrize("B,nh,N", [(2, 3, 130), (1, 2, 512), (1, 2, 513), (1, 2, 600), (2, 2, 900), (1, 8, 1370), (1, 2, 3571), (1, 2, 3601), (1, 1, 64), (1, 1, 65), (3, 1, 1)])
+def test_attention_ping_pong_kernel_is_bit_identical(H, B, nh, N, prio):
+    """attn_pp16x_kernel (round 5: 8-wave workgroups, the two waves of a SIMD alternate a matrix phase and a softmax phase, 512 queries share one
+    K / V stream) forced with ATTN_KERN = 4 against attn_pp16mq_kernel<2>: the same arithmetic per query, so BIT-identical outputs - across
+    sequence lengths that exercise every split of the queries (N < 512: all of them on the attn_pp16mq tail launch; 512 / 513 / 600: full
+    blocks + a tail launch; 900 / 3571: a partially filled ping-pong workgroup with query-less waves; 3601: 7 blocks + 17 tail queries), the
+    single-tile and two-tile rings, and late dominant keys that trip the overflow guard in some query blocks and not in their neighbours."""
+    from moge_amd import _lib as L
+    g = torch.Generator().manual_seed(N + 17)
+    q, k, v = (torch.randn(B, nh, N, 64, generator=g) for _ in range(3))
+    q = q * 1.5
+    if N > 80:
+        k[:, :, N // 2 + 3] = q[:, :, 5] * 6.0
+        k[:, 0, N - 2] = q[:, 0, min(70, N - 1)] * 5.0
+        if N > 700:
+            k[:, :, 650] = q[:, :, 600] * 6.0           # a trip inside the second group of waves (queries 256-511 of a block) / the second block
+    ref = F.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda()).permute(0, 2, 1, 3).reshape(B, N, nh * 64)
+    outs = {}
+    for kern in (1, 4):
+        L.tune("ATTN_KERN", kern)
+        L.tune("ATTN_X_PRIO", prio)
+        try:
+            outs[kern] = H.attention(1, q, k, v)
+        finally:
+            L.tune("ATTN_KERN", 3)
+            L.tune("ATTN_X_PRIO", 0)
+        assert relmax(outs[kern], ref) < 1e-2, kern
+    assert torch.equal(outs[1], outs[4])
+
+
 def test_attention_online_softmax_rescale(H):
     """rule 26: force the running-max rescale branch - one key in a LATE tile dominates one query."""
     g = torch.Generator().manual_seed(7)

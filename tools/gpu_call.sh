@@ -96,6 +96,9 @@ print('B=1: %.1f img/s %.3f ms/step p50 %.3f | ' % (d['value'], d['ms_per_step']
                 AB_SUFFIX=_b1 BENCH_ARGS="--batch 1" bash tools/gpu_call.sh $tag ab ;;
     ab2)        AB_SUFFIX=_b2 BENCH_ARGS="--batch 2" bash tools/gpu_call.sh $tag ab ;;
     tests_new2) timeout 600 python -m pytest tests/test_hip_kernels.py tests/test_hip_parity.py -m gpu -q -p no:cacheprovider -k "cast or half_model" 2>&1 | tail -3 ;;
+    tests_attn) timeout 600 python -m pytest tests/test_hip_kernels.py -k attention -m gpu -q -p no:cacheprovider -x 2>&1 | tail -8 ;;
+    kb_attn_x)  # attn_pp16x_kernel (ping-pong) against attn_pp16mq: interleaved in one process per shape, bit-identity checked by kbench
+                for f in ${KB_ATTN_CASES:-"vitl b32 N3601" "vitl b16 N3601" "518x1036"}; do KB_X=1 timeout 120 ./tools/kbench attn "$f" ${KB_ITERS:-20}; done > $out/${tag}_kbench_attn_x.log 2>&1; cat $out/${tag}_kbench_attn_x.log ;;
     *) echo "unknown step $what" ;;
   esac
 done

@@ -410,7 +410,9 @@ static int bench_attn(const char* filter, int iters) {
         CK(hipStreamSynchronize(st));
         // exp: ATTN_EXP (32x32x16 kernels), var: ATTN_VAR bits of attn_pp16_kernel - both need a library built with --experiments
         struct Var { const char* name; int kind, exp, var; int kern = 0; };
-        std::vector<Var> vars = {{"pp16", 1, 0, 0, 0}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}};
+        // kern 4 = attn_pp16x_kernel (ping-pong wave groups) [+ attn_pp16mq on the queries beyond the last full 512-block]; 5 = the same with s_setprio 1 in the M phase
+        std::vector<Var> vars = {{"pp16", 1, 0, 0, 0}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"x+prio", 1, 0, 0, 5}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"x+prio", 1, 0, 0, 5}};
+        if (getenv("KB_X")) vars = {{"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"x+prio", 1, 0, 0, 5}};
         f16* out_q2 = nullptr;                       // mq<2> result: mq<4> must reproduce it bit for bit (per-block guard decisions; spiked keys above force them)
         CK(hipMalloc(&out_q2, n * 2));
         if (getenv("KB_EXP")) vars = {{"old(vT)", 0, 0, 0}, {"x:pp32 nw4", 1, 1, 0}, {"pp16", 1, 0, 0}, {"x:noexp", 1, 0, 1}, {"x:noguard", 1, 0, 2}, {"x:ks-outer", 1, 0, 4},
@@ -420,7 +422,8 @@ static int bench_attn(const char* filter, int iters) {
         for (const Var& va : vars) {
             moge_tune_set("ATTN_EXP", va.exp);
             moge_tune_set("ATTN_VAR", va.var);
-            moge_tune_set("ATTN_KERN", va.kern);
+            moge_tune_set("ATTN_KERN", va.kern == 5 ? 4 : va.kern);
+            moge_tune_set("ATTN_X_PRIO", va.kern == 5 ? 1 : 0);
             auto run = [&]() { return va.kind == 0 ? launch_attention<f16>(q, k, vT, out, c.B, c.nh, c.Ntok, Npad, st) : launch_attention_pp(q, k, v, out, c.B, c.nh, c.Ntok, st); };
             CK(hipMemsetAsync(out, 0, n * 2, st));
             int rc = run();
@@ -439,7 +442,7 @@ static int bench_attn(const char* filter, int iters) {
             const double tf = 4.0 * BH * (double)c.Ntok * c.Ntok * 64 / (ms * 1e-3) / 1e12;
             int hdiff = -1;
             if (va.kern == 1) CK(hipMemcpyAsync(out_q2, out, n * 2, hipMemcpyDeviceToDevice, st));
-            if (va.kern == 2) {
+            if (va.kern >= 2) {
                 CK(hipMemsetAsync(dbad, 0, 4, st));
                 cmp_bits<<<2048, 256, 0, st>>>(out, out_q2, n, dbad);
                 CK(hipMemcpyAsync(&hdiff, dbad, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
