@@ -72,7 +72,7 @@ constexpr float AP_PSUM_LIMIT = 16384.f;
 //      sums: the decision is known right after the K Q^T chain, so the exponentials are free to interleave with the P V MFMAs (with the
 //      sum-based guard the branch sits between the last exponential and the first P V MFMA and serialises the two)
 constexpr int AP_VAR_DEFAULT = 0;
-constexpr int AP_X_DEFAULT = 0;         // attn_pp16x_kernel (round 5) for grids of >= ATTN_X_MIN_ROUNDS rounds: off until measured on the GPU
+constexpr int AP_X_DEFAULT = 0;         // attn_pp16x_kernel (round 5, --experiments builds only): measured 13 % slower than attn_pp16mq<4>
 constexpr int AP_KERN_DEFAULT = 3;      // 0: attn_pp16_kernel; 1 / 2 / 3: attn_pp16mq_kernel<2> / <4> / chosen by grid size (row sums on the matrix pipe)
 constexpr float AP_SCORE_LIMIT = 15.f;
 constexpr float AP_ROWSUM_LIMIT = 49152.f;      // attn_pp16m: FULL row sum of a tile (64 keys) below this -> every P < 49152 < 65504 (fp16 max)
@@ -664,378 +664,9 @@ __global__ __launch_bounds__(256, QB > 2 ? 2 : 3) void attn_pp16mq_kernel(const 
     attn_pp16mq_body<QB>(q, k, v, out, Ntok, nh, bh, q_base, smem);
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// attn_pp16x_kernel (round 5): the arithmetic of attn_pp16mq_kernel<4>, re-timed as a PING-PONG between the two waves of every SIMD.
-//
-// attn_pp16mq runs two independent 4-wave workgroups per CU; each wave walks  K Q^T (32 MFMA) -> exp / convert (64 v_exp_f32 + 32 v_cvt_pk) -> P V
-// (32 MFMA)  serially, and whether the matrix pipe has work while a wave is in its softmax is left to the drift between two unrelated
-// workgroups: 4040 clocks per tile and wave measured (1809 us per launch at 1.91 GHz, 57 tiles, 15 workgroups per slot) against 2 x 72 x 16 =
-// 2304 MFMA clocks per SIMD = 0.57 busy (r04fin4_pmc_MFMA.csv: 0.556).  Here ONE 8-wave workgroup owns the CU (waves w and w + 4 share a SIMD, as
-// in gemm_pp.hip) and 512 queries of one head; every wave alternates two phases per 64-key tile, and the two wave groups run exactly one phase
-// apart (workgroup barriers at every phase change):
-//
-//     E(t)  "softmax":  64 v_exp_f32, 32 v_cvt_pk, the 8 row-sum MFMAs + guard of tile t; V^T(t) operands requested (16 transposed reads);
-//                       this wave's two DMA pieces of tile t + 3; counted vmcnt
-//     M(t)  "matrix":   P V(t) (32 MFMA) then K Q^T(t + 1) (32 MFMA; its K fragments are requested at the head of the phase and land under P V)
-//
-// so each SIMD's matrix pipe always has one wave feeding it 64 back-to-back MFMAs while the partner does the VALU / LDS / DMA work - the
-// K Q^T(t+1) || softmax(t) overlap VERDICT r04 item 2 asks for, obtained by wave-pair role alternation instead of a hand-interleaved stream
-// (round 1's barrier-alternated attempt predates the row sums on the matrix pipe and the 64-query wave: then the softmax phase was the LONGER
-// one, 600 VALU issue clocks against 512 MFMA clocks; now it is 640 + 128 against 1024 + 128).
-// The 8 waves share ONE K / V stream: 16 KiB per tile for 512 queries instead of 256 (half the L2 -> LDS bytes and DMA instructions per FLOP), a
-// four-stage ring (tile t is read from M(t-1) of group 0 to E(t) of group 1 = 3 phases; refilled one barrier later with tile t + 4's slot
-// mate t + 3 ... wait-free: a piece has >= 4 phases to land).
-// Per-query arithmetic is EXACTLY attn_pp16mq's (same MFMA operands in the same order, same guard, same exact path for the first / last /
-// tripped tile), so the results are bit-identical to it (tools/kbench attn: "vs mq<2>: 0 values differ"; tests/test_hip_kernels.py).
-// Queries beyond the last full 512-block: <= 256 left -> attn_pp16mq_kernel on them (second launch, q_start); more -> one partially filled
-// workgroup here (waves without queries keep the DMA ring and the barriers going).
-// ------------------------------------------------------------------------------------------------------------------------
-template <int PRIO>
-__global__ __launch_bounds__(512, 2) void attn_pp16x_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
-                                                           f16* __restrict__ out, int Ntok, int nh, int xcd_remap) {
-    constexpr int QB = 4, NW = 8, NPW = 2, NST = 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // NST * AP_STAGE (K / V ring) + 8 * 8 KiB (Q fragments)
-    int bh = blockIdx.y, qblk = blockIdx.x;
-    if (((gridDim.y & 7) == 0) && (xcd_remap & 1)) {                 // a head's query blocks on ONE XCD (see attn_pp16mq_kernel)
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const int x = lin & 7, s = lin >> 3;
-        const int hs = s / (int)gridDim.x;
-        bh = x + 8 * hs;
-        qblk = s - hs * (int)gridDim.x;
-    }
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const int b = bh / nh, head = bh - b * nh;
-    const int q0 = qblk * (NW * 16 * QB) + wave * (16 * QB);
-    const int ntiles = (Ntok + 63) >> 6;
-
-    const char* kbase = reinterpret_cast<const char*>(k + (size_t)bh * Ntok * 64);
-    const char* vbase = reinterpret_cast<const char*>(v + (size_t)bh * Ntok * 64);
-    // This wave's K piece (rows 8 * wave ...) and V piece of tile t.  The per-lane source offsets are RECOMPUTED at every issue from an opaque copy
-    // of the lane id (a dozen VALU in the softmax phase, which has issue slots to spare): held in registers across the tile loop they are the
-    // first thing the allocator spills, and a scratch reload carries a compiler-inserted s_waitcnt vmcnt(0) - the whole DMA ring drained per tile.
-    auto issue = [&](int t) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int row = wave * 8 + (ln >> 3), pch = ln & 7;
-        const int ksw = ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
-        const int vsw = (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
-        const int over = t * 64 + row - (Ntok - 1);                  // > 0 only in the last tile: rows past N - 1 re-read row N - 1 (masked in exact_sm)
-        const unsigned back = over > 0 ? (unsigned)over * 128u : 0u;
-        const unsigned koff = (unsigned)(row * 128 + ((pch ^ ksw) << 4)) - back, voff = (unsigned)(row * 128 + ((pch ^ vsw) << 4)) - back;
-        char* st = smem + (t & (NST - 1)) * AP_STAGE;
-        const char* kt = uniform_ptr(kbase + (size_t)t * 8192);
-        const char* vt = uniform_ptr(vbase + (size_t)t * 8192);
-        __builtin_amdgcn_global_load_lds(AP_GPTR(kt + koff), AP_LPTR(st + wave * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(AP_GPTR(vt + voff), AP_LPTR(st + (wave + 8) * 1024), 16, 0, 0);
-    };
-    auto phase_barrier = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // end of an E phase: everything but the pieces just requested (tile t + 3) has landed, i.e. tile t + 2 (first read two phases from now)
-    auto dma_wait = [&](int t) {
-        if (t + 3 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-
-    issue(0);
-    if (ntiles > 1) issue(1);
-    if (ntiles > 2) issue(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    phase_barrier();
-
-    if (__builtin_amdgcn_readfirstlane(q0) >= Ntok) {
-        // a wave without queries (the partially filled last workgroup of a head): its share of the DMA ring and the barrier sequence, nothing else
-        if (grp == 1) phase_barrier();
-        for (int t = 0; t < ntiles; t++) {
-            if (t + 3 < ntiles) issue(t + 3);
-            dma_wait(t);
-            phase_barrier();
-            phase_barrier();
-        }
-        if (grp == 0) phase_barrier();
-        return;
-    }
-
-    // Q fragments (B operand of S^T: lane = query, d = 32 * ks + 8 * g4 ...): 32 registers that only K Q^T reads.  They live in a wave-private 8 KiB
-    // of LDS behind the ring (lane-linear 16-byte slots: conflict-free) and are re-read at the head of every K Q^T - held in registers across the
-    // softmax phase they are what the allocator spills, and a scratch reload waits vmcnt(0) = for the whole DMA ring.
-    char* qlds = smem + NST * AP_STAGE + wave * 8192 + lane * 16;
-    {
-#pragma unroll
-        for (int qb = 0; qb < QB; qb++) {
-            const int qrow = q0 + qb * 16 + l15;
-            const f16* qp = q + ((size_t)bh * Ntok + (qrow < Ntok ? qrow : Ntok - 1)) * 64;
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) *reinterpret_cast<u32x4*>(qlds + (qb * 2 + ks) * 1024) = *reinterpret_cast<const u32x4*>(qp + 32 * ks + 8 * g4);
-        }
-    }
-    auto read_q1 = [&](int qb, u32x4 (&qf)[2]) {                     // the two K-steps of one query block
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const char* qa = smem + NST * AP_STAGE + wave * 8192 + ln * 16;
-        qf[0] = *reinterpret_cast<const u32x4*>(qa + (qb * 2) * 1024);
-        qf[1] = *reinterpret_cast<const u32x4*>(qa + (qb * 2 + 1) * 1024);
-    };
-    // LDS read addresses (bytes inside a stage): ONE base per operand; K-step 1 = base ^ 64 (chunk bit 2), d block db = base ^ (db << 5) (chunk bits 1-2)
-    const int kswl = ((l15 >> 1) & 1) | ((l15 >> 2) << 1);
-    const int kaddr0 = (8 * (l15 >> 2) + (l15 & 3)) * 128 + ((g4 ^ kswl) << 4);
-    const int vswl = (((l15 >> 3) & 1) << 1) | ((g4 & 1) << 2);
-    const int vaddr0 = 8192 + (8 * g4 + (l15 >> 2)) * 128 + ((vswl | ((l15 & 3) >> 1)) << 4) + (l15 & 1) * 8;
-
-    f32x4 o[4][QB];
-    f32x4 negs[QB];
-    float l_run[QB];                             // (the running max lives in negs = -m; before tile 0 it is "none": the first tile's alpha is forced to 0)
-#pragma unroll
-    for (int qb = 0; qb < QB; qb++) {
-#pragma unroll
-        for (int db = 0; db < 4; db++) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        negs[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        l_run[qb] = 0.f;
-    }
-    f32x4 sc[4][QB];
-    u32x4 pf[QB][2];                             // [query block][32-key step]: the tile's P^T operands
-    f32x4 lt[QB];                                // this tile's row sums (every register / lane of a query holds the same number)
-    u32x4 vf[8];                                 // V^T operands of the tile: [32-key step][16-row block of d]
-    u32x4 ones;
-#pragma unroll
-    for (int i = 0; i < 4; i++) ones[i] = 0x3c003c00u;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    // (all LDS addresses are formed as smem + integer offset: a pointer that went through an integer XOR loses its address space and the
-    //  access becomes a flat load with a null check per lane)
-    auto read_k2 = [&](int t, int kb0, u32x4 (&kf)[4][2]) {          // K fragments of key blocks kb0, kb0 + 1 of tile t
-        int ka = kaddr0;
-        asm volatile("" : "+v"(ka));                                  // (opaque per use: keeps the derived addresses out of long-lived registers)
-        const int so = (t & (NST - 1)) * AP_STAGE;
-#pragma unroll
-        for (int kb = kb0; kb < kb0 + 2; kb++) {
-            const int off = ka + (32 * (kb >> 1) + 4 * (kb & 1)) * 128;
-            kf[kb][0] = *reinterpret_cast<const u32x4*>(smem + so + off);
-            kf[kb][1] = *reinterpret_cast<const u32x4*>(smem + so + (off ^ 64));
-        }
-    };
-    // V^T(t) operands: 16 ds_read_b64_tr_b16 as INLINE ASM.  Through the builtin the compiler puts s_waitcnt vmcnt(0) in front of the first of them
-    // (its memory operand carries no pointer, so it "may alias" every LDS-DMA in flight): the two pieces of tile t + 3 requested at the head of this
-    // phase would be waited for right here.  In asm the reads are invisible to its counters; their completion is the explicit lgkmcnt(0) of
-    // e_tail, in front of the hand-over barrier and a sched_barrier - no consumer can be scheduled above it (cdna guide 5.7 item 1 form iii).
-    auto read_v = [&](int t) {
-        int va = vaddr0;
-        asm volatile("" : "+v"(va));
-        const unsigned so = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem) + (unsigned)((t & (NST - 1)) * AP_STAGE);
-#pragma unroll
-        for (int db = 0; db < 4; db++) {
-            const unsigned ad = so + (unsigned)(va ^ (db << 5));
-            u32x2 a0, a1, b0, b1;
-            asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\tds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
-                         : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(ad));
-            vf[db] = u32x4{a0[0], a0[1], a1[0], a1[1]};              // keys 32 * 0 + 8 * g4 + 0..3 | + 4..7  (tr_pair's order)
-            vf[4 + db] = u32x4{b0[0], b0[1], b1[0], b1[1]};          // the second 32-key step
-        }
-    };
-    // K Q^T of the tile whose K fragments are in kf, one QUERY block at a time: its Q fragments (8 registers) arrive from LDS one block ahead
-    // (q0f = block 0's, requested by the caller).  The chain of every (kb, qb) tile is K-step 0 (C = -m) then K-step 1, as in attn_pp16mq.
-    auto qk_all = [&](const u32x4 (&kf)[4][2], u32x4 (&q0f)[2]) {
-        u32x4 q1f[2];
-#pragma unroll
-        for (int qb = 0; qb < QB; qb++) {
-            u32x4 (&cur)[2] = (qb & 1) ? q1f : q0f;
-            u32x4 (&nxt)[2] = (qb & 1) ? q0f : q1f;
-            if (qb + 1 < QB) { read_q1(qb + 1, nxt); __builtin_amdgcn_sched_barrier(0); }      // requested IN FRONT of this block's 8 MFMAs (128 clocks of cover)
-#pragma unroll
-            for (int kb = 0; kb < 4; kb++)
-                sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[kb][0]), __builtin_bit_cast(f16x8, cur[0]), negs[qb], 0, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < 4; kb++) mma16<f16>(sc[kb][qb], kf[kb][1], cur[1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto pack = [&](int qb) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-            f16x8 hp;
-#pragma unroll
-            for (int r = 0; r < 4; r++) { hp[r] = (f16)sc[2 * s2][qb][r]; hp[4 + r] = (f16)sc[2 * s2 + 1][qb][r]; }
-            pf[qb][s2] = __builtin_bit_cast(u32x4, hp);
-        }
-    };
-    // exact softmax of tile t for one query block (the first / last tile, a tripped guard): raise m to the true running max, rescale O and l,
-    // P = exp2(s - m) -> pf, l += row sum.  `fresh`: sc already holds the raw scores (tile 0, computed against negs = 0); otherwise K Q^T is
-    // redone from LDS with C = 0 (attn_pp16mq's exact_block, minus its P V - that runs in the M phase like every other tile's).
-    auto exact_sm = [&](int t, bool last, int qb, bool fresh) {
-        if (!fresh) {
-            int ka = kaddr0, ln = lane;
-            asm volatile("" : "+v"(ka), "+v"(ln));
-            const int so = (t & (NST - 1)) * AP_STAGE;
-            const char* qa = smem + NST * AP_STAGE + wave * 8192 + ln * 16;
-            const u32x4 q0f = *reinterpret_cast<const u32x4*>(qa + (qb * 2) * 1024), q1f = *reinterpret_cast<const u32x4*>(qa + (qb * 2 + 1) * 1024);
-#pragma unroll
-            for (int kb = 0; kb < 4; kb++) {
-                const int off = ka + (32 * (kb >> 1) + 4 * (kb & 1)) * 128;
-                const u32x4 kf0 = *reinterpret_cast<const u32x4*>(smem + so + off), kf1 = *reinterpret_cast<const u32x4*>(smem + so + (off ^ 64));
-                sc[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                mma16<f16>(sc[kb][qb], kf0, q0f);
-                mma16<f16>(sc[kb][qb], kf1, q1f);
-            }
-        }
-        if (last) {
-#pragma unroll
-            for (int kb = 0; kb < 4; kb++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int key = t * 64 + 32 * (kb >> 1) + 8 * g4 + 4 * (kb & 1) + r;
-                    if (key >= Ntok) sc[kb][qb][r] = -1e30f;
-                }
-        }
-        float mx = sc[0][qb][0];
-#pragma unroll
-        for (int kb = 0; kb < 4; kb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) mx = fmaxf(mx, sc[kb][qb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_old = fresh ? -1e30f : -negs[qb][0];           // (fresh = tile 0: no running max yet; -(-m) is exact)
-        const float m_new = fmaxf(m_old, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_old - m_new);
-        l_run[qb] *= alpha;
-#pragma unroll
-        for (int db = 0; db < 4; db++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) o[db][qb][r] *= alpha;
-#pragma unroll
-        for (int r = 0; r < 4; r++) negs[qb][r] = -m_new;
-        float ps = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; kb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                sc[kb][qb][r] = __builtin_amdgcn_exp2f(sc[kb][qb][r] - m_new);
-                ps += sc[kb][qb][r];
-            }
-        ps += __shfl_xor(ps, 16);
-        ps += __shfl_xor(ps, 32);
-        pack(qb);
-        l_run[qb] += ps;
-    };
-    // M(t): P V(t), then K Q^T(t + 1) unless that tile is the last one (its exact softmax recomputes the scores with C = 0)
-    auto m_phase = [&](int t) {
-        const bool do_qk = t + 1 < ntiles - 1;
-        u32x4 kf[4][2], q0f[2];
-        // K(t+1) fragments in two halves: key blocks 0-1 now (they land under the first 16 P V MFMAs), 2-3 once the first four V^T operands are
-        // dead - the fragments of the tile never coexist with all of V^T(t), and K Q^T consumes them key block by key block
-        if (do_qk) read_k2(t + 1, 0, kf);
-        __builtin_amdgcn_sched_barrier(0);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int gi = 0; gi < 4; gi++)
-#pragma unroll
-            for (int qb = 0; qb < QB; qb++) mma16<f16>(o[gi & 3][qb], vf[gi], pf[qb][gi >> 2]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (do_qk) { read_k2(t + 1, 2, kf); read_q1(0, q0f); }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int gi = 4; gi < 8; gi++)
-#pragma unroll
-            for (int qb = 0; qb < QB; qb++) mma16<f16>(o[gi & 3][qb], vf[gi], pf[qb][gi >> 2]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (do_qk) qk_all(kf, q0f);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-    };
-    // the tail of every E phase: V^T(t) operands requested, DMA completion, hand-over
-    auto e_tail = [&](int t) {
-        __builtin_amdgcn_sched_barrier(0);           // the V^T operands (32 registers) are requested once the scores of the tile are dead, not before
-        read_v(t);
-        dma_wait(t);
-        // every LDS read this wave has issued is complete before the hand-over: the partner group requests tile t + 4 into the slot of tile t
-        // right behind a later barrier, and nothing but a completed read orders a ds_read against an LDS-DMA write (the V^T operands just
-        // requested are waited for here instead of at their first use in M(t): the E phase is the shorter one)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        phase_barrier();
-    };
-
-    // ---- prologue: K Q^T(0) against negs = 0 (= the raw scores), both groups at once; then group 1 falls one phase behind
-    {
-        u32x4 kf[4][2], q0f[2];
-        read_k2(0, 0, kf);
-        read_k2(0, 2, kf);
-        read_q1(0, q0f);
-        qk_all(kf, q0f);
-    }
-    if (grp == 1) phase_barrier();
-    // ---- tile 0: exact
-    if (3 < ntiles) issue(3);
-#pragma unroll
-    for (int qb = 0; qb < QB; qb++) exact_sm(0, ntiles == 1, qb, true);
-    e_tail(0);
-    m_phase(0);
-    phase_barrier();
-    int t = 1;
-    for (;;) {
-        bool hit = false;
-        for (; t < ntiles - 1; t++) {                // ---- hot loop: E(t) fast path, M(t) ----
-            if (t + 3 < ntiles) issue(t + 3);
-#pragma unroll
-            for (int qb = 0; qb < QB; qb++) {
-#pragma unroll
-                for (int kb = 0; kb < 4; kb++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) sc[kb][qb][r] = __builtin_amdgcn_exp2f(sc[kb][qb][r]);
-                pack(qb);
-                lt[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ones), __builtin_bit_cast(f16x8, pf[qb][0]), zero4, 0, 0, 0);
-                mma16<f16>(lt[qb], ones, pf[qb][1]);
-                // one query block at a time: 16 independent exponentials cover each other's latency, and the block's 16 score registers are
-                // dead before the next block's converts need theirs (left alone the scheduler interleaves all four blocks and the allocator spills)
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            bool trig = false;
-#pragma unroll
-            for (int qb = 0; qb < QB; qb++) trig |= !(lt[qb][0] < AP_ROWSUM_LIMIT);
-            if (__builtin_expect(__any(trig), 0)) { hit = true; break; }
-#pragma unroll
-            for (int qb = 0; qb < QB; qb++) l_run[qb] += lt[qb][0];
-            e_tail(t);
-            m_phase(t);
-            phase_barrier();
-        }
-        if (!hit) break;
-        // a guard tripped in tile t: per 16-query block, as in attn_pp16mq (a block below the limit keeps the fast path's arithmetic)
-#pragma unroll
-        for (int qb = 0; qb < QB; qb++) {
-            if (__any(!(lt[qb][0] < AP_ROWSUM_LIMIT))) exact_sm(t, false, qb, false);
-            else l_run[qb] += lt[qb][0];
-        }
-        e_tail(t);
-        m_phase(t);
-        phase_barrier();
-        t++;
-    }
-    if (ntiles > 1) {
-        // (tile ntiles - 1's DMA was requested three tiles ago; nothing left to issue)
-#pragma unroll
-        for (int qb = 0; qb < QB; qb++) exact_sm(ntiles - 1, true, qb, false);
-        e_tail(ntiles - 1);
-        m_phase(ntiles - 1);
-        phase_barrier();
-    }
-    if (grp == 0) phase_barrier();
-#pragma unroll
-    for (int qb = 0; qb < QB; qb++) {
-        const float inv = 1.f / l_run[qb];
-        const int qrow = q0 + qb * 16 + l15;
-        if (qrow < Ntok) {
-            f16* op = out + ((size_t)b * Ntok + qrow) * ((size_t)nh * 64) + head * 64;
-#pragma unroll
-            for (int db = 0; db < 4; db++)
-                store4(op + 16 * db + 4 * g4, o[db][qb][0] * inv, o[db][qb][1] * inv, o[db][qb][2] * inv, o[db][qb][3] * inv);
-        }
-    }
-}
+#ifdef MOGE_EXPERIMENTS
+#include "../../tools/experiments/attention_pp16x_exp.inc"     // attn_pp16x_kernel: the 8-wave ping-pong form (round 5; bit-identical, 13 % slower: DESIGN.md)
+#endif
 
 // (A software-pipelined variant - K Q^T of tile t issued under the softmax of tile t-1, two S buffers, four-stage ring, 2 waves per SIMD -
 // was written and measured: correct, 860 TF/s against 920 for the kernel above.  With the schedule left to the compiler the exps still
@@ -1055,6 +686,7 @@ static int launch_attn_pp16(const void* q, const void* k, const void* v, void* o
         const long wgs2 = (long)((Ntok + 127) / 128) * B * nh;
         const bool q4 = akern == 2 || akern == 4 || (akern == 3 && wgs2 > moge_tune_get("ATTN_Q2_MAX_WGS", 3 * pp_device_cus()));
         const int xr = (moge_tune_get("ATTN_XCD", 1) ? 1 : 0) | (moge_tune_get("ATTN_TAIL2", 1) ? 2 : 0);
+#ifdef MOGE_EXPERIMENTS
         // attn_pp16x_kernel (ping-pong wave groups, 512 queries per workgroup, ONE workgroup per CU): bit-identical to the two above; taken while
         // its grid still fills the chip at least ATTN_X_MIN_ROUNDS (default 2) times.  ATTN_KERN 4 forces it, ATTN_X = 0 switches it off.
         const int nfull = Ntok / 512, rem = Ntok - nfull * 512;
@@ -1063,7 +695,20 @@ static int launch_attn_pp16(const void* q, const void* k, const void* v, void* o
                                                     (long)nblk * B * nh >= (long)moge_tune_get("ATTN_X_MIN_ROUNDS", 2) * pp_device_cus()));
         if (xk) {
             constexpr int smem_x = 4 * AP_STAGE + 8 * 8192;
-            if (moge_tune_get("ATTN_X_PRIO", 0)) {
+            if (moge_tune_get("ATTN_X_TS", 0)) {                // tools only: segment timeline of one workgroup (see the kernel)
+                static unsigned long long* dts = nullptr;
+                if (!dts && hipMalloc(&dts, 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+                (void)hipMemsetAsync(dts, 0, 16 * sizeof(unsigned long long), st);
+                if (int rc = set_dyn_lds<attn_pp16x_kernel<0, 1>>(smem_x)) return rc;
+                hipLaunchKernelGGL((attn_pp16x_kernel<0, 1>), dim3(nblk, B * nh), dim3(512), smem_x, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr, dts);
+                unsigned long long h[16];
+                (void)hipMemcpyAsync(h, dts, sizeof(h), hipMemcpyDeviceToHost, st);
+                (void)hipStreamSynchronize(st);
+                for (int g2 = 0; g2 < 2; g2++)
+                    if (h[g2 * 8 + 4])
+                        fprintf(stderr, "[attn_pp16x ts] group %d: %llu hot tiles; per tile (s_memtime ticks): E body %.0f, barrier wait %.0f, M body %.0f, barrier wait %.0f\n", g2, h[g2 * 8 + 4],
+                                (double)h[g2 * 8 + 0] / h[g2 * 8 + 4], (double)h[g2 * 8 + 1] / h[g2 * 8 + 4], (double)h[g2 * 8 + 2] / h[g2 * 8 + 4], (double)h[g2 * 8 + 3] / h[g2 * 8 + 4]);
+            } else if (moge_tune_get("ATTN_X_PRIO", 0)) {
                 if (int rc = set_dyn_lds<attn_pp16x_kernel<1>>(smem_x)) return rc;
                 hipLaunchKernelGGL(attn_pp16x_kernel<1>, dim3(nblk, B * nh), dim3(512), smem_x, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr);
             } else {
@@ -1077,6 +722,7 @@ static int launch_attn_pp16(const void* q, const void* k, const void* v, void* o
             }
             return (int)hipGetLastError();
         }
+#endif
         if (q4) {
             if (int rc = set_dyn_lds<attn_pp16mq_kernel<4>>(smem)) return rc;
             hipLaunchKernelGGL(attn_pp16mq_kernel<4>, dim3((Ntok + 255) / 256, B * nh), dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr, 0);

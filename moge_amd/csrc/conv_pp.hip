@@ -24,6 +24,9 @@
 #include "common.h"
 
 #define CP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+// per-lane 32-bit DMA source offset made opaque at the point of use: keeps  uniform base + zext(offset)  inside the loop, which selects the SADDR form of
+// global_load_lds (no 64-bit VALU add per piece; see pp_opaque in gemm_pp.hip)
+__device__ __forceinline__ unsigned cp_opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 #define CP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 namespace {
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
         for (int i = 0; i < HPW; i++) {
             int piece = wave + 8 * i;
             piece = piece < HALO_PIECES ? piece : HALO_PIECES - 1;
-            __builtin_amdgcn_global_load_lds(CP_GPTR(src + hoff[i]), CP_LPTR(dst + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(CP_GPTR(src + cp_opaque(hoff[i])), CP_LPTR(dst + piece * 1024), 16, 0, 0);
         }
     };
     auto issue_w = [&](int kt) {                 // K-step kt = chunk * 9 + tap  ->  weight columns (tap * C + chunk * 64); side steps follow
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
 #pragma unroll
         for (int i = 0; i < NWP; i++) {
             const unsigned off = (unsigned)(wrow[i] * rowb) + wsw[i];
-            __builtin_amdgcn_global_load_lds(CP_GPTR(src + off), CP_LPTR(dst + (wave + 8 * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(CP_GPTR(src + cp_opaque(off)), CP_LPTR(dst + (wave + 8 * i) * 1024), 16, 0, 0);
         }
     };
 

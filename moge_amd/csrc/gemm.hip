@@ -425,31 +425,43 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
     const int r0 = tid >> 3;
     const int csrc = (tid & 7) ^ ((r0 >> 1) & 7);       // logical chunk this lane fetches (same for every pass: RSTEP % 16 == 0)
 
-    const T* a_src[A_IT];
-    const T* w_src[W_IT];
+    // DMA sources as  tile base (wave-uniform, SGPR pair) + per-lane 32-bit byte offset  (< BM x lda x 4 bytes): with the offset made opaque at the
+    // point of use the compiler selects  global_load_lds_dwordx4 vOff, s[base:base+1]  - no per-lane 64-bit pointers (2 VGPRs + one 64-bit VALU add
+    // per piece and K-step) in the ring loop of the latency-regime kernels.
+    unsigned a_off[A_IT], w_off[W_IT];
+    const char* a_tile = reinterpret_cast<const char*>(reinterpret_cast<const T*>(g.a) + (size_t)m0 * g.lda);
+    const char* w_tile = reinterpret_cast<const char*>(reinterpret_cast<const T*>(g.w) + (size_t)n0 * g.ldw);
 #pragma unroll
     for (int i = 0; i < A_IT; i++) {
         int m = m0 + r0 + i * RSTEP;
         m = m < g.M ? m : g.M - 1;
-        a_src[i] = reinterpret_cast<const T*>(g.a) + (size_t)m * g.lda + csrc * CH;
+        a_off[i] = (unsigned)(((m - m0) * g.lda + csrc * CH) * (int)sizeof(T));
     }
 #pragma unroll
     for (int i = 0; i < W_IT; i++) {
         int n = n0 + r0 + i * RSTEP;
         n = n < g.N ? n : g.N - 1;
-        w_src[i] = reinterpret_cast<const T*>(g.w) + (size_t)n * g.ldw + csrc * CH;
+        w_off[i] = (unsigned)(((n - n0) * g.ldw + csrc * CH) * (int)sizeof(T));
     }
     const int wrow = wave * 8;                           // first tile row this wave fills in each pass
 
     auto issue = [&](int kt, int buf) {
         char* dA = sA + buf * BM * 128 + wrow * 128;
         char* dW = sW + buf * BN * 128 + wrow * 128;
+        const char* ak = uniform_ptr(a_tile + (size_t)kt * 8 * CH * sizeof(T));
+        const char* wk = uniform_ptr(w_tile + (size_t)kt * 8 * CH * sizeof(T));
 #pragma unroll
-        for (int i = 0; i < A_IT; i++)
-            __builtin_amdgcn_global_load_lds(GLDS_GPTR(a_src[i] + (size_t)kt * 8 * CH), GLDS_LPTR(dA + i * RSTEP * 128), 16, 0, 0);
+        for (int i = 0; i < A_IT; i++) {
+            unsigned o = a_off[i];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds(GLDS_GPTR(ak + o), GLDS_LPTR(dA + i * RSTEP * 128), 16, 0, 0);
+        }
 #pragma unroll
-        for (int i = 0; i < W_IT; i++)
-            __builtin_amdgcn_global_load_lds(GLDS_GPTR(w_src[i] + (size_t)kt * 8 * CH), GLDS_LPTR(dW + i * RSTEP * 128), 16, 0, 0);
+        for (int i = 0; i < W_IT; i++) {
+            unsigned o = w_off[i];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds(GLDS_GPTR(wk + o), GLDS_LPTR(dW + i * RSTEP * 128), 16, 0, 0);
+        }
     };
 
     // fp16: v_mfma_f32_16x16x32_f16 (the same instruction and K grouping as gemm_pp128m16: a GEMM's result does not depend on which of the

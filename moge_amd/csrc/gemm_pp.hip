@@ -25,6 +25,10 @@
 #include <type_traits>
 
 #define PP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+// A per-lane 32-bit DMA source offset, made opaque AT THE POINT OF USE: the add  uniform base + zext(offset)  then stays inside the loop and selects the
+// SADDR form  global_load_lds_dwordx4 vOff, s[base:base+1]  (no VALU).  Left to itself the compiler hoists the zero-extension out of the K loop, keeps
+// every offset as a 64-bit VGPR pair and pays one v_lshl_add_u64 per piece and tile in the read segments (round 5: 8 VALU + 8 VGPRs per wave and K-tile).
+__device__ __forceinline__ unsigned pp_opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 #define PP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 // ---- shared epilogue: this wave's (TM*32) x 64 accumulator tile -> global memory ---------------------------------
@@ -447,14 +451,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128m16_kernel(const GemmArgs g)
         char* base = smem + 98304 + (t & 1) * 32768;
         const char* gw = uniform_ptr(baseW + (size_t)t * 128);
 #pragma unroll
-        for (int kw = 0; kw < 4; kw++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[kw]), PP_LPTR(base + (wave + 8 * kw) * 1024), 16, 0, 0);
+        for (int kw = 0; kw < 4; kw++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + pp_opaque(offW[kw])), PP_LPTR(base + (wave + 8 * kw) * 1024), 16, 0, 0);
     };
     auto issue_a = [&](int t, int slot, int hi_rows) {
         char* base = smem + slot * 32768;
         const char* ga = uniform_ptr(baseA + (size_t)t * 128);
 #pragma unroll
         for (int k = 0; k < 2; k++)
-            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + offA[hi_rows * 2 + k]), PP_LPTR(base + (k * 128 + hi_rows * 64 + wave * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + pp_opaque(offA[hi_rows * 2 + k])), PP_LPTR(base + (k * 128 + hi_rows * 64 + wave * 8) * 128), 16, 0, 0);
     };
 
     const int sx = (l15 >> 1) & 7;
@@ -856,25 +860,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
         char* base = smem + 98304 + (t & 1) * 32768;
         const char* gw = uniform_ptr(baseW + (size_t)t * 128);
 #pragma unroll
-        for (int kw = 0; kw < 4; kw++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[kw]), PP_LPTR(base + (wave + 8 * kw) * 1024), 16, 0, 0);
+        for (int kw = 0; kw < 4; kw++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + pp_opaque(offW[kw])), PP_LPTR(base + (wave + 8 * kw) * 1024), 16, 0, 0);
     };
     auto issue_a = [&](int t, int slot, int hi_rows) {
         char* base = smem + slot * 32768;
         const char* ga = uniform_ptr(baseA + (size_t)t * 128);
 #pragma unroll
         for (int k = 0; k < 2; k++)
-            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + offA[hi_rows * 2 + k]), PP_LPTR(base + (k * 128 + hi_rows * 64 + wave * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(PP_GPTR(ga + pp_opaque(offA[hi_rows * 2 + k])), PP_LPTR(base + (k * 128 + hi_rows * 64 + wave * 8) * 128), 16, 0, 0);
     };
     auto issue_w2 = [&](int t, int part) {                    // half of a W K-tile: part 0 = pieces kw 0, 1 (rows 0-127), part 1 = kw 2, 3 (rows 128-255)
         char* base = smem + 98304 + (t & 1) * 32768;
         const char* gw = uniform_ptr(baseW + (size_t)t * 128);
 #pragma unroll
-        for (int kw = 2 * part; kw < 2 * part + 2; kw++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + offW[kw]), PP_LPTR(base + (wave + 8 * kw) * 1024), 16, 0, 0);
+        for (int kw = 2 * part; kw < 2 * part + 2; kw++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + pp_opaque(offW[kw])), PP_LPTR(base + (wave + 8 * kw) * 1024), 16, 0, 0);
     };
     auto issue_a1 = [&](int t, int slot, int k) {             // ONE piece of the "lo" rows: k = 0 rows 8w (wave group 0's), k = 1 rows 128 + 8w (group 1's)
         char* base = smem + slot * 32768;
         const char* ga = uniform_ptr(baseA + (size_t)t * 128);
-        __builtin_amdgcn_global_load_lds(PP_GPTR(ga + offA[k]), PP_LPTR(base + (k * 128 + wave * 8) * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(PP_GPTR(ga + pp_opaque(offA[k])), PP_LPTR(base + (k * 128 + wave * 8) * 128), 16, 0, 0);
     };
     auto prefetch = [&]() {                                   // the pieces that do not touch the staging region (A slots 1, 2)
         // straight-line (K >= 192 is a launch condition): a branch in here makes the compiler wait vmcnt(0) for the epilogue's loads behind it

@@ -411,8 +411,10 @@ static int bench_attn(const char* filter, int iters) {
         // exp: ATTN_EXP (32x32x16 kernels), var: ATTN_VAR bits of attn_pp16_kernel - both need a library built with --experiments
         struct Var { const char* name; int kind, exp, var; int kern = 0; };
         // kern 4 = attn_pp16x_kernel (ping-pong wave groups) [+ attn_pp16mq on the queries beyond the last full 512-block]; 5 = the same with s_setprio 1 in the M phase
-        std::vector<Var> vars = {{"pp16", 1, 0, 0, 0}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"x+prio", 1, 0, 0, 5}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"x+prio", 1, 0, 0, 5}};
+        std::vector<Var> vars = {{"pp16", 1, 0, 0, 0}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}};
+#ifdef MOGE_EXPERIMENTS
         if (getenv("KB_X")) vars = {{"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"x+prio", 1, 0, 0, 5}};
+#endif
         f16* out_q2 = nullptr;                       // mq<2> result: mq<4> must reproduce it bit for bit (per-block guard decisions; spiked keys above force them)
         CK(hipMalloc(&out_q2, n * 2));
         if (getenv("KB_EXP")) vars = {{"old(vT)", 0, 0, 0}, {"x:pp32 nw4", 1, 1, 0}, {"pp16", 1, 0, 0}, {"x:noexp", 1, 0, 1}, {"x:noguard", 1, 0, 2}, {"x:ks-outer", 1, 0, 4},
