@@ -6,7 +6,8 @@ equirectangular image is split into 12 views, the views go through `MoGeModel.in
 GPU, the distance maps are merged on the host (moge_amd/panorama.py).  Differences, all forced by what this image ships: decode / resize use
 PIL (BOX filter for `--resize`), EXR / GLB / PLY are written by moge_amd.io, `--show` is not provided, and the mesh mask is
 `mask & ~depth_map_edge(distance, rtol=threshold)` - the reference additionally requires a normal-map edge (utils3d.np.normal_map_edge, not
-restated here), so this removes a superset of the reference's edge pixels."""
+restated here), so this removes a superset of the reference's edge pixels.  Mirrored quirks of the reference script: `--resolution_level` is accepted
+but not passed to `infer()` (infer_panorama.py:101), and the GLB gets the mesh builder's uvs unflipped (:147; `scripts/infer.py:148` is the one that flips v)."""
 from __future__ import annotations
 
 import itertools
@@ -24,7 +25,7 @@ import numpy as np
 @click.option("--device", "device_name", type=str, default="cuda", help='Device, default "cuda".')
 @click.option("--fp16", "use_fp16", is_flag=True, help="fp16 inference (model.half()).")
 @click.option("--resize", "resize_to", type=int, default=None, help="Resize the long side to this size first.")
-@click.option("--resolution_level", type=int, default=9, help="0-9, passed to infer().")
+@click.option("--resolution_level", type=int, default=9, help="0-9; accepted and unused, as in the reference script (its infer() call does not pass it).")
 @click.option("--threshold", type=float, default=0.03, help="Relative depth-edge threshold of the mesh mask, default 0.03.")
 @click.option("--batch_size", type=int, default=4, help="Views per infer() call, default 4.")
 @click.option("--splitted", "save_splitted", is_flag=True, help="Also save the 12 views and their distance visualisations.")
@@ -62,7 +63,9 @@ def main(input_path, output_path, pretrained_model_name_or_path, model_version, 
             im = im.resize((w2, h2), Image.BOX)
         image = np.asarray(im, dtype=np.uint8)
         H, W = image.shape[:2]
-        out = infer_panorama(model, image, resolution=512, batch_size=batch_size, merge_size=(1920, 960), resolution_level=resolution_level)
+        # (`--resolution_level` is accepted and NOT forwarded: the reference calls `model.infer(image_tensor, fov_x=fov_x, apply_mask=False)` with the
+        #  model's default, moge/scripts/infer_panorama.py:101)
+        out = infer_panorama(model, image, resolution=512, batch_size=batch_size, merge_size=(1920, 960))
         depth, mask, points = out["distance"], out["mask"], out["points"]
         save_path = Path(output_path, p.relative_to(root).parent, p.stem)
         save_path.mkdir(exist_ok=True, parents=True)
@@ -82,7 +85,7 @@ def main(input_path, output_path, pretrained_model_name_or_path, model_version, 
             cleaned = model.depth_edge_mask(torch.from_numpy(depth)[None], torch.from_numpy(mask)[None], rtol=threshold).cpu().numpy()[0]
             faces, vertices, vertex_colors, vertex_uvs = build_mesh_from_map(points, image.astype(np.float32) / 255, uv_map(H, W), mask=cleaned, tri=True)
             if save_glb_:
-                save_glb(save_path / "mesh.glb", vertices, faces, vertex_uvs * [1, -1] + [0, 1], image)
+                save_glb(save_path / "mesh.glb", vertices, faces, vertex_uvs, image)      # uvs as built, like infer_panorama.py:147 (it is scripts/infer.py:148 that flips v)
             if save_ply_:
                 save_ply(save_path / "mesh.ply", vertices, faces, vertex_colors)
 
