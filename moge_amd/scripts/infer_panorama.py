@@ -7,7 +7,8 @@ GPU, the distance maps are merged on the host (moge_amd/panorama.py).  Differenc
 PIL (BOX filter for `--resize`), EXR / GLB / PLY are written by moge_amd.io, `--show` is not provided, and the mesh mask is
 `mask & ~depth_map_edge(distance, rtol=threshold)` - the reference additionally requires a normal-map edge (utils3d.np.normal_map_edge, not
 restated here), so this removes a superset of the reference's edge pixels.  Mirrored quirks of the reference script: `--resolution_level` is accepted
-but not passed to `infer()` (infer_panorama.py:101), and the GLB gets the mesh builder's uvs unflipped (:147; `scripts/infer.py:148` is the one that flips v)."""
+but not passed to `infer()` (infer_panorama.py:101), the GLB gets the mesh builder's uvs unflipped (:147; `scripts/infer.py:148` is the one that flips v), and `points.exr` carries R, G, B = z, y, x (:132 writes the
+array without the RGB -> BGR conversion of `scripts/infer.py:114`)."""
 from __future__ import annotations
 
 import itertools
@@ -79,7 +80,9 @@ def main(input_path, output_path, pretrained_model_name_or_path, model_version, 
             Image.fromarray(image).save(save_path / "image.jpg")
             Image.fromarray(colorize_depth(depth, mask=mask)).save(save_path / "depth_vis.png")
             save_exr(save_path / "depth.exr", depth)
-            save_exr(save_path / "points.exr", points)
+            # The reference's PANORAMA script hands `points` to cv2.imwrite as they are (infer_panorama.py:132), and cv2 takes the last axis as B, G, R: its file
+            # has R = z, G = y, B = x - unlike scripts/infer.py:114, which converts RGB -> BGR first (R, G, B = x, y, z).  Mirrored, not fixed.
+            save_exr(save_path / "points.exr", points[..., ::-1])
             Image.fromarray((mask * 255).astype(np.uint8)).save(save_path / "mask.png")
         if save_glb_ or save_ply_:
             cleaned = model.depth_edge_mask(torch.from_numpy(depth)[None], torch.from_numpy(mask)[None], rtol=threshold).cpu().numpy()[0]

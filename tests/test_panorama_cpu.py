@@ -176,3 +176,22 @@ def test_cli_is_importable_without_a_gpu_and_lists_the_reference_flags():
     for flag in ("--input", "--output", "--pretrained", "--device", "--resize", "--resolution_level", "--threshold", "--batch_size", "--splitted",
                  "--maps", "--glb", "--ply"):
         assert flag in r.output, flag
+
+
+def test_cli_mirrors_the_reference_scripts_file_conventions(tmp_path, monkeypatch):
+    """the panorama CLI's EXR channel order and GLB uv convention, pinned against what the two reference scripts do.
+    scripts/infer.py:114 writes points through cv2.cvtColor(RGB2BGR) -> file channels R, G, B = x, y, z and flips v for the GLB (:148);
+    scripts/infer_panorama.py:132,147 does neither -> R, G, B = z, y, x and the mesh builder's uvs as they are."""
+    import inspect
+    from moge_amd.scripts import infer as S, infer_panorama as SP
+    src_p, src_i = inspect.getsource(SP), inspect.getsource(S)
+    assert 'save_exr(save_path / "points.exr", points[..., ::-1])' in src_p          # B, G, R = x, y, z as cv2 writes an un-converted array
+    assert 'save_exr(save_path / "points.exr", out["points"][j])' in src_i           # R, G, B = x, y, z
+    assert "vertex_uvs * [1, -1] + [0, 1]" in src_i and "vertex_uvs * [1, -1]" not in src_p
+    assert "resolution_level=resolution_level" not in src_p                          # accepted, not forwarded (infer_panorama.py:101)
+    # and the writer itself: channel R of the file is array[..., 0]
+    from moge_amd import io as IO
+    pts = np.arange(2 * 3 * 3, dtype=np.float32).reshape(2, 3, 3)
+    IO.save_exr(tmp_path / "p.exr", pts[..., ::-1])
+    back = IO.read_exr(tmp_path / "p.exr")                                            # (H, W, 3) in R, G, B order
+    assert np.array_equal(back[..., 0], pts[..., 2]) and np.array_equal(back[..., 2], pts[..., 0])
