@@ -447,6 +447,56 @@ def test_odd_shapes_and_token_grids_match_the_oracle_fp32(MoGeModel, tmp_path_fa
     check_fp32(out, ref)
 
 
+def _sweep_cases():
+    """Seeded random (B, H, W, options) for the tiny model: extremes of size and aspect, every infer() option, per-image fov_x."""
+    import random
+    rng = random.Random(20260922)
+    cases = []
+    for i in range(12):
+        B = rng.choice([1, 1, 2, 3, 5])
+        H, W = rng.choice([(14, 14), (15, 400), (400, 15), (29, 31), (200, 333), (333, 200), (128, 128), (57, 601), (99, 98), (250, 250), (41, 183), (183, 41)])
+        opts = dict(apply_mask=rng.random() < 0.7, force_projection=rng.random() < 0.7)
+        if rng.random() < 0.5:
+            opts["num_tokens"] = rng.choice([16, 30, 64, 100, 150, 256, 333])
+        else:
+            opts["resolution_level"] = rng.choice([0, 3, 5, 9])
+        fov = rng.choice([None, "scalar", "tensor", "tensor"])
+        cases.append((i, B, H, W, opts, fov))
+    return cases
+
+
+@pytest.mark.parametrize("i,B,H,W,opts,fov", _sweep_cases())
+def test_random_shape_and_option_sweep_matches_the_oracle_fp32(MoGeModel, tmp_path_factory, i, B, H, W, opts, fov):
+    """A seeded sweep over what the fixtures hold fixed: batch sizes 1-5, 14-pixel to 600-pixel sides, 1:27 aspect ratios either way, `num_tokens` or
+    `resolution_level`, `apply_mask` / `force_projection` on and off, `fov_x` absent / a number / one value per image (v2.py:194-303).  fp32 mode against the
+    CPU oracle: every pixel within 1e-3, mask bit-exact (check_fp32)."""
+    from oracle import moge_oracle as O
+    model, cfg, sd = get_model(MoGeModel, "tiny-vits-normal", 0, True, tmp_path_factory)
+    g = torch.Generator().manual_seed(1000 + i)
+    x = torch.rand(B, 3, H, W, generator=g)
+    kw = dict(opts)
+    if fov == "scalar":
+        kw["fov_x"] = 55.0
+    elif fov == "tensor":
+        kw["fov_x"] = torch.tensor([40.0 + 7.0 * b for b in range(B)])
+    out = model.infer(x, use_fp16=False, **kw)
+    trace = {}
+    ref = O.infer(cfg, sd, x, trace=trace, **kw)
+    assert out["points"].shape == (B, H, W, 3) and out["mask"].shape == (B, H, W)
+    # Knife-edge pixels: the mask is `sigmoid > 0.5 and z + shift > 0` (v2.py:253,268).  Over 10^6 random pixels a few land within float rounding of a
+    # threshold (the first run of this sweep: one pixel of 171 285 with the mask logit at 0.5 +- 1e-7), where 1e-7 of forward noise - or the
+    # reference's own thread count - decides.  Those pixels, identified from the ORACLE's own margins, are exempt; there must be next to none of them.
+    prob = trace["forward"]["mask"].reshape(B, H, W)
+    z = trace["forward"]["points"].reshape(B, H, W, 3)[..., 2] + trace["shift"].reshape(B, 1, 1)
+    knife = ((prob - 0.5).abs() < 2e-6) | (z.abs() < 2e-6 * z.abs().median())
+    assert int(knife.sum()) <= 3, int(knife.sum())
+    out = {k: v.cpu().clone() for k, v in out.items()}
+    for k in ("points", "depth", "mask", "normal"):
+        if k in out:
+            out[k][knife] = ref[k][knife]
+    check_fp32(out, ref)
+
+
 @pytest.mark.parametrize("kind", ["black", "white", "flat_gray"])
 def test_fp16_mode_on_constant_images_stays_in_band(MoGeModel, tmp_path_factory, kind):
     """Degenerate inputs for the folded LayerNorm (fp16 path: row statistics from partial sums, raw residual in fp16): a constant image gives
