@@ -233,8 +233,10 @@ struct GemmArgs {
                            // channels are inputs of the ConvTranspose2d, v1.py:118-121); 0: at the output pixel, indexed by output channel (MoGe-2 resampler)
     int nt_store;          // gemm_pp: non-temporal stores for the f16 output rows (streaming activations; keeps the residual in the Infinity Cache)
     unsigned long long* dbg_ts;   // gemm_pp128: optional s_memtime stamps of one block (tools/kbench)
-    int stagger;           // gemm_pp128: number of start-phase classes (0/1 = off)
+    int stagger;           // gemm_pp128p_kernel: > 1 = the workgroups of an XCD start in that many phase groups spread over one tile time (PP_STAGGER; 0 / 1 = off)
     int dbg;               // gemm_pp ablation bits (tools/kbench only): 1 no DMA, 2 no LDS reads, 4 no MFMA, 8 no barriers
+    int stagger_clk;       // ... and over at most this many shader clocks (PP_STAGGER_CLK)
+    int abl;               // gemm_pp128p_kernel, -DMOGE_EXPERIMENTS builds only (PP_ABL, tools/energy.sh): 1 no main-loop DMA, 2 fragment reads only in K-tile 0, 4 no epilogue, 8 no MFMA
     // conv_rb.hip (fused residual block, modules.py:47-68): out = add + conv2(relu(conv1(relu(a)) + bias)) + rb_bias2; w / rb_w2 = [C][9C]
     const void* rb_w2;
     const float* rb_bias2;

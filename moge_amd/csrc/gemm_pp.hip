@@ -829,6 +829,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
     }
     if (li >= cnt) return;
     const int nkt = g.K >> 6;
+#ifdef MOGE_EXPERIMENTS
+    // energy / time attribution (tools/energy.sh with PP_ABL): pieces of the kernel switched off at run time - wrong results, same control flow
+    const int abl = g.abl;
+#else
+    constexpr int abl = 0;
+#endif
 
     const int prow = lane >> 3;
     const int lchunk = (lane & 7) ^ (((wave & 1) << 2) + (lane >> 4));
@@ -857,12 +863,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
         }
     };
     auto issue_w = [&](int t) {
+        if ((abl & 1) && t >= 2) return;
         char* base = smem + 98304 + (t & 1) * 32768;
         const char* gw = uniform_ptr(baseW + (size_t)t * 128);
 #pragma unroll
         for (int kw = 0; kw < 4; kw++) __builtin_amdgcn_global_load_lds(PP_GPTR(gw + pp_opaque(offW[kw])), PP_LPTR(base + (wave + 8 * kw) * 1024), 16, 0, 0);
     };
     auto issue_a = [&](int t, int slot, int hi_rows) {
+        if ((abl & 1) && t >= 3) return;
         char* base = smem + slot * 32768;
         const char* ga = uniform_ptr(baseA + (size_t)t * 128);
 #pragma unroll
@@ -902,6 +910,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
 #endif
     setup(li);
     prefetch();
+#ifdef MOGE_EXPERIMENTS
+    // STAGGER (round 5, tools/kbench KB_STAG / PP_STAGGER; not in the product).  All 256 workgroups of a persistent launch start together and stay in lockstep, so
+    // their epilogues arrive as ONE burst per round: 32-70 MB of stores (+ residual reads) at once = 4.5-6.7 TB/s, and the next tile's operand requests queue behind
+    // it - ablating the epilogue recovers 19-27 % of the K = 1024 launches (profiles/r05l_energy_attribution_*.log) although its arithmetic is a few k clocks.  With
+    // `stagger` = G > 1 the workgroups of an XCD start in G phase groups spread over one tile time (at most stagger_clk clocks).  Measured: qkv +2.6 %, proj +5-10 %,
+    // fc1 +1.5 %, fc2 0 in kbench, GEMM class 63.2 -> 61.9 ms in the single-stream profile - and 246 -> 244 img/s in the production two-stream step, B = 1 p50 6.1 ->
+    // 6.5 ms (profiles/r05n_*): a sleeping workgroup holds its CU, and the other stream already fills the ragged ends the stagger creates.
+    if (g.stagger > 1) {
+        const int ph = li % g.stagger;
+        int t_spread = nkt * 2900 + 9000;
+        t_spread = t_spread < g.stagger_clk ? t_spread : g.stagger_clk;
+        for (int n = ph * t_spread / g.stagger / 8128; n > 0; n--) __builtin_amdgcn_s_sleep(127);      // s_sleep 127 = 64 x 127 clocks
+    }
+#endif
     bool first = true;
     for (;;) {
         const int m0 = m0n, n0 = n0n;
@@ -1055,6 +1077,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (!(abl & 2) || t == 0) {
                 if (half == 0) {
 #pragma unroll
                     for (int j = 0; j < 4; j++)
@@ -1065,6 +1088,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
                 for (int i = 0; i < 4; i++)
 #pragma unroll
                     for (int ks = 0; ks < 2; ks++) af[i][ks] = *reinterpret_cast<const u32x4*>(sl + (a_off ^ (ks * 64)) + (half * 4 + i) * 2048);
+                }
                 if (half == 0) {
                     if constexpr (W_SPLIT) {
                         if (t >= 1 && t + 1 < nkt) issue_w2(t + 1, 1);
@@ -1115,6 +1139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
                     if (half == 1 && t + 2 < nkt) issue_w(t + 2);          // W(t)'s slot: read by both groups in their L_a(t), two barriers ago at the latest
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (!(abl & 8) || FIRST) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++)
 #pragma unroll
@@ -1124,6 +1149,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
                             if (FIRST && ks == 0) acc[half * 4 + i][j] = mma16_first<f16>(wf[j][ks], af[i][ks]);
                             else mma16<f16>(acc[half * 4 + i][j], wf[j][ks], af[i][ks]);
                         }
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("" ::: "memory");
@@ -1161,6 +1187,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
             prefetch();
             asm volatile("" ::: "memory");
         };
+        if (abl & 4) {                                       // no epilogue: the accumulators stay alive, the next tile's prefetch is still requested
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) asm volatile("" ::"v"(acc[i][j]));
+            mid();
+        } else
         pp_epi_run<EPK, SROWS>(g, acc, pre, R, lane, m0 + wm * 128, n0 + wn * 64, mid);
         PP_STAMP(4);
 #ifdef MOGE_EXPERIMENTS
@@ -1322,7 +1355,9 @@ static int launch_pp_any(const GemmArgs& g, hipStream_t st) {
 int launch_gemm_pp(const GemmArgs& g0, hipStream_t st) {
     GemmArgs g = g0;
     g.dbg = moge_tune_get("PP_DBG", 0);
-    g.stagger = 0;
+    g.abl = moge_tune_get("PP_ABL", 0);
+    g.stagger = moge_tune_get("PP_STAGGER", 0);
+    g.stagger_clk = moge_tune_get("PP_STAGGER_CLK", 56000);
     {
         const int nt = moge_tune_get("NT_STORE", 0);        // bit 0: GELU (MLP hidden), bit 1: QKV, bit 2: plain stores
         g.nt_store = (g.epi == EPI_QKV) ? (nt >> 1) & 1 : (g.act == ACT_GELU ? nt & 1 : (nt >> 2) & 1);
