@@ -139,6 +139,90 @@ def measure_sustained_mfma(seconds: float = 1.5):
         return None
 
 
+class PowerSampler:
+    """Socket power and shader clock of one GPU, sampled in a background thread during an UNTIMED pass of the same steps (never inside the timed
+    region).  amdgpu hwmon first (reading a sysfs file costs microseconds), `rocm-smi --json` as the fall-back.  Reported as `power` in the bench
+    line: avg watts, joules per image, avg shader clock - the evidence behind DESIGN.md section 7's "the chip is power-limited under this path"."""
+
+    def __init__(self, dev_index: int, period: float = 0.05):
+        import glob
+        import threading
+        self.period, self.samples, self._stop, self._thread = period, [], threading.Event(), None
+        self.power_file = self.sclk_file = None
+        self.source = self.cap_w = None
+        try:
+            prop = torch.cuda.get_device_properties(dev_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(prop, "pci_domain_id", 0), prop.pci_bus_id, prop.pci_device_id)
+            base = "/sys/bus/pci/devices/" + bdf
+            cands = glob.glob(base + "/hwmon/hwmon*/power1_average") + glob.glob(base + "/hwmon/hwmon*/power1_input")
+            if cands:
+                self.power_file, self.source = cands[0], "amdgpu hwmon " + cands[0].split("/")[-1] + " of " + bdf
+                try:
+                    self.cap_w = int(open(os.path.join(os.path.dirname(cands[0]), "power1_cap")).read().strip()) / 1e6
+                except Exception:
+                    pass
+            if os.path.exists(base + "/pp_dpm_sclk"):
+                self.sclk_file = base + "/pp_dpm_sclk"
+        except Exception:
+            pass
+        self.dev_index = dev_index
+
+    def _read(self):
+        w = mhz = None
+        if self.power_file:
+            try:
+                w = int(open(self.power_file).read().strip()) / 1e6
+            except Exception:
+                w = None
+        if self.sclk_file:
+            try:
+                for ln in open(self.sclk_file).read().splitlines():
+                    if ln.strip().endswith("*"):
+                        mhz = float(ln.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+            except Exception:
+                mhz = None
+        if w is None:                                  # fall-back: one rocm-smi process per sample (slow: ~0.3 s each)
+            import re
+            import subprocess
+            try:
+                d = json.loads(subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout)
+                c = d[sorted(d)[min(self.dev_index, len(d) - 1)]]
+                ws = [float(v) for k, v in c.items() if re.search("power", k, re.I) and re.match(r"^[0-9.]+$", str(v))]
+                ms = [re.search(r"(\d+)Mhz", str(v)) for k, v in c.items() if re.search("sclk", k, re.I)]
+                ms = [int(m.group(1)) for m in ms if m]
+                w, mhz = (ws[0] if ws else None), (ms[0] if ms else mhz)
+                self.source = "rocm-smi --showpower --showclocks"
+            except Exception:
+                pass
+        return w, mhz
+
+    def __enter__(self):
+        import threading
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append(self._read())
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._thread.join(timeout=10)
+
+    def summary(self, images: int, seconds: float):
+        ws = [w for w, _ in self.samples if w]
+        ms = [m for _, m in self.samples if m]
+        if not ws:
+            return None
+        ws = ws[1:] if len(ws) > 3 else ws             # the first sample may predate the load
+        avg = sum(ws) / len(ws)
+        return {"avg_socket_w": round(avg, 1), "joules_per_image": round(avg * seconds / images, 3), "avg_sclk_mhz": round(sum(ms) / len(ms)) if ms else None,
+                "power_cap_w": self.cap_w, "samples": len(ws), "seconds": round(seconds, 3), "source": self.source,
+                "note": "sampled during an untimed repeat of the same steps right after the timed region (this rank's GPU)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +236,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pipeline leg and the blob load-time comparison")
     ap.add_argument("--no-profile", action="store_true", help="disable the per-kernel HIP-event profiler")
+    ap.add_argument("--no-power", action="store_true", help="skip the untimed power-sampling pass (socket watts / joules per image)")
     ap.add_argument("--no-autocast-pass", action="store_true", help="skip the extra steps in the reference's other fp16 form (fp32 weights + use_fp16); "
                                                                      "rocprofv3 passes use it so that the trace holds the headline mode's kernels only")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="run only the cpu_baseline leg (no GPU needed) and print it")
@@ -270,6 +355,21 @@ def main():
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    # power pass (rank 0, untimed): the same K steps once more with the sampler thread running
+    power = None
+    if rank == 0 and not args.no_power:
+        try:
+            with PowerSampler(dev_index) as ps:
+                tpw = time.perf_counter()
+                for _ in range(max(args.steps, 8)):
+                    step()
+                torch.cuda.synchronize(dev)
+                tpw = time.perf_counter() - tpw
+            power = ps.summary(max(args.steps, 8) * B, tpw)
+        except Exception as e:                              # noqa: BLE001  (a measurement extra must not fail the bench)
+            power = {"error": str(e)[:200]}
+    if world > 1:
+        dist.barrier()
     # per-kernel-class HIP-event profile: the SAME K steps again with events around every launch (on the launch stream).
     # The profiler serialises the two half-batch streams of the production path (a kernel's event bracket must see only that
     # kernel), so it runs right after the timed region instead of inside it; its own step time is reported alongside.
@@ -341,6 +441,8 @@ def main():
         }
         if rccl is not None:
             res["rccl"] = rccl
+        if power is not None:
+            res["power"] = power
         if prof is not None:
             gm = prof["gemm_pp"] if prof["gemm_pp"]["launches"] else prof["gemm"]
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
