@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MOGE_ABI_VERSION 3
+#define MOGE_ABI_VERSION 4
 #define MOGE_MAX_TAPS 8
 #define MOGE_LEVELS 5
 
@@ -54,12 +54,18 @@ typedef enum moge_remap { MOGE_REMAP_LINEAR = 0, MOGE_REMAP_SINH = 1, MOGE_REMAP
 
 /* ConvStack options (moge/model/modules.py:18-67, 139-181, 195-240).  Resampler of level l -> l + 1 (x2 up-samplers only: the decoder stacks): */
 typedef enum moge_resampler { MOGE_RS_CONV_TRANSPOSE = 0, MOGE_RS_BILINEAR = 1, MOGE_RS_NEAREST = 2, MOGE_RS_PIXEL_SHUFFLE = 3 } moge_resampler;
-/* in_norm / hidden_norm of the residual blocks: Identity, GroupNorm(1, C) ("layer_norm") or GroupNorm(C / 32, C) ("group_norm") */
-typedef enum moge_res_norm { MOGE_NORM_NONE = 0, MOGE_NORM_LAYER = 1, MOGE_NORM_GROUP = 2 } moge_res_norm;
+/* in_norm / hidden_norm of the residual blocks (modules.py:47-58): Identity, GroupNorm(1, C) ("layer_norm"), GroupNorm(C / 32, C) ("group_norm"),
+ * InstanceNorm2d(C) ("instance_norm": per-channel statistics, no affine parameters) */
+typedef enum moge_res_norm { MOGE_NORM_NONE = 0, MOGE_NORM_LAYER = 1, MOGE_NORM_GROUP = 2, MOGE_NORM_INSTANCE = 3 } moge_res_norm;
+/* activation of the residual blocks (modules.py:31-40): ReLU, LeakyReLU(0.2), SiLU, ELU(1) */
+typedef enum moge_activation { MOGE_ACT_RELU = 0, MOGE_ACT_LEAKY_RELU = 1, MOGE_ACT_SILU = 2, MOGE_ACT_ELU = 3 } moge_activation;
 
-/* Mirrors the checkpoint's `model_config` (moge/model/v2.py:29-56, configs/train/v2.json:238-285): 5 levels, ReLU, replicate padding,
- * hidden width = width.  The released layout - resamplers [conv_transpose x3, bilinear], res-block norms "none" - runs on the fused
- * throughput kernels; the other resamplers / norms (ABI v3) run on the generic kernels of the same library. */
+/* Mirrors the checkpoint's `model_config` (moge/model/v2.py:29-56, configs/train/v2.json:238-285): 5 levels, replicate padding.
+ * The released layout - resamplers [conv_transpose x3, bilinear], res-block norms "none", ReLU, hidden width = width - runs on the fused
+ * throughput kernels; the other resamplers / norms (ABI v3) and the other activations / instance_norm / dim_times_res_block_hidden > 1
+ * (ABI v4) run on the generic kernels of the same library.  Not representable: the x0.5 resamplers (pixel_unshuffle, avg_pool, max_pool) -
+ * MoGeModel.forward hands level l a map of 2^l x the token grid (v2.py:154-160), so ConvStack.forward's `x + feature` (modules.py:247-249)
+ * is a shape error in the reference itself for any of them. */
 typedef struct moge_config {
     int32_t embed_dim;                 /* ViT width D (384 / 768 / 1024)            vision_transformer.py:351-390 */
     int32_t depth;                     /* ViT blocks                                                               */
@@ -76,6 +82,8 @@ typedef struct moge_config {
     int32_t head_resamplers[MOGE_LEVELS - 1];   /* (all heads share one layout)                                            */
     int32_t neck_in_norm, neck_hidden_norm;     /* moge_res_norm                             modules.py:47-60              */
     int32_t head_in_norm, head_hidden_norm;
+    int32_t neck_activation, head_activation;   /* moge_activation, 0 = ReLU                 modules.py:31-40, 203         */
+    int32_t neck_hidden_mult, head_hidden_mult; /* dim_times_res_block_hidden (0 reads as 1) modules.py:199, 222           */
 } moge_config;
 
 /* Mirrors the `model_config` of a MoGe-1 checkpoint (moge/model/v1.py:148-163).  Supported layout = the released one:
@@ -304,6 +312,9 @@ int moge_test_preprocess(const float* image, float* out, int B, int H, int W, in
 int moge_test_resize_bicubic_aa(const float* image, float* out, int B, int H, int W, int OH, int OW, void* stream);
 /* relu(GroupNorm(groups, C)(x)), eps 1e-5, NHWC x (B,H,W,C) fp32 in / out, computed in `precision` (v1.py:44-49) */
 int moge_test_groupnorm_relu(int precision, const float* x, const float* gamma, const float* beta, float* y, int B, int H, int W, int C, int groups, void* stream);
+/* act(norm(x)) of a v2 residual block (modules.py:31-58): groups = 0 no norm, 1 "layer_norm", C / 32 "group_norm", C "instance_norm" (gamma = beta = NULL);
+ * act = moge_activation; in_place != 0 runs the kernel on its own input buffer (how the hidden norm of a block is applied) */
+int moge_test_norm_act(int precision, const float* x, const float* gamma, const float* beta, float* y, int B, int H, int W, int C, int groups, int act, int in_place, void* stream);
 /* pos_embed (1+37*37, D) -> (1+rows*cols, D) bicubic with the +0.1 kludge */
 int moge_test_posembed(const float* pos, float* out, int D, int rows, int cols, void* stream);
 /* focal/shift solve on (B,H,W,3) points + (B,H,W) 0/1 mask; focal_in NULL or (B,) */

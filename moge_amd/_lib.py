@@ -17,10 +17,11 @@ HEAD_POINTS, HEAD_NORMAL, HEAD_MASK, HEAD_SCALE = 1, 2, 4, 8
 FORCE_PROJECTION, APPLY_MASK = 1, 2
 REMAP = {"linear": 0, "sinh": 1, "exp": 2, "sinh_exp": 3}
 RESAMPLER = {"conv_transpose": 0, "bilinear": 1, "nearest": 2, "pixel_shuffle": 3}      # moge_resampler (x2 up-samplers, modules.py:139-181)
-RES_NORM = {"none": 0, "layer_norm": 1, "group_norm": 2}                                # moge_res_norm (modules.py:47-60)
+RES_NORM = {"none": 0, "layer_norm": 1, "group_norm": 2, "instance_norm": 3}            # moge_res_norm (modules.py:47-60)
+ACTIVATION = {"relu": 0, "leaky_relu": 1, "silu": 2, "elu": 3}                          # moge_activation (modules.py:31-40)
 ERR_NONFINITE = -5
 KC_NAMES = ["gemm", "attn", "conv", "norm", "pre", "post", "recover", "gemm_pp"]
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MogeConfig(C.Structure):
@@ -29,7 +30,8 @@ class MogeConfig(C.Structure):
                 ("neck_res_blocks", C.c_int32 * MOGE_LEVELS), ("head_res_blocks", C.c_int32 * MOGE_LEVELS),
                 ("heads", C.c_int32), ("scale_hidden", C.c_int32), ("remap_output", C.c_int32),
                 ("neck_resamplers", C.c_int32 * (MOGE_LEVELS - 1)), ("head_resamplers", C.c_int32 * (MOGE_LEVELS - 1)),
-                ("neck_in_norm", C.c_int32), ("neck_hidden_norm", C.c_int32), ("head_in_norm", C.c_int32), ("head_hidden_norm", C.c_int32)]
+                ("neck_in_norm", C.c_int32), ("neck_hidden_norm", C.c_int32), ("head_in_norm", C.c_int32), ("head_hidden_norm", C.c_int32),
+                ("neck_activation", C.c_int32), ("head_activation", C.c_int32), ("neck_hidden_mult", C.c_int32), ("head_hidden_mult", C.c_int32)]
 
 
 MOGE_V1_MAX_UP = 4
@@ -120,6 +122,7 @@ def _load() -> C.CDLL:
         "moge_test_preprocess": (C.c_int, [f32p, f32p, i32, i32, i32, i32, i32, vp]),
         "moge_test_resize_bicubic_aa": (C.c_int, [f32p, f32p, i32, i32, i32, i32, i32, vp]),
         "moge_test_groupnorm_relu": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, vp]),
+        "moge_test_norm_act": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, vp]),
         "moge_test_posembed": (C.c_int, [f32p, f32p, i32, i32, i32, vp]),
         "moge_test_recover": (C.c_int, [f32p, vp, f32p, i32, i32, i32, f32p, f32p, vp, vp]),
         "moge_align_l1": (C.c_int, [f32p, f32p, f32p, i32, i32, C.c_float, f32p, f32p, vp, vp]),
@@ -141,7 +144,7 @@ EXPORTS = ["moge_abi_version", "moge_last_error", "moge_create", "moge_create_v1
            "moge_master_blob", "moge_master_ready", "moge_broadcast_weights", "moge_set_precision", "moge_set_onnx_compatible_mode", "moge_workspace_bytes", "moge_forward", "moge_infer",
            "moge_postprocess", "moge_depth_edge_mask", "moge_cast_f16", "moge_sync", "moge_profile_enable", "moge_profile_read", "moge_debug_tap", "moge_tune_set", "moge_test_gemm",
            "moge_test_gemm_ex", "moge_test_layernorm", "moge_test_attention", "moge_test_conv3x3", "moge_test_conv_ex", "moge_test_convt2x2", "moge_test_preprocess",
-           "moge_test_resize_bicubic_aa", "moge_test_groupnorm_relu", "moge_test_posembed", "moge_test_recover",
+           "moge_test_resize_bicubic_aa", "moge_test_groupnorm_relu", "moge_test_norm_act", "moge_test_posembed", "moge_test_recover",
            "moge_align_l1", "moge_align_l1_anchored", "moge_align_select", "moge_align_lstsq"]
 
 

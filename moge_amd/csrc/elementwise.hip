@@ -602,7 +602,7 @@ template int launch_resize_bicubic_aa<f16>(const void*, float*, int, int, int, i
 // GroupNorm (v1.py:44,47: nn.GroupNorm(G, C), eps 1e-5) on an NHWC map, fused with the ReLU that follows it.  Three deterministic steps:
 //   gn_partial: every block reduces a fixed slab of pixels to per-group (sum, sum of squares) in fp32 -> part[b][blk][G][2]
 //   gn_finalize: one thread per (b, group) adds the slabs in order in fp64 -> (mean, rstd)
-//   gn_apply: y = relu((x - mean) * rstd * gamma[c] + beta[c])
+//   gn_apply: y = act((x - mean) * rstd * gamma[c] + beta[c])   (ReLU for MoGe-1 and the v2 defaults; modules.py:31-40 for the others)
 // C % CH == 0 and C / CH divides 256 (C in {32, 64, 128, 256} for the released models).
 constexpr int GN_PIX_PER_BLOCK = 2048;
 template <typename T>
@@ -659,17 +659,27 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part, float* __rest
     mr[2 * i] = (float)mean;
     mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
+// activation of a residual block (modules.py:31-40): ReLU, LeakyReLU(0.2), SiLU, ELU(alpha = 1); codes = moge_activation
+__device__ __forceinline__ float res_act(float v, int act) {
+    switch (act) {
+        case 1: return v > 0.f ? v : 0.2f * v;
+        case 2: return v / (1.f + expf(-v));
+        case 3: return v > 0.f ? v : expm1f(v);
+        default: return fmaxf(v, 0.f);
+    }
+}
+// y = act((x - mean[g]) * rstd[g] * gamma[c] + beta[c]); gamma / beta may be null (InstanceNorm2d has no affine part), mr may be null (no norm:
+// the bare activation of a block whose norm is Identity and whose activation the conv kernels do not fuse).  cg = channels per group (1 = per channel).
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_relu_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ mr,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta, long HW, int C, int G, long total_chunks) {
+__global__ __launch_bounds__(256) void gn_apply_act_kernel(const T* x, T* y /* may alias x: elementwise */, const float* __restrict__ mr,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, long HW, int C, int G, long total_chunks, int act) {
     constexpr int CH = TT<T>::CH;
     const int cpr = C / CH, cg = C / G;
     for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total_chunks; idx += (long)gridDim.x * 256) {
         const int chunk = idx % cpr;
         const long pix = idx / cpr;
         const int b = pix / HW;
-        const int c0 = chunk * CH, g = c0 / cg;
-        const float mean = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
+        const int c0 = chunk * CH;
         float v[CH];
         if constexpr (CH == 8) {
             const f16x8 h = *reinterpret_cast<const f16x8*>(x + idx * CH);
@@ -681,7 +691,16 @@ __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const T* __restrict_
             for (int i = 0; i < 4; i++) v[i] = h[i];
         }
 #pragma unroll
-        for (int i = 0; i < CH; i++) v[i] = fmaxf((v[i] - mean) * rstd * gamma[c0 + i] + beta[c0 + i], 0.f);
+        for (int i = 0; i < CH; i++) {
+            float t = v[i];
+            if (mr) {
+                const int g = cg == 1 ? c0 + i : c0 / cg;          // (a 16-byte chunk never straddles groups: cg % CH == 0, or cg == 1)
+                const float mean = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
+                t = (t - mean) * rstd;
+                if (gamma) t = t * gamma[c0 + i] + beta[c0 + i];
+            }
+            v[i] = res_act(t, act);
+        }
         if constexpr (CH == 8) {
             f16x8 h;
 #pragma unroll
@@ -692,22 +711,76 @@ __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const T* __restrict_
         }
     }
 }
-// scratch: part (B * nblk * G * 2 floats) followed by mr (B * G * 2 floats); returns the float count needed when x == nullptr
+// InstanceNorm2d statistics (modules.py:50,56: nn.InstanceNorm2d(C), eps 1e-5, no affine, instance statistics in eval mode too): the slab
+// scheme of gn_partial with one (sum, sum of squares) pair per CHANNEL -> part[b][blk][C][2]; gn_finalize then runs with G = C.
 template <typename T>
-int launch_groupnorm_relu(const void* x, void* y, const float* gamma, const float* beta, float* scratch, int B, int H, int W, int C, int G, hipStream_t st) {
+__global__ __launch_bounds__(256) void in_partial_kernel(const T* __restrict__ x, float* __restrict__ part, int HW, int C, int nblk) {
     constexpr int CH = TT<T>::CH;
-    if (C % G || (C / G) % CH || C % CH || 256 % (C / CH) || G > 64) return -1;
+    const int cpr = C / CH;
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr, ppb = 256 / cpr;
+    const long p0 = (long)blk * GN_PIX_PER_BLOCK;
+    const long p1 = p0 + GN_PIX_PER_BLOCK < HW ? p0 + GN_PIX_PER_BLOCK : HW;
+    float s1[CH], s2[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) { s1[i] = 0.f; s2[i] = 0.f; }
+    const T* base = x + (size_t)b * HW * C + chunk * CH;
+    for (long p = p0 + prow; p < p1; p += ppb) {
+        float v[CH];
+        if constexpr (CH == 8) {
+            const f16x8 h = *reinterpret_cast<const f16x8*>(base + (size_t)p * C);
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (float)h[i];
+        } else {
+            const f32x4 h = *reinterpret_cast<const f32x4*>(base + (size_t)p * C);
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = h[i];
+        }
+#pragma unroll
+        for (int i = 0; i < CH; i++) { s1[i] += v[i]; s2[i] = fmaf(v[i], v[i], s2[i]); }
+    }
+    __shared__ float sh1[256 * CH], sh2[256 * CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) { sh1[threadIdx.x * CH + i] = s1[i]; sh2[threadIdx.x * CH + i] = s2[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {            // fixed-order sum over the pixel rows that hold channel c
+        const int ck = c / CH, i = c - ck * CH;
+        double a1 = 0.0, a2 = 0.0;
+        for (int r = 0; r < ppb; r++) { a1 += sh1[(r * cpr + ck) * CH + i]; a2 += sh2[(r * cpr + ck) * CH + i]; }
+        float* o = part + (((size_t)b * nblk + blk) * C + c) * 2;
+        o[0] = (float)a1; o[1] = (float)a2;
+    }
+}
+// scratch: part (B * nblk * G * 2 floats) followed by mr (B * G * 2 floats); groupnorm_scratch_floats(B, H, W, G) floats.
+// G = 0: no normalisation (activation only, scratch unused); G = C with cg < a 16-byte chunk: per-channel statistics (InstanceNorm2d, pass null gamma / beta).
+template <typename T>
+int launch_groupnorm_act(const void* x, void* y, const float* gamma, const float* beta, float* scratch, int B, int H, int W, int C, int G, int act, hipStream_t st) {
+    constexpr int CH = TT<T>::CH;
+    if (C % CH || act < 0 || act > 3 || (G != 0 && 256 % (C / CH))) return -1;
     const long HW = (long)H * W;
-    const int nblk = (int)((HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK);
-    float* part = scratch;
-    float* mr = scratch + (size_t)B * nblk * G * 2;
-    hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, part, (int)HW, C, G, nblk);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 63) / 64), dim3(64), 0, st, part, mr, B, G, nblk, (double)HW * (C / G), 1e-5f);
     const long chunks = (long)B * HW * (C / CH);
     int blocks = (int)((chunks + 255) / 256);
     if (blocks > 32768) blocks = 32768;
-    hipLaunchKernelGGL((gn_apply_relu_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)y, mr, gamma, beta, HW, C, G, chunks);
+    if (G == 0) {
+        hipLaunchKernelGGL((gn_apply_act_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)y, (const float*)nullptr, gamma, beta, HW, C, 1, chunks, act);
+        return (int)hipGetLastError();
+    }
+    if (C % G) return -1;
+    const bool per_channel = G == C;
+    if (!per_channel && ((C / G) % CH || G > 64)) return -1;
+    const int nblk = (int)((HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK);
+    float* part = scratch;
+    float* mr = scratch + (size_t)B * nblk * G * 2;
+    if (per_channel) hipLaunchKernelGGL((in_partial_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, part, (int)HW, C, nblk);
+    else hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, part, (int)HW, C, G, nblk);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 63) / 64), dim3(64), 0, st, part, mr, B, G, nblk, (double)HW * (C / G), 1e-5f);
+    hipLaunchKernelGGL((gn_apply_act_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)y, mr, gamma, beta, HW, C, G, chunks, act);
     return (int)hipGetLastError();
+}
+template <typename T>
+int launch_groupnorm_relu(const void* x, void* y, const float* gamma, const float* beta, float* scratch, int B, int H, int W, int C, int G, hipStream_t st) {
+    if (G <= 0 || G == C) return -1;                       // (GroupNorm proper: MoGe-1's blocks and the "layer_norm" / "group_norm" options)
+    return launch_groupnorm_act<T>(x, y, gamma, beta, scratch, B, H, W, C, G, 0, st);
 }
 size_t groupnorm_scratch_floats(int B, int H, int W, int G) {
     const long HW = (long)H * W;
@@ -716,6 +789,8 @@ size_t groupnorm_scratch_floats(int B, int H, int W, int G) {
 }
 template int launch_groupnorm_relu<f16>(const void*, void*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 template int launch_groupnorm_relu<float>(const void*, void*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+template int launch_groupnorm_act<f16>(const void*, void*, const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
+template int launch_groupnorm_act<float>(const void*, void*, const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
 
 // v1.py:127-130: bilinear (align_corners=False, no antialias) resize of the NHWC feature map (B, hs, ws, C) to (B, OH, OW, .) with the view-plane
 // uv of the OUTPUT grid appended as channels C, C+1 (aspect = OW / OH) and zeros up to the padded pitch Cp (a multiple of 8: the 3x3 conv

@@ -50,6 +50,8 @@ int launch_finalize(const float* points_in, const float* normal_in, const float*
 template <typename TIn> int launch_resize_bicubic_aa(const void* img, float* out, int B, int H, int W, int OH, int OW, int round16, hipStream_t st);
 template <typename T>
 int launch_groupnorm_relu(const void* x, void* y, const float* gamma, const float* beta, float* scratch, int B, int H, int W, int C, int G, hipStream_t st);
+template <typename T>
+int launch_groupnorm_act(const void* x, void* y, const float* gamma, const float* beta, float* scratch, int B, int H, int W, int C, int G, int act, hipStream_t st);
 size_t groupnorm_scratch_floats(int B, int H, int W, int G);
 template <typename T>
 int launch_resize_bilinear_uv(const void* x, void* out, int B, int hs, int ws, int C, int OH, int OW, int Cp, float u0, float u1, float v0, float v1, hipStream_t st);

@@ -176,6 +176,12 @@ static const int* stack_rs(const moge_config& c, bool neck) { return neck ? c.ne
 static bool rs_is_phase(int r) { return r == MOGE_RS_BILINEAR || r == MOGE_RS_NEAREST; }
 static const char* rs_final_conv(int r) { return r == MOGE_RS_PIXEL_SHUFFLE ? "2" : "1"; }      // index of the resampler's last 3x3 conv in its nn.Sequential
 static bool stack_has_norm(const moge_config& c, bool neck) { return neck ? (c.neck_in_norm || c.neck_hidden_norm) : (c.head_in_norm || c.head_hidden_norm); }
+static int stack_act(const moge_config& c, bool neck) { return neck ? c.neck_activation : c.head_activation; }
+static int stack_mult(const moge_config& c, bool neck) { const int m = neck ? c.neck_hidden_mult : c.head_hidden_mult; return m > 0 ? m : 1; }      // dim_times_res_block_hidden (0 = unset)
+// residual blocks that leave the fused [ReLU -> 3x3 -> ReLU -> 3x3] pair of launches: any norm, or an activation the conv kernels do not fuse
+static bool stack_generic_blocks(const moge_config& c, bool neck) { return stack_has_norm(c, neck) || stack_act(c, neck) != MOGE_ACT_RELU; }
+// groups of a residual-block norm on a C-channel map (modules.py:47-58)
+static int norm_groups(int mode, int C) { return mode == MOGE_NORM_LAYER ? 1 : mode == MOGE_NORM_INSTANCE ? C : (C / 32 > 0 ? C / 32 : 1); }
 
 static void build_tables_v2_decoder(moge_handle* h) {
     const moge_config& c = h->cfg;
@@ -238,13 +244,14 @@ static void build_tables_v2_decoder(moge_handle* h) {
         }
         for (int l = 0; l < MOGE_LEVELS; l++)
             for (int j = 0; j < nres[l]; j++) {
-                const int cl = c.dims[l];
-                if (in_norm) { tadd(h, name + S(".res_blocks.%d.%d.layers.0.weight", l, j), cl); tadd(h, name + S(".res_blocks.%d.%d.layers.0.bias", l, j), cl); }
-                if (hid_norm) { tadd(h, name + S(".res_blocks.%d.%d.layers.3.weight", l, j), cl); tadd(h, name + S(".res_blocks.%d.%d.layers.3.bias", l, j), cl); }
+                const int cl = c.dims[l], ch = cl * stack_mult(c, neck);          // hidden width (modules.py:222)
+                // (InstanceNorm2d has no parameters: affine=False, track_running_stats=False - nothing in the state dict)
+                if (in_norm && in_norm != MOGE_NORM_INSTANCE) { tadd(h, name + S(".res_blocks.%d.%d.layers.0.weight", l, j), cl); tadd(h, name + S(".res_blocks.%d.%d.layers.0.bias", l, j), cl); }
+                if (hid_norm && hid_norm != MOGE_NORM_INSTANCE) { tadd(h, name + S(".res_blocks.%d.%d.layers.3.weight", l, j), ch); tadd(h, name + S(".res_blocks.%d.%d.layers.3.bias", l, j), ch); }
                 for (int li = 2; li <= 5; li += 3) {
-                    tadd(h, name + S(".res_blocks.%d.%d.layers.%d.weight", l, j, li), (int64_t)cl * cl * 9);
-                    tadd(h, name + S(".res_blocks.%d.%d.layers.%d.bias", l, j, li), cl);
-                    padd(h, name + S(".res%d.%d.w%d", l, j, li == 2 ? 1 : 2), (int64_t)cl * 9 * cl);
+                    tadd(h, name + S(".res_blocks.%d.%d.layers.%d.weight", l, j, li), (int64_t)cl * ch * 9);
+                    tadd(h, name + S(".res_blocks.%d.%d.layers.%d.bias", l, j, li), li == 2 ? ch : cl);
+                    padd(h, name + S(".res%d.%d.w%d", l, j, li == 2 ? 1 : 2), (int64_t)cl * 9 * ch);
                 }
             }
         if (cout > 0) {
@@ -528,8 +535,9 @@ static int pack_weights(moge_handle* h, hipStream_t st) {
         }
         for (int l = 0; l < MOGE_LEVELS; l++)
             for (int j = 0; j < nres[l]; j++) {
-                LCHK(conv3(M(h, name + S(".res_blocks.%d.%d.layers.2.weight", l, j)), Pm<T>(h, name + S(".res%d.%d.w1", l, j)), c.dims[l], c.dims[l]));
-                LCHK(conv3(M(h, name + S(".res_blocks.%d.%d.layers.5.weight", l, j)), Pm<T>(h, name + S(".res%d.%d.w2", l, j)), c.dims[l], c.dims[l]));
+                const int ch = c.dims[l] * stack_mult(c, neck);
+                LCHK(conv3(M(h, name + S(".res_blocks.%d.%d.layers.2.weight", l, j)), Pm<T>(h, name + S(".res%d.%d.w1", l, j)), ch, c.dims[l]));
+                LCHK(conv3(M(h, name + S(".res_blocks.%d.%d.layers.5.weight", l, j)), Pm<T>(h, name + S(".res%d.%d.w2", l, j)), c.dims[l], ch));
             }
         return 0;
     };
@@ -599,19 +607,26 @@ static Plan make_plan(const moge_config& c, int prec, int B, int H, int W, int r
         p.neck[l] = take(p, e * s);
         if (e > mx) mx = e;
     }
+    {   // the hidden map of a residual block is dim_times_res_block_hidden x its level's width (modules.py:222)
+        const int km = stack_mult(c, true) > stack_mult(c, false) ? stack_mult(c, true) : stack_mult(c, false);
+        mx *= (size_t)km;
+    }
     p.scratch_elems = mx;
     int nheads = 0;
     for (int k = 0; k < 3; k++) nheads += (c.heads & HEAD_BITS[k]) ? 1 : 0;
     // (normalised residual blocks share ONE GroupNorm scratch per plan: heads then run one after the other)
-    p.head_sets = (nheads > 1 && moge_tune_get("HEAD_STREAMS", 1) != 0 && B <= moge_tune_get("HEAD_STREAMS_MAX_B", 1) && !stack_has_norm(c, false)) ? nheads : 1;
+    p.head_sets = (nheads > 1 && moge_tune_get("HEAD_STREAMS", 1) != 0 && B <= moge_tune_get("HEAD_STREAMS_MAX_B", 1) && !stack_generic_blocks(c, false)) ? nheads : 1;
     for (int i = 0; i < 3 * p.head_sets; i++) p.scratch[i] = take(p, mx * s);
     if (stack_has_norm(c, true) || stack_has_norm(c, false)) {
         size_t gmax = 0;
-        for (int l = 0; l < MOGE_LEVELS; l++) {
-            const int G = c.dims[l] / 32 > 0 ? c.dims[l] / 32 : 1;
-            const size_t g1 = groupnorm_scratch_floats(B, rows << l, cols << l, G);
-            if (g1 > gmax) gmax = g1;
-        }
+        for (int l = 0; l < MOGE_LEVELS; l++)
+            for (int nk = 0; nk < 2; nk++) {
+                const bool neck = nk == 1;
+                const int nin = neck ? c.neck_in_norm : c.head_in_norm, nhid = neck ? c.neck_hidden_norm : c.head_hidden_norm;
+                const int G1 = nin ? norm_groups(nin, c.dims[l]) : 0, G2 = nhid ? norm_groups(nhid, c.dims[l] * stack_mult(c, neck)) : 0;
+                const size_t g1 = groupnorm_scratch_floats(B, rows << l, cols << l, G1 > G2 ? G1 : G2);
+                if (g1 > gmax) gmax = g1;
+            }
         p.gn = take(p, gmax * 4);
     }
     return p;
@@ -750,39 +765,40 @@ static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* 
     T* cur = x; T* oth = tmp;
     const bool neck = name == "neck";
     const int in_norm = neck ? h->cfg.neck_in_norm : h->cfg.head_in_norm, hid_norm = neck ? h->cfg.neck_hidden_norm : h->cfg.head_hidden_norm;
+    const int act = stack_act(h->cfg, neck), Ch = C * stack_mult(h->cfg, neck);
     for (int j = 0; j < n; j++) {
         const T* w1 = P<T>(h, name + S(".res%d.%d.w1", l, j)); const T* w2 = P<T>(h, name + S(".res%d.%d.w2", l, j));
         const float* b1 = M(h, name + S(".res_blocks.%d.%d.layers.2.bias", l, j)); const float* b2 = M(h, name + S(".res_blocks.%d.%d.layers.5.bias", l, j));
-        if (in_norm || hid_norm) {
-            // normalised block (modules.py:47-67): [GroupNorm ->] ReLU -> 3x3 -> [GroupNorm ->] ReLU -> 3x3, + x.  "layer_norm" = GroupNorm(1, C),
-            // "group_norm" = GroupNorm(C / 32, C); the GroupNorm + ReLU pairs run on MoGe-1's deterministic slab kernels (elementwise.hip)
-            if (!tmp2 || !gn) return fail(MOGE_ERR_INVALID, "res_blocks: normalised blocks need a second scratch map");
+        if (in_norm || hid_norm || act != MOGE_ACT_RELU) {
+            // generic block (modules.py:47-67): [norm ->] act -> 3x3 (C -> Ch) -> [norm ->] act -> 3x3 (Ch -> C), + x.  "layer_norm" = GroupNorm(1, C),
+            // "group_norm" = GroupNorm(C / 32, C), "instance_norm" = InstanceNorm2d (per channel, no affine); the norm + activation pairs run on
+            // MoGe-1's deterministic slab kernels (elementwise.hip).  ReLU without a norm stays fused in the conv (input side / epilogue).
+            if (!tmp2 || (!gn && (in_norm || hid_norm))) return fail(MOGE_ERR_INVALID, "res_blocks: generic blocks need a second scratch map");
             const std::string r = name + S(".res_blocks.%d.%d.layers.", l, j);
-            auto groups = [&](int mode) { return mode == MOGE_NORM_LAYER ? 1 : (C / 32 > 0 ? C / 32 : 1); };
+            auto affine = [&](int mode, const char* key) -> const float* { return (mode == MOGE_NORM_LAYER || mode == MOGE_NORM_GROUP) ? M(h, r + key) : nullptr; };
             const T* in1 = cur;
             int relu1 = 1;
-            if (in_norm) {
+            if (in_norm || act != MOGE_ACT_RELU) {
                 ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)B * Hh * Ww * C * 2 * sizeof(T));
-                LCHK(launch_groupnorm_relu<T>(cur, oth, M(h, r + "0.weight"), M(h, r + "0.bias"), gn, B, Hh, Ww, C, groups(in_norm), st));
+                LCHK(launch_groupnorm_act<T>(cur, oth, affine(in_norm, "0.weight"), affine(in_norm, "0.bias"), gn, B, Hh, Ww, C, in_norm ? norm_groups(in_norm, C) : 0, act, st));
                 in1 = oth; relu1 = 0;
             }
-            T* h1 = in_norm ? tmp2 : oth;                 // conv1's output
-            CHK(conv3x3<T>(h, in1, w1, b1, h1, B, Hh, Ww, C, C, relu1, hid_norm ? ACT_NONE : ACT_RELU, nullptr, nullptr, st));
-            const T* in2 = h1;
-            if (hid_norm) {
-                T* h2 = in_norm ? oth : tmp2;
-                ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)B * Hh * Ww * C * 2 * sizeof(T));
-                LCHK(launch_groupnorm_relu<T>(h1, h2, M(h, r + "3.weight"), M(h, r + "3.bias"), gn, B, Hh, Ww, C, groups(hid_norm), st));
-                in2 = h2;
+            T* h1 = in1 == oth ? tmp2 : oth;              // conv1's output (Ch channels)
+            const bool relu_fused = !hid_norm && act == MOGE_ACT_RELU;
+            CHK(conv3x3<T>(h, in1, w1, b1, h1, B, Hh, Ww, C, Ch, relu1, relu_fused ? ACT_RELU : ACT_NONE, nullptr, nullptr, st));
+            if (!relu_fused) {
+                // elementwise after the statistics pass: in place
+                ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)B * Hh * Ww * Ch * 2 * sizeof(T));
+                LCHK(launch_groupnorm_act<T>(h1, h1, affine(hid_norm, "3.weight"), affine(hid_norm, "3.bias"), gn, B, Hh, Ww, Ch, hid_norm ? norm_groups(hid_norm, Ch) : 0, act, st));
             }
-            CHK(conv3x3<T>(h, in2, w2, b2, cur, B, Hh, Ww, C, C, 0, ACT_NONE, cur, nullptr, st));
+            CHK(conv3x3<T>(h, h1, w2, b2, cur, B, Hh, Ww, Ch, C, 0, ACT_NONE, cur, nullptr, st));
             continue;
         }
 #ifdef MOGE_EXPERIMENTS   // tools/experiments/conv_rb.hip: not part of the product library (python -m moge_amd.build --experiments)
         // CONV_RB (default OFF): measured on MI355X the fused launch is 5-10 % SLOWER than the two conv_pp launches at the bench's level-3 shape
         // (1.44-1.46 vs 1.37-1.38 ms at batch 32, profiles/r03a_kbench_rb.log, timeline r03j: one 130 KiB workgroup per CU exposes every
         // latency the two-per-CU conv_pp form hides, and the MFMA segments run at 21.7 clocks per MFMA beside the partner's read segment)
-        if (std::is_same<T, f16>::value && moge_tune_get("CONV_RB", 0) && (may_swap || ((n - j) >= 2) || cur != x)) {
+        if (std::is_same<T, f16>::value && Ch == C && moge_tune_get("CONV_RB", 0) && (may_swap || ((n - j) >= 2) || cur != x)) {
             // (without may_swap the result must end in x: fuse blocks in pairs, or the last one when the data currently sits in tmp)
             GemmArgs g = gemm_args();
             g.a = cur; g.H = Hh; g.W = Ww; g.C = C; g.relu_in = 1; g.w = w1; g.ldw = 9 * C; g.M = B * Hh * Ww; g.N = C; g.K = 9 * C;
@@ -798,8 +814,8 @@ static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* 
         }
 #endif
         if (cur != x) return fail(MOGE_ERR_INVALID, "res_blocks: internal buffer order");      // (unreachable: an unfused block only follows an even number of fused ones)
-        CHK(conv3x3<T>(h, cur, w1, b1, oth, B, Hh, Ww, C, C, 1, ACT_RELU, nullptr, nullptr, st));
-        CHK(conv3x3<T>(h, oth, w2, b2, cur, B, Hh, Ww, C, C, 0, ACT_NONE, cur, nullptr, st));
+        CHK(conv3x3<T>(h, cur, w1, b1, oth, B, Hh, Ww, C, Ch, 1, ACT_RELU, nullptr, nullptr, st));
+        CHK(conv3x3<T>(h, oth, w2, b2, cur, B, Hh, Ww, Ch, C, 0, ACT_NONE, cur, nullptr, st));
     }
     if (res) *res = cur;
     else if (cur != x) return fail(MOGE_ERR_INVALID, "res_blocks: result left in the scratch buffer");
@@ -1412,15 +1428,19 @@ int moge_create(const moge_config* cfg, int device, moge_handle** out) {
         if (c.neck_resamplers[l] < 0 || c.neck_resamplers[l] > MOGE_RS_PIXEL_SHUFFLE || c.head_resamplers[l] < 0 || c.head_resamplers[l] > MOGE_RS_PIXEL_SHUFFLE)
             return fail(MOGE_ERR_INVALID, "bad resampler code at level %d", l);
     for (int nk = 0; nk < 2; nk++) {
-        const int in_n = nk ? c.neck_in_norm : c.head_in_norm, hid_n = nk ? c.neck_hidden_norm : c.head_hidden_norm;
-        if (in_n < 0 || in_n > MOGE_NORM_GROUP || hid_n < 0 || hid_n > MOGE_NORM_GROUP) return fail(MOGE_ERR_INVALID, "bad res-block norm code");
-        if (in_n || hid_n)
-            for (int l = 0; l < MOGE_LEVELS; l++) {
-                // GroupNorm runs on gn_partial's fixed slabs (as in moge_create_v1): widths 32 ... 512, powers of two
-                const int C = c.dims[l], nb = nk ? c.neck_res_blocks[l] : c.head_res_blocks[l];
-                if (nb > 0 && C != 32 && C != 64 && C != 128 && C != 256 && C != 512)
-                    return fail(MOGE_ERR_INVALID, "normalised residual blocks at level %d need a width of 32 / 64 / 128 / 256 / 512, got %d", l, C);
-            }
+        const bool neck = nk == 1;
+        const int in_n = neck ? c.neck_in_norm : c.head_in_norm, hid_n = neck ? c.neck_hidden_norm : c.head_hidden_norm;
+        if (in_n < 0 || in_n > MOGE_NORM_INSTANCE || hid_n < 0 || hid_n > MOGE_NORM_INSTANCE) return fail(MOGE_ERR_INVALID, "bad res-block norm code");
+        if (stack_act(c, neck) < 0 || stack_act(c, neck) > MOGE_ACT_ELU) return fail(MOGE_ERR_INVALID, "bad res-block activation code");
+        const int km = neck ? c.neck_hidden_mult : c.head_hidden_mult;
+        if (km < 0 || km > 8) return fail(MOGE_ERR_INVALID, "dim_times_res_block_hidden must be 1 ... 8 (0 = unset), got %d", km);
+        for (int l = 0; l < MOGE_LEVELS; l++) {
+            // the norms run on gn_partial's / in_partial's fixed slabs (as in moge_create_v1): widths 32 ... 1024, powers of two
+            const int C = c.dims[l], Ch = C * stack_mult(c, neck), nb = neck ? c.neck_res_blocks[l] : c.head_res_blocks[l];
+            auto pow2 = [](int v) { return v >= 32 && v <= 1024 && (v & (v - 1)) == 0; };
+            if (nb > 0 && ((in_n && !pow2(C)) || (hid_n && !pow2(Ch))))
+                return fail(MOGE_ERR_INVALID, "normalised residual blocks at level %d need widths of 32 ... 1024 (powers of two), got %d (hidden %d)", l, C, Ch);
+        }
     }
     HIPCHK(hipSetDevice(device));
     moge_handle* h = new moge_handle();

@@ -255,6 +255,17 @@ static int t_convt(const float* x, const float* w, const float* bias, float* y, 
 }
 
 template <typename T>
+static int t_norm_act(const float* x, const float* gamma, const float* beta, float* y, int B, int H, int W, int C, int G, int act, int in_place, hipStream_t st) {
+    const size_t n = (size_t)B * H * W * C;
+    DevBuf xb, yb, sc;
+    TCHK(xb.alloc(n * sizeof(T))); TCHK(yb.alloc(n * sizeof(T))); TCHK(sc.alloc((groupnorm_scratch_floats(B, H, W, G > 0 ? G : 1) + 4) * sizeof(float)));
+    TL(to_t<T>(x, xb.p, (long)n, st));
+    TL(launch_groupnorm_act<T>(xb.p, in_place ? xb.p : yb.p, gamma, beta, (float*)sc.p, B, H, W, C, G, act, st));
+    TL(from_t<T>(in_place ? xb.p : yb.p, y, (long)n, st));
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
+template <typename T>
 static int t_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int B, int H, int W, int C, int G, hipStream_t st) {
     const size_t n = (size_t)B * H * W * C;
     DevBuf xb, yb, sc;
@@ -328,6 +339,11 @@ int moge_test_resize_bicubic_aa(const float* image, float* out, int B, int H, in
     TL(launch_resize_bicubic_aa<float>(image, out, B, H, W, OH, OW, 0, st));
     TCHK(hipStreamSynchronize(st));
     return 0;
+}
+
+int moge_test_norm_act(int precision, const float* x, const float* gamma, const float* beta, float* y, int B, int H, int W, int C, int groups, int act, int in_place, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    return precision == MOGE_FP16 ? t_norm_act<f16>(x, gamma, beta, y, B, H, W, C, groups, act, in_place, st) : t_norm_act<float>(x, gamma, beta, y, B, H, W, C, groups, act, in_place, st);
 }
 
 int moge_test_groupnorm_relu(int precision, const float* x, const float* gamma, const float* beta, float* y, int B, int H, int W, int C, int groups, void* stream) {

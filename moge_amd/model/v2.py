@@ -24,26 +24,34 @@ _HEADS = [("points_head", L.HEAD_POINTS, 3), ("normal_head", L.HEAD_NORMAL, 3), 
 
 
 def _check_stack(name: str, sc: Dict[str, Any], dims: List[int], neck: bool):
-    """-> (num_res_blocks per level, resampler codes, (in_norm, hidden_norm) codes) of one ConvStack config (modules.py:195-240).
-    Supported: x2 up-samplers conv_transpose / bilinear / nearest / pixel_shuffle per level, residual-block norms none / layer_norm /
-    group_norm, ReLU, hidden width = width.  (Down-samplers, instance_norm, other activations: no MoGe decoder uses them.)"""
+    """-> (num_res_blocks per level, resampler codes, (in_norm, hidden_norm, activation, hidden multiplier) codes) of one ConvStack config
+    (modules.py:195-240).  Supported: the x2 up-samplers conv_transpose / bilinear / nearest / pixel_shuffle per level; residual-block norms
+    none / layer_norm / group_norm / instance_norm; activations relu / leaky_relu / silu / elu; dim_times_res_block_hidden >= 1.
+    NOT representable: the x0.5 resamplers pixel_unshuffle / avg_pool / max_pool - MoGeModel.forward feeds level l a map of 2^l x the token
+    grid (v2.py:154-160), so `x + feature` (modules.py:247-249) is a shape error in the reference itself with any of them."""
     if list(sc["dim_res_blocks"]) != list(dims):
         raise NotImplementedError(f"{name}: dim_res_blocks must equal the neck's ({dims})")
     res = sc.get("resamplers", "conv_transpose")
     res = list(res) if isinstance(res, (list, tuple)) else [res] * 4
     if len(res) != 4 or any(r not in L.RESAMPLER for r in res):
-        raise NotImplementedError(f"{name}: resamplers {res} unsupported (four of {sorted(L.RESAMPLER)})")
+        raise NotImplementedError(f"{name}: resamplers {res} unsupported (four of {sorted(L.RESAMPLER)}; a x0.5 resampler cannot appear in a "
+                                  f"working MoGe-2 decoder, v2.py:154-160)")
     in_norm, hid_norm = sc.get("res_block_in_norm", "layer_norm"), sc.get("res_block_hidden_norm", "group_norm")
     if in_norm not in L.RES_NORM or hid_norm not in L.RES_NORM:
         raise NotImplementedError(f"{name}: res_block norms ({in_norm}, {hid_norm}) unsupported ({sorted(L.RES_NORM)})")
-    if sc.get("activation", "relu") != "relu" or sc.get("dim_times_res_block_hidden", 1) != 1:
-        raise NotImplementedError(f"{name}: only ReLU res blocks with hidden = dim are implemented")
+    act = sc.get("activation", "relu")
+    if act not in L.ACTIVATION:
+        raise ValueError(f"Unsupported activation function: {act}")                     # modules.py:41
+    mult = sc.get("dim_times_res_block_hidden", 1)
+    if not isinstance(mult, int) or not 1 <= mult <= 8:
+        raise NotImplementedError(f"{name}: dim_times_res_block_hidden {mult} unsupported (an integer 1 ... 8)")
     nres = sc.get("num_res_blocks", 1)
     nres = list(nres) if isinstance(nres, (list, tuple)) else [nres] * 5
-    if in_norm != "none" or hid_norm != "none":
-        for l in range(5):
-            if nres[l] > 0 and dims[l] not in (32, 64, 128, 256, 512):
-                raise NotImplementedError(f"{name}: normalised residual blocks need a width of 32 / 64 / 128 / 256 / 512 (level {l}: {dims[l]})")
+    widths = (32, 64, 128, 256, 512, 1024)
+    for l in range(5):
+        if nres[l] > 0 and ((in_norm != "none" and dims[l] not in widths) or (hid_norm != "none" and dims[l] * mult not in widths)):
+            raise NotImplementedError(f"{name}: normalised residual blocks need widths of 32 ... 1024, powers of two "
+                                      f"(level {l}: {dims[l]}, hidden {dims[l] * mult})")
     dim_in = list(sc["dim_in"])
     want_in = [dims[0] + 2, 2, 2, 2, 2] if neck else list(dims)
     if dim_in != want_in:
@@ -52,7 +60,7 @@ def _check_stack(name: str, sc: Dict[str, Any], dims: List[int], neck: bool):
     dim_out = list(dim_out) if isinstance(dim_out, (list, tuple)) else [dim_out] * 5
     if neck and any(d is not None for d in dim_out):
         raise NotImplementedError("neck.dim_out must be null")
-    return nres, [L.RESAMPLER[r] for r in res], (L.RES_NORM[in_norm], L.RES_NORM[hid_norm])
+    return nres, [L.RESAMPLER[r] for r in res], (L.RES_NORM[in_norm], L.RES_NORM[hid_norm], L.ACTIVATION[act], mult)
 
 
 class MoGeModel:
@@ -96,7 +104,7 @@ class MoGeModel:
             if not isinstance(do, (list, tuple)) or list(do[:4]) != [None] * 4 or do[4] != cout:
                 raise NotImplementedError(f"{name}: dim_out must be [null,null,null,null,{cout}]")
             if head_res is not None and (r != head_res or rs != head_rs or nm != head_norm):
-                raise NotImplementedError("all heads must share num_res_blocks, resamplers and res-block norms")
+                raise NotImplementedError("all heads must share num_res_blocks, resamplers and residual-block options")
             head_res, head_rs, head_norm = r, rs, nm
             bits |= bit
             self._head_names.append(name)
@@ -113,8 +121,8 @@ class MoGeModel:
         for l in range(4):
             cfg.neck_resamplers[l] = neck_rs[l]
             cfg.head_resamplers[l] = (head_rs or neck_rs)[l]
-        cfg.neck_in_norm, cfg.neck_hidden_norm = neck_norm
-        cfg.head_in_norm, cfg.head_hidden_norm = head_norm or (0, 0)
+        cfg.neck_in_norm, cfg.neck_hidden_norm, cfg.neck_activation, cfg.neck_hidden_mult = neck_norm
+        cfg.head_in_norm, cfg.head_hidden_norm, cfg.head_activation, cfg.head_hidden_mult = head_norm or (0, 0, 0, 1)
         cfg.heads = bits
         cfg.remap_output = L.REMAP[remap_output]
         self._cfg = cfg

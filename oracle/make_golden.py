@@ -191,6 +191,11 @@ CASES = [
          kwargs=dict(num_tokens=108, use_fp16=False)),
     dict(name="tiny_generic_stack_b", config="tiny-generic-stack-b", seed=1, sane=True, input_seed=27, shape=[1, 3, 98, 126],
          kwargs=dict(num_tokens=120, use_fp16=False)),
+    # ... and every residual-block option (modules.py:31-58, 199-203): SiLU / ELU / LeakyReLU, InstanceNorm2d, hidden width 2x and 4x the level's
+    dict(name="tiny_block_options", config="tiny-block-options", seed=2, sane=True, input_seed=28, shape=[2, 3, 84, 112],
+         kwargs=dict(num_tokens=108, use_fp16=False)),
+    dict(name="tiny_block_options_b", config="tiny-block-options-b", seed=3, sane=True, input_seed=29, shape=[1, 3, 98, 126],
+         kwargs=dict(num_tokens=120, use_fp16=False)),
     dict(name="tiny_points_head_only", config="tiny-vits-normal", cfg_override=dict(drop=["mask_head", "normal_head", "scale_head"]), seed=0, sane=True, input_seed=25,
          shape=[2, 3, 84, 112], kwargs=dict(num_tokens=108, use_fp16=False)),
 ]

@@ -54,23 +54,33 @@ HEAD_NAMES = ("points_head", "normal_head", "mask_head")
 def make_config(backbone: str = "dinov2_vitl14", taps: Sequence[int] = (5, 11, 17, 23),
                 dims: Sequence[int] = (1024, 256, 128, 64, 32), normal: bool = True,
                 scale_hidden: Optional[int] = None, num_tokens_range=(1200, 3600),
-                neck_resamplers=None, head_resamplers=None, neck_norms=("none", "none"), head_norms=("none", "none")) -> dict:
+                neck_resamplers=None, head_resamplers=None, neck_norms=("none", "none"), head_norms=("none", "none"),
+                neck_block=("relu", 1), head_block=("relu", 1)) -> dict:
     """model_config in the shape of configs/train/v2.json:238-285 (vitl) for any backbone/dims; the ConvStack options the released models
-    leave at [conv_transpose x3, bilinear] / no norms (modules.py:139-181, 47-60) can be set for the generic-layout test configs."""
+    leave at [conv_transpose x3, bilinear] / no norms / ReLU / hidden = width (modules.py:139-181, 31-60, 199-203) can be set for the
+    generic-layout test configs: *_block = (activation, dim_times_res_block_hidden), written to the config only when not the default."""
     D = VIT_SPECS[backbone][0]
     dims = list(dims)
     resamplers = ["conv_transpose", "conv_transpose", "conv_transpose", "bilinear"]
 
+    def block_opts(blk):
+        out = {}
+        if blk[0] != "relu":
+            out["activation"] = blk[0]
+        if blk[1] != 1:
+            out["dim_times_res_block_hidden"] = blk[1]
+        return out
+
     def head(cout):
         return {"dim_in": list(dims), "dim_out": [None, None, None, None, cout], "dim_res_blocks": list(dims),
                 "num_res_blocks": [0, 1, 1, 1, 0], "res_block_in_norm": head_norms[0], "res_block_hidden_norm": head_norms[1],
-                "resamplers": list(head_resamplers or resamplers)}
+                "resamplers": list(head_resamplers or resamplers), **block_opts(head_block)}
 
     cfg = {
         "encoder": {"backbone": backbone, "intermediate_layers": list(taps), "dim_out": dims[0]},
         "neck": {"dim_in": [dims[0] + 2, 2, 2, 2, 2], "dim_out": None, "dim_res_blocks": list(dims),
                  "num_res_blocks": [0, 2, 2, 2, 0], "res_block_in_norm": neck_norms[0], "res_block_hidden_norm": neck_norms[1],
-                 "resamplers": list(neck_resamplers or resamplers)},
+                 "resamplers": list(neck_resamplers or resamplers), **block_opts(neck_block)},
         "points_head": head(3),
         "mask_head": head(1),
         "scale_head": {"dims": [D, scale_hidden or D, scale_hidden or D, 1]},
@@ -101,6 +111,14 @@ def named_configs() -> Dict[str, dict]:
                                             neck_resamplers=["bilinear", "conv_transpose", "pixel_shuffle", "nearest"],
                                             head_resamplers=["conv_transpose", "pixel_shuffle", "bilinear", "conv_transpose"],
                                             neck_norms=("none", "none"), head_norms=("group_norm", "none")),
+        # ... and the residual-block options (modules.py:31-58, 199-203): the other activations, InstanceNorm2d, hidden width = k x width
+        "tiny-block-options": make_config("dinov2_vits14", (2, 5, 8, 11), (128, 64, 64, 32, 32), True, scale_hidden=128,
+                                          neck_norms=("instance_norm", "group_norm"), head_norms=("none", "instance_norm"),
+                                          neck_block=("silu", 2), head_block=("elu", 1)),
+        "tiny-block-options-b": make_config("dinov2_vits14", (2, 5, 8, 11), (128, 64, 64, 32, 32), True, scale_hidden=128,
+                                            neck_resamplers=["nearest", "conv_transpose", "conv_transpose", "pixel_shuffle"],
+                                            neck_norms=("none", "none"), head_norms=("layer_norm", "none"),
+                                            neck_block=("relu", 2), head_block=("leaky_relu", 4)),
     }
 
 
@@ -155,17 +173,22 @@ def state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
                 out.append((f"{name}.resamplers.{l}.2.bias", (cout,)))
             else:
                 raise NotImplementedError(kind)
+        mult = sc.get("dim_times_res_block_hidden", 1)
         for l, c in enumerate(dims):
+            ch = c * mult                                       # hidden width (modules.py:222)
             for j in range(nres[l]):
-                if sc["res_block_in_norm"] != "none":          # GroupNorm affine parameters (modules.py:47-50)
+                # GroupNorm affine parameters (modules.py:47-50); InstanceNorm2d(C) has none (affine=False, no running statistics)
+                # (key order = the order the synthetic weights are drawn in: norms first, as the committed fixtures were made)
+                if sc["res_block_in_norm"] not in ("none", "instance_norm"):
                     out.append((f"{name}.res_blocks.{l}.{j}.layers.0.weight", (c,)))
                     out.append((f"{name}.res_blocks.{l}.{j}.layers.0.bias", (c,)))
-                if sc["res_block_hidden_norm"] != "none":
-                    out.append((f"{name}.res_blocks.{l}.{j}.layers.3.weight", (c,)))
-                    out.append((f"{name}.res_blocks.{l}.{j}.layers.3.bias", (c,)))
-                for li in (2, 5):
-                    out.append((f"{name}.res_blocks.{l}.{j}.layers.{li}.weight", (c, c, 3, 3)))
-                    out.append((f"{name}.res_blocks.{l}.{j}.layers.{li}.bias", (c,)))
+                if sc["res_block_hidden_norm"] not in ("none", "instance_norm"):
+                    out.append((f"{name}.res_blocks.{l}.{j}.layers.3.weight", (ch,)))
+                    out.append((f"{name}.res_blocks.{l}.{j}.layers.3.bias", (ch,)))
+                out.append((f"{name}.res_blocks.{l}.{j}.layers.2.weight", (ch, c, 3, 3)))
+                out.append((f"{name}.res_blocks.{l}.{j}.layers.2.bias", (ch,)))
+                out.append((f"{name}.res_blocks.{l}.{j}.layers.5.weight", (c, ch, 3, 3)))
+                out.append((f"{name}.res_blocks.{l}.{j}.layers.5.bias", (c,)))
         for l, c in enumerate(dims):
             if dim_out[l] is not None:
                 out.append((f"{name}.output_blocks.{l}.weight", (dim_out[l], c, 1, 1)))
@@ -401,17 +424,35 @@ def _conv3(x, w, b):
 
 
 def _res_norm(x, kind, w, b):
-    """in_norm / hidden_norm of ResidualConvBlock (modules.py:47-58): GroupNorm(1, C) ("layer_norm") or GroupNorm(C // 32, C) ("group_norm")."""
+    """in_norm / hidden_norm of ResidualConvBlock (modules.py:47-58): GroupNorm(1, C) ("layer_norm"), GroupNorm(C // 32, C) ("group_norm"),
+    InstanceNorm2d(C) ("instance_norm": no affine part, instance statistics in eval mode as well - track_running_stats=False)."""
     if kind == "none":
         return x
+    if kind == "instance_norm":
+        return F.instance_norm(x, eps=1e-5)
     C = x.shape[1]
     return F.group_norm(x, 1 if kind == "layer_norm" else C // 32, w, b, eps=1e-5)
 
 
+def _res_act(x, kind):
+    """activation of ResidualConvBlock (modules.py:31-40)"""
+    if kind == "relu":
+        return F.relu(x)
+    if kind == "leaky_relu":
+        return F.leaky_relu(x, negative_slope=0.2)
+    if kind == "silu":
+        return F.silu(x)
+    if kind == "elu":
+        return F.elu(x)
+    raise ValueError(f"Unsupported activation function: {kind}")
+
+
 def conv_stack(sc: dict, sd: Dict[str, torch.Tensor], name: str, feats: List[Optional[torch.Tensor]]) -> List[torch.Tensor]:
-    """ConvStack.forward (modules.py:242-254): ReLU residual blocks with optional GroupNorms, the x2 up-samplers conv_transpose / bilinear /
-    nearest / pixel_shuffle (modules.py:139-181).  The released v2 models use no norms and [conv_transpose x3, bilinear]."""
+    """ConvStack.forward (modules.py:242-254): residual blocks [norm ->] act -> 3x3 -> [norm ->] act -> 3x3 with every norm / activation /
+    hidden width of modules.py:18-67, the x2 up-samplers conv_transpose / bilinear / nearest / pixel_shuffle (modules.py:139-181).  The released
+    v2 models use no norms, ReLU, hidden = width and [conv_transpose x3, bilinear]."""
     in_norm, hid_norm = sc["res_block_in_norm"], sc["res_block_hidden_norm"]
+    act = sc.get("activation", "relu")
     dims = sc["dim_res_blocks"]
     dim_out = sc["dim_out"] if isinstance(sc["dim_out"], list) else [sc["dim_out"]] * len(dims)
     outs = []
@@ -424,9 +465,9 @@ def conv_stack(sc: dict, sd: Dict[str, torch.Tensor], name: str, feats: List[Opt
         for j in range(sc["num_res_blocks"][l]):
             p = f"{name}.res_blocks.{l}.{j}.layers."
             y = _res_norm(x, in_norm, sd.get(p + "0.weight"), sd.get(p + "0.bias"))
-            y = _conv3(F.relu(y), sd[p + "2.weight"], sd[p + "2.bias"])
+            y = _conv3(_res_act(y, act), sd[p + "2.weight"], sd[p + "2.bias"])
             y = _res_norm(y, hid_norm, sd.get(p + "3.weight"), sd.get(p + "3.bias"))
-            y = _conv3(F.relu(y), sd[p + "5.weight"], sd[p + "5.bias"])
+            y = _conv3(_res_act(y, act), sd[p + "5.weight"], sd[p + "5.bias"])
             x = x + y
         if dim_out[l] is not None:
             outs.append(F.conv2d(x, sd[f"{name}.output_blocks.{l}.weight"], sd[f"{name}.output_blocks.{l}.bias"]))

@@ -160,6 +160,17 @@ def groupnorm_relu(prec, x_nhwc, gamma, beta, groups):
     return y
 
 
+def norm_act(prec, x_nhwc, gamma, beta, groups, act, in_place=False):
+    """act(norm(x)) of a v2 residual block: groups 0 = no norm, C = InstanceNorm2d (gamma = beta = None)."""
+    x = _f(x_nhwc)
+    B, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    g = _f(gamma) if gamma is not None else None
+    b = _f(beta) if beta is not None else None
+    L.check(L.lib.moge_test_norm_act(prec, _p(x), _p(g) if g is not None else None, _p(b) if b is not None else None, _p(y), B, H, W, Cc, groups, act, int(in_place), st()))
+    return y
+
+
 def conv_ex(x_nhwc, w, bias, prec=1, relu_in=False, act=0, add=None, side=None, side_w=None, uv=None, up2=False, w2=None, bias2=None, dot_w=None):
     """One 3x3 conv through the pieces the decoder fuses into it (moge_test_conv_ex).  uv = (wu, wv, u0, u1, v0, v1) at the OUTPUT resolution;
     w2 / bias2 select the fused residual block (conv_rb.hip)."""

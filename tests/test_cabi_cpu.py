@@ -16,12 +16,12 @@ def test_library_exports_match_header():
     assert declared == sorted(L.EXPORTS)
     for name in declared:
         assert hasattr(L.lib, name), f"libmoge_hip.so does not export {name}"
-    assert L.lib.moge_abi_version() == L.ABI_VERSION == 3
+    assert L.lib.moge_abi_version() == L.ABI_VERSION == 4
 
 
 def test_config_struct_layout():
     from moge_amd import _lib as L
-    assert ctypes.sizeof(L.MogeConfig) == 4 * (4 + 8 + 5 + 5 + 5 + 3 + 4 + 4 + 4)
+    assert ctypes.sizeof(L.MogeConfig) == 4 * (4 + 8 + 5 + 5 + 5 + 3 + 4 + 4 + 4 + 4)      # ABI v4: + activations, hidden multipliers
     assert ctypes.sizeof(L.Outputs) == 9 * ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(L.Profile) == 8 * 8 * 4
 
@@ -48,8 +48,9 @@ def test_model_mirror_host_logic():
 
 
 def test_mirror_maps_every_convstack_option_it_supports():
-    """modules.py:139-181, 47-60: the x2 up-samplers and residual-block norms of ConvStack reach the C ABI as codes (ABI v3); options no decoder
-    uses (down-samplers, instance_norm, other activations, a hidden-width multiplier) are refused when the model is constructed."""
+    """modules.py:139-181, 31-60, 199-203: the x2 up-samplers, residual-block norms (ABI v3), activations, InstanceNorm2d and the hidden-width
+    multiplier (ABI v4) of ConvStack reach the C ABI as codes; the x0.5 resamplers - which make the reference's own forward a shape error
+    (v2.py:154-160 with modules.py:247-249) - and unknown names are refused when the model is constructed."""
     import copy
     from moge_amd import _lib as L
     from moge_amd.model import import_model_class_by_version
@@ -60,16 +61,31 @@ def test_mirror_maps_every_convstack_option_it_supports():
     assert list(m._cfg.neck_resamplers) == [L.RESAMPLER[r] for r in cfg["neck"]["resamplers"]] == [3, 2, 1, 0]
     assert list(m._cfg.head_resamplers) == [2, 0, 3, 1]
     assert (m._cfg.neck_in_norm, m._cfg.neck_hidden_norm, m._cfg.head_in_norm, m._cfg.head_hidden_norm) == (1, 2, 0, 1)
+    assert (m._cfg.neck_activation, m._cfg.head_activation, m._cfg.neck_hidden_mult, m._cfg.head_hidden_mult) == (0, 0, 1, 1)
     rel = M(**O.named_configs()["moge-2-vitl-normal"])._cfg
     assert list(rel.neck_resamplers) == list(rel.head_resamplers) == [0, 0, 0, 1] and rel.neck_in_norm == rel.head_hidden_norm == 0
-    for path, value in ((("neck", "resamplers"), ["conv_transpose", "avg_pool", "conv_transpose", "bilinear"]), (("points_head", "res_block_in_norm"), "instance_norm"),
-                        (("neck", "activation"), "silu"), (("mask_head", "dim_times_res_block_hidden"), 2)):
+    assert rel.neck_activation == rel.head_activation == 0 and rel.neck_hidden_mult == rel.head_hidden_mult == 1
+    opt = M(**O.named_configs()["tiny-block-options"])._cfg
+    assert (opt.neck_in_norm, opt.neck_hidden_norm, opt.head_in_norm, opt.head_hidden_norm) == (3, 2, 0, 3)
+    assert (opt.neck_activation, opt.head_activation, opt.neck_hidden_mult, opt.head_hidden_mult) == (L.ACTIVATION["silu"], L.ACTIVATION["elu"], 2, 1)
+    optb = M(**O.named_configs()["tiny-block-options-b"])._cfg
+    assert (optb.neck_activation, optb.head_activation, optb.neck_hidden_mult, optb.head_hidden_mult) == (0, L.ACTIVATION["leaky_relu"], 2, 4)
+    for path, value, exc in ((("neck", "resamplers"), ["conv_transpose", "avg_pool", "conv_transpose", "bilinear"], NotImplementedError),
+                             (("neck", "resamplers"), ["pixel_unshuffle"] * 4, NotImplementedError),
+                             (("points_head", "res_block_in_norm"), "batch_norm", NotImplementedError),
+                             (("neck", "activation"), "gelu", ValueError),                               # modules.py:41 raises ValueError too
+                             (("mask_head", "dim_times_res_block_hidden"), 2, NotImplementedError),      # heads must share their options
+                             (("neck", "dim_times_res_block_hidden"), 0, NotImplementedError)):
         bad = copy.deepcopy(cfg)
         bad[path[0]][path[1]] = value
-        with pytest.raises(NotImplementedError):
+        with pytest.raises(exc):
             M(**bad)
-    wide = copy.deepcopy(O.named_configs()["moge-2-vitl-normal"])           # GroupNorm slabs: widths 32 ... 512 only
-    wide["neck"]["res_block_in_norm"] = "layer_norm"; wide["neck"]["num_res_blocks"] = [1, 2, 2, 2, 0]
+    odd = copy.deepcopy(O.named_configs()["moge-2-vits-normal"])            # norm slabs: power-of-two widths 32 ... 1024 only (level 0 is 384 wide here)
+    odd["neck"]["res_block_in_norm"] = "layer_norm"; odd["neck"]["num_res_blocks"] = [1, 2, 2, 2, 0]
+    with pytest.raises(NotImplementedError):
+        M(**odd)
+    wide = copy.deepcopy(O.named_configs()["moge-2-vitl-normal"])           # ... and the hidden map counts: 256 x 8 = 2048 is too wide for a hidden norm
+    wide["neck"]["res_block_hidden_norm"] = "group_norm"; wide["neck"]["dim_times_res_block_hidden"] = 8
     with pytest.raises(NotImplementedError):
         M(**wide)
 

@@ -24,7 +24,7 @@ def _build():
     return exe
 
 
-@pytest.mark.parametrize("config,prec", [("tiny-vits-normal", 0), ("tiny-vits-normal", 2), ("tiny-generic-stack", 1)])
+@pytest.mark.parametrize("config,prec", [("tiny-vits-normal", 0), ("tiny-vits-normal", 2), ("tiny-generic-stack", 1), ("tiny-block-options", 1)])
 def test_c_host_without_torch_reproduces_the_python_mirror(tmp_path, config, prec):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")

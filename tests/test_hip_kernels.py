@@ -293,6 +293,35 @@ def test_groupnorm_relu(H, prec, B, Hh, Ww, Cc, G):
     assert relmax(out, ref) < (2e-5 if prec == 0 else 2e-3)
 
 
+_ACTS = [F.relu, lambda t: F.leaky_relu(t, 0.2), F.silu, F.elu]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,Hh,Ww,Cc,norm,act,in_place", [
+    (2, 24, 30, 64, "instance", 2, False), (1, 111, 77, 128, "instance", 3, True), (3, 50, 41, 32, "instance", 0, False), (1, 70, 66, 1024, "instance", 1, True),
+    (2, 24, 30, 256, "none", 1, False), (1, 97, 130, 40, "none", 2, True), (2, 33, 31, 64, "none", 3, False),
+    (2, 24, 30, 256, "group", 2, True), (1, 111, 77, 128, "layer", 3, False), (1, 40, 52, 1024, "group", 1, False), (1, 97, 130, 64, "layer", 0, True)])
+def test_residual_block_norm_and_activation(H, prec, B, Hh, Ww, Cc, norm, act, in_place):
+    """ResidualConvBlock's [norm ->] activation pairs (modules.py:31-58): InstanceNorm2d (per channel, no affine, eps 1e-5), GroupNorm(1, C),
+    GroupNorm(C / 32, C) or no norm, followed by ReLU / LeakyReLU(0.2) / SiLU / ELU; out of place and on its own input buffer (the hidden norm
+    of a block runs in place); widths up to 1024 (a 4 x 256 hidden map), multi-slab and ragged last slabs."""
+    g = torch.Generator().manual_seed(Cc + act)
+    x = torch.randn(B, Cc, Hh, Ww, generator=g) * 2 + 0.7
+    xin = (x.half().float() if prec else x).cuda()
+    w = b = None
+    if norm == "instance":
+        y, groups = F.instance_norm(xin, eps=1e-5), Cc
+    elif norm == "none":
+        y, groups = xin, 0
+    else:
+        groups = 1 if norm == "layer" else Cc // 32
+        w, b = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+        y = F.group_norm(xin, groups, w.cuda(), b.cuda(), 1e-5)
+    ref = _ACTS[act](y).permute(0, 2, 3, 1)
+    out = H.norm_act(prec, x.permute(0, 2, 3, 1), w, b, groups, act, in_place)
+    assert relmax(out, ref) < (2e-5 if prec == 0 else 2e-3)
+
+
 def test_cast_f16_matches_torch_half_bit_for_bit(H):
     """moge_cast_f16 (what MoGeModel.forward of a half model returns through, v2.py:386-387): round-to-nearest-even like `.half()`, including
     ties, overflow to inf, subnormal halves, signed zeros, inf and NaN."""
