@@ -86,8 +86,9 @@ typedef struct moge_config {
     int32_t neck_hidden_mult, head_hidden_mult; /* dim_times_res_block_hidden (0 reads as 1) modules.py:199, 222           */
 } moge_config;
 
-/* Mirrors the `model_config` of a MoGe-1 checkpoint (moge/model/v1.py:148-163).  Supported layout = the released one:
- * group_norm residual blocks, dim_times_res_block_hidden 1, last_res_blocks 0, last_conv_size 1, head outputs [3 (points), 1 (mask)]. */
+/* Mirrors the `model_config` of a MoGe-1 checkpoint (moge/model/v1.py:148-163).  Supported: group_norm / layer_norm residual
+ * blocks, dim_times_res_block_hidden 1 ... 8 (configs/train/v1.json:31 trains with 2), last_res_blocks 0, last_conv_size 1 (the defaults, and
+ * what configs/train/v1.json uses), head outputs [3 (points), 1 (mask)]. */
 #define MOGE_V1_MAX_UP 4
 typedef struct moge_v1_config {
     int32_t embed_dim, depth, num_heads;      /* ViT (head_dim 64)                                                          */
@@ -100,6 +101,8 @@ typedef struct moge_v1_config {
     int32_t last_conv_channels;               /* hidden width of the output blocks                      v1.py:105-110       */
     int32_t remap_output;                     /* moge_remap                                             v1.py:253-267       */
     float mask_threshold;                     /* validity = raw mask output > mask_threshold            v1.py:358           */
+    int32_t hidden_mult;                      /* dim_times_res_block_hidden (0 reads as 1)              v1.py:69, 85        */
+    int32_t res_block_norm;                   /* hidden norm: MOGE_NORM_GROUP (or 0) = GroupNorm(Ch / 32, Ch), MOGE_NORM_LAYER = GroupNorm(1, Ch)   v1.py:47 */
 } moge_v1_config;
 
 /* One state-dict entry handed to moge_load_weights: fp32, contiguous, host memory. */

@@ -1206,6 +1206,8 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
 // encode above); this is the Head (v1.py:61-142) and the two-stage input resize (v1.py:271-278).
 // ============================================================================================================================
 static int v1_cpad(int c) { return (c + 2 + 7) / 8 * 8; }            // channels + (u, v), padded to 16-byte chunks in both storage types
+static int v1_mult(const moge_v1_config& c) { return c.hidden_mult > 0 ? c.hidden_mult : 1; }                          // dim_times_res_block_hidden (v1.py:85)
+static int v1_hidden_groups(const moge_v1_config& c, int ch) { return c.res_block_norm == MOGE_NORM_LAYER ? 1 : (ch / 32 > 0 ? ch / 32 : 1); }     // v1.py:47
 
 static void build_tables_v1_decoder(moge_handle* h) {
     const moge_v1_config& c = h->cfg1;
@@ -1219,12 +1221,13 @@ static void build_tables_v1_decoder(moge_handle* h) {
         aadd(h, S("v1.up%d.wu", i), 4 * co); aadd(h, S("v1.up%d.wv", i), 4 * co); aadd(h, S("v1.up%d.biasT", i), 4 * co);
         for (int j = 0; j < c.num_res_blocks; j++) {
             const std::string r = u + S("%d.layers.", 1 + j);
+            const int ch = co * v1_mult(c);                      // hidden width (v1.py:85)
             tadd(h, r + "0.weight", co); tadd(h, r + "0.bias", co);
-            tadd(h, r + "2.weight", (int64_t)co * co * 9); tadd(h, r + "2.bias", co);
-            tadd(h, r + "3.weight", co); tadd(h, r + "3.bias", co);
-            tadd(h, r + "5.weight", (int64_t)co * co * 9); tadd(h, r + "5.bias", co);
-            padd(h, S("v1.up%d.res%d.w1", i, j), (int64_t)co * 9 * co);
-            padd(h, S("v1.up%d.res%d.w2", i, j), (int64_t)co * 9 * co);
+            tadd(h, r + "2.weight", (int64_t)ch * co * 9); tadd(h, r + "2.bias", ch);
+            tadd(h, r + "3.weight", ch); tadd(h, r + "3.bias", ch);
+            tadd(h, r + "5.weight", (int64_t)co * ch * 9); tadd(h, r + "5.bias", co);
+            padd(h, S("v1.up%d.res%d.w1", i, j), (int64_t)ch * 9 * co);
+            padd(h, S("v1.up%d.res%d.w2", i, j), (int64_t)co * 9 * ch);
         }
     }
     const int cl = c.dim_upsample[c.n_up - 1], c4 = c.last_conv_channels;
@@ -1266,8 +1269,9 @@ static int pack_weights_v1(moge_handle* h, hipStream_t st) {
         LCHK(conv3(M(h, u + "0.1.weight"), Pm<T>(h, S("v1.up%d.w3", i)), co, co, co));
         for (int j = 0; j < c.num_res_blocks; j++) {
             const std::string r = u + S("%d.layers.", 1 + j);
-            LCHK(conv3(M(h, r + "2.weight"), Pm<T>(h, S("v1.up%d.res%d.w1", i, j)), co, co, co));
-            LCHK(conv3(M(h, r + "5.weight"), Pm<T>(h, S("v1.up%d.res%d.w2", i, j)), co, co, co));
+            const int ch = co * v1_mult(c);
+            LCHK(conv3(M(h, r + "2.weight"), Pm<T>(h, S("v1.up%d.res%d.w1", i, j)), ch, co, co));
+            LCHK(conv3(M(h, r + "5.weight"), Pm<T>(h, S("v1.up%d.res%d.w2", i, j)), co, ch, ch));
         }
     }
     const int cl = c.dim_upsample[c.n_up - 1], c4 = c.last_conv_channels, cp = v1_cpad(cl);
@@ -1315,9 +1319,10 @@ static PlanV1 make_plan_v1(moge_handle* h, int prec, int B, int H, int W, int rh
     p.scratch_elems = 0;
     size_t mx = 0, gnmax = 0;
     for (int i = 0; i < c1.n_up; i++) {
-        const size_t e = BP * ((size_t)1 << (2 * (i + 1))) * c1.dim_upsample[i];
+        const int ch = c1.dim_upsample[i] * v1_mult(c1);              // the hidden map of a residual block is the widest one of its stage
+        const size_t e = BP * ((size_t)1 << (2 * (i + 1))) * ch;
         if (e > mx) mx = e;
-        const size_t gsz = groupnorm_scratch_floats(B, rows << (i + 1), cols << (i + 1), c1.dim_upsample[i] / 32 > 0 ? c1.dim_upsample[i] / 32 : 1);
+        const size_t gsz = groupnorm_scratch_floats(B, rows << (i + 1), cols << (i + 1), v1_hidden_groups(c1, ch));
         if (gsz > gnmax) gnmax = gsz;
     }
     v.img1 = take(p, (size_t)B * 3 * rh * rw * 4);
@@ -1365,18 +1370,19 @@ static int forward_v1_impl(moge_handle* h, const void* image, int img_dtype, con
         hh *= 2; ww *= 2;
         CHK(conv3x3<T>(h, T1, P<T>(h, S("v1.up%d.w3", i)), M(h, u + "0.1.bias"), X, B, hh, ww, co, co, 0, ACT_NONE, nullptr, nullptr, st));
         for (int j = 0; j < c.num_res_blocks; j++) {
-            // ResidualConvBlock (v1.py:44-58): GN(1) -> ReLU -> 3x3 -> GN(co/32) -> ReLU -> 3x3, + x
+            // ResidualConvBlock (v1.py:44-58): GN(1) -> ReLU -> 3x3 (co -> ch) -> GN(ch / 32, or 1 for "layer_norm") -> ReLU -> 3x3 (ch -> co), + x
             const std::string r = u + S("%d.layers.", 1 + j);
+            const int ch = co * v1_mult(c);
             {
                 ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)B * hh * ww * co * 2 * sizeof(T));
                 LCHK(launch_groupnorm_relu<T>(X, T1, M(h, r + "0.weight"), M(h, r + "0.bias"), gns, B, hh, ww, co, 1, st));
             }
-            CHK(conv3x3<T>(h, T1, P<T>(h, S("v1.up%d.res%d.w1", i, j)), M(h, r + "2.bias"), T2, B, hh, ww, co, co, 0, ACT_NONE, nullptr, nullptr, st));
+            CHK(conv3x3<T>(h, T1, P<T>(h, S("v1.up%d.res%d.w1", i, j)), M(h, r + "2.bias"), T2, B, hh, ww, co, ch, 0, ACT_NONE, nullptr, nullptr, st));
             {
-                ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)B * hh * ww * co * 2 * sizeof(T));
-                LCHK(launch_groupnorm_relu<T>(T2, T1, M(h, r + "3.weight"), M(h, r + "3.bias"), gns, B, hh, ww, co, co / 32 > 0 ? co / 32 : 1, st));
+                ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)B * hh * ww * ch * 2 * sizeof(T));
+                LCHK(launch_groupnorm_relu<T>(T2, T1, M(h, r + "3.weight"), M(h, r + "3.bias"), gns, B, hh, ww, ch, v1_hidden_groups(c, ch), st));
             }
-            CHK(conv3x3<T>(h, T1, P<T>(h, S("v1.up%d.res%d.w2", i, j)), M(h, r + "5.bias"), X, B, hh, ww, co, co, 0, ACT_NONE, X, nullptr, st));
+            CHK(conv3x3<T>(h, T1, P<T>(h, S("v1.up%d.res%d.w2", i, j)), M(h, r + "5.bias"), X, B, hh, ww, ch, co, 0, ACT_NONE, X, nullptr, st));
         }
         x = X; ci = co;
     }
@@ -1473,6 +1479,12 @@ int moge_create_v1(const moge_v1_config* cfg, int device, moge_handle** out) {
     if (c.last_conv_channels != 32 && c.last_conv_channels != 64 && c.last_conv_channels != 16)
         return fail(MOGE_ERR_INVALID, "last_conv_channels must be 16, 32 or 64");
     if (c.num_res_blocks < 0 || c.num_res_blocks > 8) return fail(MOGE_ERR_INVALID, "bad num_res_blocks");
+    if (c.hidden_mult < 0 || c.hidden_mult > 8) return fail(MOGE_ERR_INVALID, "dim_times_res_block_hidden must be 1 ... 8 (0 = unset), got %d", c.hidden_mult);
+    if (c.res_block_norm != 0 && c.res_block_norm != MOGE_NORM_LAYER && c.res_block_norm != MOGE_NORM_GROUP) return fail(MOGE_ERR_INVALID, "res_block_norm must be group_norm or layer_norm");
+    for (int i = 0; i < c.n_up && c.num_res_blocks > 0; i++) {
+        const int ch = c.dim_upsample[i] * v1_mult(c);
+        if (ch > 1024 || (ch & (ch - 1))) return fail(MOGE_ERR_INVALID, "dim_upsample[%d] x dim_times_res_block_hidden = %d: the hidden norm's slabs need a power of two up to 1024", i, ch);
+    }
     HIPCHK(hipSetDevice(device));
     moge_handle* h = new moge_handle();
     h->version = 1;

@@ -35,14 +35,21 @@ class MoGeModel(_MoGeModelV2):
             raise ValueError(f"Invalid remap output type: {remap_output}")
         if encoder not in _VIT:
             raise NotImplementedError(f"backbone {encoder} is not supported (ViT-S/B/L-14 only)")
-        if res_block_norm != "group_norm" or dim_times_res_block_hidden != 1 or last_res_blocks != 0 or last_conv_size != 1:
-            raise NotImplementedError("only the released MoGe-1 head layout is implemented: group_norm res blocks, hidden = dim, no last res blocks, 1x1 last conv")
+        if last_res_blocks != 0 or last_conv_size != 1:
+            raise NotImplementedError("MoGe-1 output blocks: only the default layout (and configs/train/v1.json's) is implemented - no last res blocks, 1x1 last conv")
+        if res_block_norm not in ("group_norm", "layer_norm"):
+            raise NotImplementedError(f"res_block_norm {res_block_norm}: group_norm or layer_norm (v1.py:25)")
+        if not isinstance(dim_times_res_block_hidden, int) or not 1 <= dim_times_res_block_hidden <= 8:
+            raise NotImplementedError(f"dim_times_res_block_hidden {dim_times_res_block_hidden} unsupported (an integer 1 ... 8)")
         D, depth, heads = _VIT[encoder]
         taps = list(range(depth - intermediate_layers, depth)) if isinstance(intermediate_layers, int) else list(intermediate_layers)
         if not 1 <= len(dim_upsample) <= L.MOGE_V1_MAX_UP:
             raise NotImplementedError("1..4 upsample stages")
         if any(d not in (32, 64, 128, 256, 512) for d in dim_upsample):
             raise NotImplementedError(f"dim_upsample {list(dim_upsample)}: supported widths are 32, 64, 128, 256, 512 (GroupNorm slab kernels)")
+        if num_res_blocks > 0 and any(d * dim_times_res_block_hidden not in (32, 64, 128, 256, 512, 1024) for d in dim_upsample):
+            raise NotImplementedError(f"dim_upsample {list(dim_upsample)} x dim_times_res_block_hidden {dim_times_res_block_hidden}: "
+                                      f"hidden widths must be powers of two up to 1024 (GroupNorm slab kernels)")
         self.encoder = encoder
         self.remap_output = remap_output
         self.intermediate_layers = intermediate_layers
@@ -62,6 +69,8 @@ class MoGeModel(_MoGeModelV2):
         cfg.num_res_blocks, cfg.last_conv_channels = num_res_blocks, last_conv_channels
         cfg.remap_output = L.REMAP[remap_output]
         cfg.mask_threshold = float(mask_threshold)
+        cfg.hidden_mult = dim_times_res_block_hidden                                      # v1.py:85 (configs/train/v1.json:31 trains with 2)
+        cfg.res_block_norm = L.RES_NORM[res_block_norm]                                   # hidden norm: GroupNorm(Ch / 32, Ch) or GroupNorm(1, Ch), v1.py:47
         self._cfg = cfg
         self._bits = L.HEAD_POINTS | L.HEAD_MASK
         self._state = None

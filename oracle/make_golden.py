@@ -209,6 +209,14 @@ CASES += [
          kwargs=dict(use_fp16=False, resolution_level=3)),
     dict(name="v1_vitl_518", version="v1", config="moge-vitl", seed=0, sane=True, input="rand", input_seed=0, shape=[1, 3, 518, 518],
          kwargs=dict(use_fp16=False), stride=7),
+    # Head options beyond the class defaults (v1.py:69-71): dim_times_res_block_hidden 2 with two blocks per stage = the layout of the reference's own
+    # training recipe (configs/train/v1.json:27-36); 4x with res_block_norm = layer_norm; and that recipe at full size
+    dict(name="v1_tiny_hidden_x2", version="v1", config="tiny-v1-vits-x2", seed=2, sane=True, input_seed=14, shape=[2, 3, 98, 126],
+         kwargs=dict(num_tokens=120, use_fp16=False)),
+    dict(name="v1_tiny_hidden_x4_layer_norm", version="v1", config="tiny-v1-vits-x4-layer", seed=3, sane=True, input_seed=15, shape=[1, 3, 84, 112],
+         kwargs=dict(num_tokens=100, use_fp16=False)),
+    dict(name="v1_vitl_train_config_518", version="v1", config="moge-vitl-train-config", seed=0, sane=True, input="rand", input_seed=0, shape=[1, 3, 518, 518],
+         kwargs=dict(use_fp16=False), stride=7),
 ]
 
 
@@ -227,7 +235,7 @@ def case_state_dict(case: dict, cfg: dict):
 
 
 # the cases whose reference run takes more than a few seconds on 8 cores (the CPU suite replays the oracle on the fast ones only)
-SLOW_CASES = ("vits_house518", "vitb_normal_518_t3600", "vitl_518_t3600", "vitl_normal_518x1036", "vitl_normal_1036x518", "v1_vitl_518", "vitl_518_t3600_massive",
+SLOW_CASES = ("vits_house518", "vitb_normal_518_t3600", "vitl_518_t3600", "vitl_normal_518x1036", "vitl_normal_1036x518", "v1_vitl_518", "v1_vitl_train_config_518", "vitl_518_t3600_massive",
               "vitl_normal_518_t3600")
 
 

@@ -28,10 +28,13 @@ PATCH = O2.PATCH
 
 
 def make_config(encoder: str = "dinov2_vitl14", intermediate_layers=4, dim_proj: int = 512, dim_upsample=(256, 128, 128), num_res_blocks: int = 1,
-                remap_output: str = "exp", num_tokens_range=(1200, 2500), last_conv_channels: int = 32, mask_threshold: float = 0.5) -> dict:
-    """`model_config` of a MoGe-1 checkpoint (v1.py:148-163).  The released Ruicheng/moge-vitl uses the defaults below."""
+                remap_output: str = "exp", num_tokens_range=(1200, 2500), last_conv_channels: int = 32, mask_threshold: float = 0.5,
+                dim_times_res_block_hidden: int = 1, res_block_norm: str = "group_norm") -> dict:
+    """`model_config` of a MoGe-1 checkpoint (v1.py:148-163).  The defaults are the class's; what Ruicheng/moge-vitl carries lives in the
+    (unreachable) HF checkpoint - the repo's own training recipe configs/train/v1.json:27-36 uses dim_upsample [256, 128, 64],
+    dim_times_res_block_hidden 2, num_res_blocks 2 ("moge-vitl-train-config" below)."""
     return dict(encoder=encoder, intermediate_layers=intermediate_layers, dim_proj=dim_proj, dim_upsample=list(dim_upsample),
-                dim_times_res_block_hidden=1, num_res_blocks=num_res_blocks, remap_output=remap_output, res_block_norm="group_norm",
+                dim_times_res_block_hidden=dim_times_res_block_hidden, num_res_blocks=num_res_blocks, remap_output=remap_output, res_block_norm=res_block_norm,
                 num_tokens_range=list(num_tokens_range), last_res_blocks=0, last_conv_channels=last_conv_channels, last_conv_size=1,
                 mask_threshold=mask_threshold)
 
@@ -40,6 +43,10 @@ def named_configs() -> Dict[str, dict]:
     return {
         "moge-vitl": make_config(),
         "tiny-v1-vits": make_config("dinov2_vits14", 4, 128, (64, 64, 32), 1, "exp", (60, 200)),
+        # configs/train/v1.json:27-36 (the reference's own MoGe-1 recipe): hidden width 2x, two residual blocks per stage
+        "moge-vitl-train-config": make_config("dinov2_vitl14", 4, 512, (256, 128, 64), 2, "exp", (1200, 2500), dim_times_res_block_hidden=2),
+        "tiny-v1-vits-x2": make_config("dinov2_vits14", 4, 128, (64, 64, 32), 2, "exp", (60, 200), dim_times_res_block_hidden=2),
+        "tiny-v1-vits-x4-layer": make_config("dinov2_vits14", 4, 128, (64, 32, 32), 1, "exp", (60, 200), dim_times_res_block_hidden=4, res_block_norm="layer_norm"),
     }
 
 
@@ -68,10 +75,11 @@ def state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
     for i, (ci, co) in enumerate(zip([P] + ups[:-1], ups)):
         u = f"head.upsample_blocks.{i}."
         out += [(u + "0.0.weight", (ci + 2, co, 2, 2)), (u + "0.0.bias", (co,)), (u + "0.1.weight", (co, co, 3, 3)), (u + "0.1.bias", (co,))]
+        ch = co * cfg.get("dim_times_res_block_hidden", 1)          # hidden width (v1.py:85)
         for j in range(cfg["num_res_blocks"]):
             r = f"{u}{1 + j}.layers."
-            out += [(r + "0.weight", (co,)), (r + "0.bias", (co,)), (r + "2.weight", (co, co, 3, 3)), (r + "2.bias", (co,)),
-                    (r + "3.weight", (co,)), (r + "3.bias", (co,)), (r + "5.weight", (co, co, 3, 3)), (r + "5.bias", (co,))]
+            out += [(r + "0.weight", (co,)), (r + "0.bias", (co,)), (r + "2.weight", (ch, co, 3, 3)), (r + "2.bias", (ch,)),
+                    (r + "3.weight", (ch,)), (r + "3.bias", (ch,)), (r + "5.weight", (co, ch, 3, 3)), (r + "5.bias", (co,))]
     for o, dim_out in enumerate((3, 1)):
         b = f"head.output_block.{o}."
         out += [(b + "0.weight", (c4, ups[-1] + 2, 3, 3)), (b + "0.bias", (c4,)), (b + "2.weight", (dim_out, c4, 1, 1)), (b + "2.bias", (dim_out,))]
@@ -133,11 +141,11 @@ def resized_dims(H: int, W: int, num_tokens: int) -> Tuple[int, int]:
     return int(H * f), int(W * f)
 
 
-def res_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str) -> torch.Tensor:
-    C = x.shape[1]
+def res_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str, norm: str = "group_norm") -> torch.Tensor:
+    """v1.py:44-58: GroupNorm(1, C) -> ReLU -> 3x3 (C -> Ch) -> GroupNorm(Ch // 32 | 1, Ch) -> ReLU -> 3x3 (Ch -> C), + x; Ch = the conv's own width"""
     h = F.relu(F.group_norm(x, 1, sd[p + "0.weight"], sd[p + "0.bias"]))
     h = F.conv2d(F.pad(h, (1, 1, 1, 1), mode="replicate"), sd[p + "2.weight"], sd[p + "2.bias"])
-    h = F.relu(F.group_norm(h, C // 32, sd[p + "3.weight"], sd[p + "3.bias"]))
+    h = F.relu(F.group_norm(h, h.shape[1] // 32 if norm == "group_norm" else 1, sd[p + "3.weight"], sd[p + "3.bias"]))
     h = F.conv2d(F.pad(h, (1, 1, 1, 1), mode="replicate"), sd[p + "5.weight"], sd[p + "5.bias"])
     return h + x
 
@@ -180,7 +188,7 @@ def forward(cfg: dict, sd: Dict[str, torch.Tensor], image: torch.Tensor, num_tok
         x = F.conv_transpose2d(x, sd[u + "0.0.weight"], sd[u + "0.0.bias"], stride=2)
         x = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), sd[u + "0.1.weight"], sd[u + "0.1.bias"])
         for j in range(cfg["num_res_blocks"]):
-            x = res_block(x, sd, f"{u}{1 + j}.layers.")
+            x = res_block(x, sd, f"{u}{1 + j}.layers.", cfg.get("res_block_norm", "group_norm"))
         if trace is not None:
             trace[f"up{i}"] = x
     x = F.interpolate(x, (rh, rw), mode="bilinear", align_corners=False)

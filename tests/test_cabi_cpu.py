@@ -90,6 +90,33 @@ def test_mirror_maps_every_convstack_option_it_supports():
         M(**wide)
 
 
+def test_v1_mirror_maps_the_head_options():
+    """v1.py:62-75: dim_times_res_block_hidden (configs/train/v1.json:31 trains with 2) and res_block_norm reach the C ABI; the output-block
+    options no config uses (last_res_blocks, last_conv_size 3) are refused at construction."""
+    from moge_amd import _lib as L
+    from moge_amd.model import import_model_class_by_version
+    from oracle import moge_oracle_v1 as O1
+    M1 = import_model_class_by_version("v1")
+    rel = M1(**O1.named_configs()["moge-vitl"])._cfg
+    assert (rel.hidden_mult, rel.res_block_norm) == (1, L.RES_NORM["group_norm"])
+    tr = M1(**O1.named_configs()["moge-vitl-train-config"])._cfg
+    assert (tr.hidden_mult, tr.num_res_blocks, list(tr.dim_upsample)[:3]) == (2, 2, [256, 128, 64])
+    x4 = M1(**O1.named_configs()["tiny-v1-vits-x4-layer"])._cfg
+    assert (x4.hidden_mult, x4.res_block_norm) == (4, L.RES_NORM["layer_norm"])
+    base = O1.named_configs()["tiny-v1-vits"]
+    for key, value in (("last_res_blocks", 1), ("last_conv_size", 3), ("res_block_norm", "instance_norm"), ("dim_times_res_block_hidden", 3),
+                       ("dim_times_res_block_hidden", 0)):
+        with pytest.raises(NotImplementedError):
+            M1(**{**base, key: value})
+    with pytest.raises(NotImplementedError):                                  # 512 x 4 = 2048 > 1024: the hidden norm's slab kernels
+        M1(**{**O1.named_configs()["moge-vitl"], "dim_upsample": [512, 128, 64], "dim_times_res_block_hidden": 4})
+    cfg = L.MogeV1Config()
+    cfg.embed_dim, cfg.num_heads, cfg.depth, cfg.n_taps, cfg.dim_proj, cfg.n_up = 384, 6, 12, 1, 128, 1
+    cfg.dim_upsample[0], cfg.last_conv_channels, cfg.num_res_blocks, cfg.hidden_mult = 64, 32, 1, 3
+    h = ctypes.c_void_p()
+    assert L.lib.moge_create_v1(ctypes.byref(cfg), 0, ctypes.byref(h)) == -1 and b"power of two" in L.lib.moge_last_error()
+
+
 def test_create_rejects_bad_config_without_gpu():
     from moge_amd import _lib as L
     cfg = L.MogeConfig()
