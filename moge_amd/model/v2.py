@@ -170,6 +170,32 @@ class MoGeModel:
     def requires_grad_(self, flag: bool = False) -> "MoGeModel":
         return self
 
+    def enable_pytorch_native_sdpa(self):
+        """v2.py:119-120 swaps the DINOv2 attention for torch's fused SDPA; the attention here IS a fused kernel (csrc/attention_pp.hip): nothing to do."""
+
+    def enable_gradient_checkpointing(self):
+        """v2.py:112-117: a training-memory switch with no effect on results; inference-only here, accepted and ignored."""
+        warnings.warn("moge_amd is inference-only: enable_gradient_checkpointing() has no effect")
+
+    def init_weights(self):
+        """v2.py:109-110 downloads the pretrained DINOv2 backbone to START training from."""
+        raise NotImplementedError("moge_amd is inference-only: load a trained checkpoint with from_pretrained()")
+
+    def _remap_points(self, points: torch.Tensor) -> torch.Tensor:
+        """v2.py:122-136 (applied inside `moge_forward` on the product path; this is the same map for callers that hold raw head outputs)."""
+        if self.remap_output == "linear":
+            return points
+        if self.remap_output == "sinh":
+            return torch.sinh(points)
+        if self.remap_output == "exp":
+            xy, z = points.split([2, 1], dim=-1)
+            z = torch.exp(z)
+            return torch.cat([xy * z, z], dim=-1)
+        if self.remap_output == "sinh_exp":
+            xy, z = points.split([2, 1], dim=-1)
+            return torch.cat([torch.sinh(xy), torch.exp(z)], dim=-1)
+        raise ValueError(f"Invalid remap output type: {self.remap_output}")
+
     def half(self) -> "MoGeModel":
         return self.to(torch.float16)
 

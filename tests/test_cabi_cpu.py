@@ -45,6 +45,18 @@ def test_model_mirror_host_logic():
         M(**{**O.named_configs()["tiny-vits-normal"], "remap_output": "bogus"})
     with pytest.raises(RuntimeError):
         m.to("cpu")            # no CPU fallback, by design
+    # the rest of the class surface (v2.py:109-136, v1.py:244-267): training switches are accepted / refused, the remap is the reference's
+    import torch
+    assert m.enable_pytorch_native_sdpa() is None
+    with pytest.warns(UserWarning):
+        m.enable_gradient_checkpointing()
+    with pytest.raises(NotImplementedError):
+        m1.init_weights()
+    p = torch.tensor([[0.3, -0.2, 0.5]])
+    assert torch.allclose(m._remap_points(p), torch.tensor([[0.3 * 0.5 ** 0 * torch.e ** 0.5, -0.2 * torch.e ** 0.5, torch.e ** 0.5]]))       # 'exp'
+    for mode, want in (("linear", p), ("sinh", torch.sinh(p)), ("sinh_exp", torch.cat([torch.sinh(p[:, :2]), torch.exp(p[:, 2:])], -1))):
+        mm = M(**{**O.named_configs()["tiny-vits-normal"], "remap_output": mode})
+        assert torch.allclose(mm._remap_points(p), want) and torch.allclose(O.remap_points(p, mode), want)
 
 
 def test_mirror_maps_every_convstack_option_it_supports():
