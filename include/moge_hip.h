@@ -86,9 +86,10 @@ typedef struct moge_config {
     int32_t neck_hidden_mult, head_hidden_mult; /* dim_times_res_block_hidden (0 reads as 1) modules.py:199, 222           */
 } moge_config;
 
-/* Mirrors the `model_config` of a MoGe-1 checkpoint (moge/model/v1.py:148-163).  Supported: group_norm / layer_norm residual
- * blocks, dim_times_res_block_hidden 1 ... 8 (configs/train/v1.json:31 trains with 2), last_res_blocks 0, last_conv_size 1 (the defaults, and
- * what configs/train/v1.json uses), head outputs [3 (points), 1 (mask)]. */
+/* Mirrors the `model_config` of a MoGe-1 checkpoint (moge/model/v1.py:148-163): group_norm / layer_norm residual blocks,
+ * dim_times_res_block_hidden 1 ... 8 (configs/train/v1.json:31 trains with 2), last_res_blocks 0 ... 8, last_conv_size 1 or 3, head outputs
+ * [3 (points), 1 (mask)].  The default output block (no last residual blocks, 1x1 last conv: also what configs/train/v1.json uses) runs fused;
+ * the other layouts run per output on the generic kernels. */
 #define MOGE_V1_MAX_UP 4
 typedef struct moge_v1_config {
     int32_t embed_dim, depth, num_heads;      /* ViT (head_dim 64)                                                          */
@@ -103,6 +104,8 @@ typedef struct moge_v1_config {
     float mask_threshold;                     /* validity = raw mask output > mask_threshold            v1.py:358           */
     int32_t hidden_mult;                      /* dim_times_res_block_hidden (0 reads as 1)              v1.py:69, 85        */
     int32_t res_block_norm;                   /* hidden norm: MOGE_NORM_GROUP (or 0) = GroupNorm(Ch / 32, Ch), MOGE_NORM_LAYER = GroupNorm(1, Ch)   v1.py:47 */
+    int32_t last_res_blocks;                  /* ResidualConvBlocks inside each output block            v1.py:106           */
+    int32_t last_conv_size;                   /* kernel of the last conv, 1 or 3 (0 reads as 1)         v1.py:108           */
 } moge_v1_config;
 
 /* One state-dict entry handed to moge_load_weights: fp32, contiguous, host memory. */

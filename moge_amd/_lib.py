@@ -41,7 +41,7 @@ class MogeV1Config(C.Structure):
     _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32), ("n_taps", C.c_int32),
                 ("taps", C.c_int32 * MOGE_MAX_TAPS), ("dim_proj", C.c_int32), ("n_up", C.c_int32), ("dim_upsample", C.c_int32 * MOGE_V1_MAX_UP),
                 ("num_res_blocks", C.c_int32), ("last_conv_channels", C.c_int32), ("remap_output", C.c_int32), ("mask_threshold", C.c_float),
-                ("hidden_mult", C.c_int32), ("res_block_norm", C.c_int32)]
+                ("hidden_mult", C.c_int32), ("res_block_norm", C.c_int32), ("last_res_blocks", C.c_int32), ("last_conv_size", C.c_int32)]
 
 
 class TensorDesc(C.Structure):

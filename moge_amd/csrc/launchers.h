@@ -37,6 +37,8 @@ int launch_head_final_dot(int kind, const float* y, const float* z, int zld, int
                           int remap, hipStream_t st);
 
 template <typename T>
+int launch_head_final_k3(int kind, const void* x4, const float* w, const float* bias, float* out, int B, int Hd, int Wd, int C, int H, int W, int remap, hipStream_t st);
+template <typename T>
 int launch_head_final(int kind, const void* x4, const float* w, const float* bias, const void* n4, const float* w2, float* out, int B, int Hd,
                       int Wd, int C, int H, int W, int remap, hipStream_t st, int ld = 0);      // ld: channel pitch of x4 / n4 (0 = C)
 int launch_mlp_layer(const float* in, const float* W, const float* bias, float* out, int B, int K, int N, int act, hipStream_t st);

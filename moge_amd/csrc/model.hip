@@ -1207,6 +1207,8 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
 // ============================================================================================================================
 static int v1_cpad(int c) { return (c + 2 + 7) / 8 * 8; }            // channels + (u, v), padded to 16-byte chunks in both storage types
 static int v1_mult(const moge_v1_config& c) { return c.hidden_mult > 0 ? c.hidden_mult : 1; }                          // dim_times_res_block_hidden (v1.py:85)
+static int v1_ks(const moge_v1_config& c) { return c.last_conv_size == 3 ? 3 : 1; }
+static bool v1_generic_out(const moge_v1_config& c) { return c.last_res_blocks > 0 || v1_ks(c) == 3; }      // output blocks beyond [3x3 -> ReLU -> 1x1] (v1.py:103-109)
 static int v1_hidden_groups(const moge_v1_config& c, int ch) { return c.res_block_norm == MOGE_NORM_LAYER ? 1 : (ch / 32 > 0 ? ch / 32 : 1); }     // v1.py:47
 
 static void build_tables_v1_decoder(moge_handle* h) {
@@ -1231,10 +1233,21 @@ static void build_tables_v1_decoder(moge_handle* h) {
         }
     }
     const int cl = c.dim_upsample[c.n_up - 1], c4 = c.last_conv_channels;
+    const int nl = c.last_res_blocks, ks = v1_ks(c), ch4 = c4 * v1_mult(c);
     for (int o = 0; o < 2; o++) {
+        // nn.Sequential(3x3, ResidualConvBlock x last_res_blocks, ReLU, Conv2d(k = last_conv_size))   (v1.py:103-109)
         const std::string b = S("head.output_block.%d.", o);
         tadd(h, b + "0.weight", (int64_t)c4 * (cl + 2) * 9); tadd(h, b + "0.bias", c4);
-        tadd(h, b + "2.weight", (int64_t)(o == 0 ? 3 : 1) * c4); tadd(h, b + "2.bias", o == 0 ? 3 : 1);
+        for (int j = 0; j < nl; j++) {
+            const std::string r = b + S("%d.layers.", 1 + j);
+            tadd(h, r + "0.weight", c4); tadd(h, r + "0.bias", c4);
+            tadd(h, r + "2.weight", (int64_t)ch4 * c4 * 9); tadd(h, r + "2.bias", ch4);
+            tadd(h, r + "3.weight", ch4); tadd(h, r + "3.bias", ch4);
+            tadd(h, r + "5.weight", (int64_t)c4 * ch4 * 9); tadd(h, r + "5.bias", c4);
+            padd(h, S("v1.out%d.res%d.w1", o, j), (int64_t)ch4 * 9 * c4);
+            padd(h, S("v1.out%d.res%d.w2", o, j), (int64_t)c4 * 9 * ch4);
+        }
+        tadd(h, b + S("%d.weight", nl + 2), (int64_t)(o == 0 ? 3 : 1) * c4 * ks * ks); tadd(h, b + S("%d.bias", nl + 2), o == 0 ? 3 : 1);
     }
     padd(h, "v1.out.w3", (int64_t)2 * c4 * 9 * v1_cpad(cl));
     aadd(h, "v1.out.bias", 2 * c4);
@@ -1274,9 +1287,15 @@ static int pack_weights_v1(moge_handle* h, hipStream_t st) {
             LCHK(conv3(M(h, r + "5.weight"), Pm<T>(h, S("v1.up%d.res%d.w2", i, j)), co, ch, ch));
         }
     }
-    const int cl = c.dim_upsample[c.n_up - 1], c4 = c.last_conv_channels, cp = v1_cpad(cl);
-    for (int o = 0; o < 2; o++)
+    const int cl = c.dim_upsample[c.n_up - 1], c4 = c.last_conv_channels, cp = v1_cpad(cl), ch4 = c4 * v1_mult(c);
+    for (int o = 0; o < 2; o++) {
         LCHK(conv3(M(h, S("head.output_block.%d.0.weight", o)), Pm<T>(h, "v1.out.w3") + (size_t)o * c4 * 9 * cp, c4, cl + 2, cp));
+        for (int j = 0; j < c.last_res_blocks; j++) {
+            const std::string r = S("head.output_block.%d.%d.layers.", o, 1 + j);
+            LCHK(conv3(M(h, r + "2.weight"), Pm<T>(h, S("v1.out%d.res%d.w1", o, j)), ch4, c4, c4));
+            LCHK(conv3(M(h, r + "5.weight"), Pm<T>(h, S("v1.out%d.res%d.w2", o, j)), c4, ch4, ch4));
+        }
+    }
     return 0;
 }
 
@@ -1284,6 +1303,7 @@ struct PlanV1 {
     Plan p;                       // encoder buffers + the caller-visible post buffers (same fields as MoGe-2)
     int rh, rw;                   // resized image (v1.py:272-274)
     size_t img1, X, T1, T2, R, Y, gn;
+    size_t La, Lb;                // generic output blocks only: norm output (c4) and hidden map (k c4) at the resized image's size
 };
 static PlanV1 make_plan_v1(moge_handle* h, int prec, int B, int H, int W, int rh, int rw) {
     const moge_config& c = h->cfg;
@@ -1330,6 +1350,16 @@ static PlanV1 make_plan_v1(moge_handle* h, int prec, int B, int H, int W, int rh
     const size_t rpx = (size_t)B * rh * rw;
     v.R = take(p, rpx * v1_cpad(c1.dim_upsample[c1.n_up - 1]) * s);
     v.Y = take(p, rpx * 2 * c1.last_conv_channels * s);
+    v.La = v.Lb = 0;
+    if (v1_generic_out(c1)) {
+        const int c4 = c1.last_conv_channels, ch4 = c4 * v1_mult(c1);
+        if (c1.last_res_blocks > 0) {
+            v.La = take(p, rpx * c4 * s);
+            v.Lb = take(p, rpx * ch4 * s);
+            const size_t gsz = groupnorm_scratch_floats(B, rh, rw, v1_hidden_groups(c1, ch4));
+            if (gsz > gnmax) gnmax = gsz;
+        }
+    }
     v.gn = take(p, gnmax * 4);
     return v;
 }
@@ -1395,6 +1425,47 @@ static int forward_v1_impl(moge_handle* h, const void* image, int img_dtype, con
         const UVTerm uv = uv_term(nullptr, nullptr, rw, rh, aspect);
         LCHK(launch_resize_bilinear_uv<T>(x, R, B, hh, ww, cl, rh, rw, cp, uv.u0, uv.u1, uv.v0, uv.v1, st));
     }
+    if (v1_generic_out(c)) {
+        // output blocks with residual blocks and / or a 3x3 last conv (v1.py:103-109), one output at a time on dense c4-channel maps (the two
+        // halves of Y): 3x3 -> [GN(1) -> ReLU -> 3x3 -> GN -> ReLU -> 3x3, + x] x n -> ReLU -> last conv; the resize back + remap stay in head_final
+        const int nl = c.last_res_blocks, ks = v1_ks(c), ch4 = c4 * v1_mult(c);
+        const size_t rpx = (size_t)B * rh * rw;
+        T* La = (T*)(ws + v.La); T* Lb = (T*)(ws + v.Lb);
+        float* gns = (float*)(ws + v.gn);
+        for (int o = 0; o < 2; o++) {
+            float* dst = o == 0 ? o_points : o_mask;
+            if (!dst) continue;
+            T* Yo = Y + (size_t)o * rpx * c4;
+            CHK(conv3x3<T>(h, R, P<T>(h, "v1.out.w3") + (size_t)o * c4 * 9 * cp, A(h, "v1.out.bias") + o * c4, Yo, B, rh, rw, cp, c4, 0, nl ? ACT_NONE : ACT_RELU, nullptr, nullptr, st));
+            for (int j = 0; j < nl; j++) {
+                const std::string r = S("head.output_block.%d.%d.layers.", o, 1 + j);
+                {
+                    ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)rpx * c4 * 2 * sizeof(T));
+                    LCHK(launch_groupnorm_relu<T>(Yo, La, M(h, r + "0.weight"), M(h, r + "0.bias"), gns, B, rh, rw, c4, 1, st));
+                }
+                CHK(conv3x3<T>(h, La, P<T>(h, S("v1.out%d.res%d.w1", o, j)), M(h, r + "2.bias"), Lb, B, rh, rw, c4, ch4, 0, ACT_NONE, nullptr, nullptr, st));
+                {
+                    ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)rpx * ch4 * 2 * sizeof(T));
+                    LCHK(launch_groupnorm_act<T>(Lb, Lb, M(h, r + "3.weight"), M(h, r + "3.bias"), gns, B, rh, rw, ch4, v1_hidden_groups(c, ch4), MOGE_ACT_RELU, st));
+                }
+                CHK(conv3x3<T>(h, Lb, P<T>(h, S("v1.out%d.res%d.w2", o, j)), M(h, r + "5.bias"), Yo, B, rh, rw, ch4, c4, 0, ACT_NONE, Yo, nullptr, st));
+            }
+            if (nl) {
+                ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)rpx * c4 * 2 * sizeof(T));
+                LCHK(launch_groupnorm_act<T>(Yo, Yo, nullptr, nullptr, nullptr, B, rh, rw, c4, 0, MOGE_ACT_RELU, st));       // the ReLU in front of the last conv
+            }
+            const std::string lk = S("head.output_block.%d.%d.", o, nl + 2);
+            const int kind = o == 0 ? 0 : 3, remap = o == 0 ? c.remap_output : 0;
+            if (ks == 1) {
+                ProfScope ps(h, st, MOGE_KC_POST, 0, (double)rpx * c4 * sizeof(T));
+                LCHK(launch_head_final<T>(kind, Yo, M(h, lk + "weight"), M(h, lk + "bias"), nullptr, nullptr, dst, B, rh, rw, c4, pl.H, pl.W, remap, st, c4));
+            } else {
+                // the 3x3 last conv (replicate padding) evaluated inside the resize: fp32 weights straight from the master, no intermediate map
+                ProfScope ps(h, st, MOGE_KC_POST, 2.0 * B * pl.H * pl.W * 36.0 * c4 * (o == 0 ? 3 : 1), (double)rpx * c4 * sizeof(T));
+                LCHK(launch_head_final_k3<T>(kind, Yo, M(h, lk + "weight"), M(h, lk + "bias"), dst, B, rh, rw, c4, pl.H, pl.W, remap, st));
+            }
+        }
+    } else {
     CHK(conv3x3<T>(h, R, P<T>(h, "v1.out.w3"), A(h, "v1.out.bias"), Y, B, rh, rw, cp, 2 * c4, 0, ACT_RELU, nullptr, nullptr, st));
     {
         ProfScope ps(h, st, MOGE_KC_POST, 0, (double)B * rh * rw * 2 * c4 * sizeof(T));
@@ -1404,6 +1475,7 @@ static int forward_v1_impl(moge_handle* h, const void* image, int img_dtype, con
         if (o_mask)
             LCHK(launch_head_final<T>(3, Y + c4, M(h, "head.output_block.1.2.weight"), M(h, "head.output_block.1.2.bias"), nullptr, nullptr, o_mask, B, rh, rw, c4,
                                       pl.H, pl.W, 0, st, 2 * c4));
+    }
     }
     h->last.valid = true; h->last.prec = TT<T>::PREC; h->last.B = B; h->last.rows = ph; h->last.cols = pw;
     h->last.bufs.clear();
@@ -1479,6 +1551,13 @@ int moge_create_v1(const moge_v1_config* cfg, int device, moge_handle** out) {
     if (c.last_conv_channels != 32 && c.last_conv_channels != 64 && c.last_conv_channels != 16)
         return fail(MOGE_ERR_INVALID, "last_conv_channels must be 16, 32 or 64");
     if (c.num_res_blocks < 0 || c.num_res_blocks > 8) return fail(MOGE_ERR_INVALID, "bad num_res_blocks");
+    if (c.last_res_blocks < 0 || c.last_res_blocks > 8) return fail(MOGE_ERR_INVALID, "bad last_res_blocks");
+    if (c.last_conv_size != 0 && c.last_conv_size != 1 && c.last_conv_size != 3) return fail(MOGE_ERR_INVALID, "last_conv_size must be 1 or 3");
+    if (c.last_res_blocks > 0) {
+        const int ch4 = c.last_conv_channels * (c.hidden_mult > 0 ? c.hidden_mult : 1);
+        if (c.last_conv_channels < 32 || ch4 > 1024 || (ch4 & (ch4 - 1)))
+            return fail(MOGE_ERR_INVALID, "last residual blocks need last_conv_channels 32 or 64 and a power-of-two hidden width up to 1024 (got %d, hidden %d)", c.last_conv_channels, ch4);
+    }
     if (c.hidden_mult < 0 || c.hidden_mult > 8) return fail(MOGE_ERR_INVALID, "dim_times_res_block_hidden must be 1 ... 8 (0 = unset), got %d", c.hidden_mult);
     if (c.res_block_norm != 0 && c.res_block_norm != MOGE_NORM_LAYER && c.res_block_norm != MOGE_NORM_GROUP) return fail(MOGE_ERR_INVALID, "res_block_norm must be group_norm or layer_norm");
     for (int i = 0; i < c.n_up && c.num_res_blocks > 0; i++) {

@@ -221,6 +221,94 @@ int launch_head_final(int kind, const void* x4, const float* w, const float* bia
 template int launch_head_final<f16>(int, const void*, const float*, const float*, const void*, const float*, float*, int, int, int, int, int, int, int, hipStream_t, int);
 template int launch_head_final<float>(int, const void*, const float*, const float*, const void*, const float*, float*, int, int, int, int, int, int, int, hipStream_t, int);
 
+// head_final with a 3x3 last conv (MoGe-1 `last_conv_size` 3, v1.py:108: replicate padding): out = remap(resize(conv3x3(x) + bias)).  Resize and conv
+// are both linear: every output pixel takes its four bilinear taps of the conv evaluated on the fly (4 x 9 positions x C channels, fp32 weights in
+// LDS in the checkpoint's own [CO][C][3][3] layout) - no intermediate map, no rounding between the conv and the resize.
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void head_final_k3_kernel(const T* __restrict__ x4, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out,
+                                                            int B, int Hd, int Wd, int C, int H, int W, int remap) {
+    constexpr int CH = TT<T>::CH;
+    constexpr int CO = (KIND == 2 || KIND == 3) ? 1 : 3;
+    __shared__ float sw[3 * 64 * 9];
+    for (int i = threadIdx.x; i < CO * C * 9; i += 256) sw[i] = w[i];
+    __syncthreads();
+    const long total = (long)B * H * W;
+    const float sy_scale = (float)Hd / (float)H, sx_scale = (float)Wd / (float)W;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ox = idx % W;
+        const long t = idx / W;
+        const int oy = t % H, b = t / H;
+        float sy = sy_scale * (oy + 0.5f) - 0.5f, sx = sx_scale * (ox + 0.5f) - 0.5f;
+        sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx;
+        int y0 = (int)sy, x0 = (int)sx;
+        y0 = y0 < Hd - 1 ? y0 : Hd - 1; x0 = x0 < Wd - 1 ? x0 : Wd - 1;
+        const int y1 = y0 + 1 < Hd ? y0 + 1 : Hd - 1, x1 = x0 + 1 < Wd ? x0 + 1 : Wd - 1;
+        float ly = sy - y0, lx = sx - x0;
+        ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
+        const float wt[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
+        const int ty[4] = {y0, y0, y1, y1}, tx[4] = {x0, x1, x0, x1};
+        const T* base = x4 + (size_t)b * Hd * Wd * C;
+        float o[CO];
+#pragma unroll
+        for (int j = 0; j < CO; j++) o[j] = bias[j];
+        for (int k = 0; k < 4; k++) {
+            if (wt[k] == 0.f) continue;
+            float acc[CO];
+#pragma unroll
+            for (int j = 0; j < CO; j++) acc[j] = 0.f;
+            for (int dy = -1; dy <= 1; dy++) {
+                int py = ty[k] + dy; py = py < 0 ? 0 : (py > Hd - 1 ? Hd - 1 : py);
+                for (int dx = -1; dx <= 1; dx++) {
+                    int px = tx[k] + dx; px = px < 0 ? 0 : (px > Wd - 1 ? Wd - 1 : px);
+                    const T* p = base + ((size_t)py * Wd + px) * C;
+                    const int tap = (dy + 1) * 3 + dx + 1;
+                    for (int c0 = 0; c0 < C; c0 += CH) {
+                        float f[CH];
+                        const u32x4 a = *reinterpret_cast<const u32x4*>(p + c0);
+                        if constexpr (CH == 8) {
+                            const f16x8 va = __builtin_bit_cast(f16x8, a);
+#pragma unroll
+                            for (int i = 0; i < CH; i++) f[i] = (float)va[i];
+                        } else {
+                            const f32x4 va = __builtin_bit_cast(f32x4, a);
+#pragma unroll
+                            for (int i = 0; i < CH; i++) f[i] = va[i];
+                        }
+#pragma unroll
+                        for (int j = 0; j < CO; j++)
+#pragma unroll
+                            for (int i = 0; i < CH; i++) acc[j] = fmaf(sw[(j * C + c0 + i) * 9 + tap], f[i], acc[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CO; j++) o[j] = fmaf(wt[k], acc[j], o[j]);
+        }
+        if (KIND == 0) {
+            float x = o[0], y = o[1], z = o[2];
+            if (remap == MOGE_REMAP_EXP) { z = expf(z); x *= z; y *= z; }
+            else if (remap == MOGE_REMAP_SINH) { x = sinhf(x); y = sinhf(y); z = sinhf(z); }
+            else if (remap == MOGE_REMAP_SINH_EXP) { x = sinhf(x); y = sinhf(y); z = expf(z); }
+            out[idx * 3] = x; out[idx * 3 + 1] = y; out[idx * 3 + 2] = z;
+        } else {
+            out[idx] = o[0];
+        }
+    }
+}
+// kind 0: points (3 channels + remap), kind 3: raw mask (1 channel); x (B,Hd,Wd,C) dense, C <= 64
+template <typename T>
+int launch_head_final_k3(int kind, const void* x4, const float* w, const float* bias, float* out, int B, int Hd, int Wd, int C, int H, int W, int remap, hipStream_t st) {
+    if (C > 64 || C % TT<T>::CH != 0 || (kind != 0 && kind != 3)) return -1;
+    const long total = (long)B * H * W;
+    long nb = (total + 255) / 256;
+    const int blocks = (int)(nb > 65536 ? 65536 : nb);
+    if (kind == 0) hipLaunchKernelGGL((head_final_k3_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const T*)x4, w, bias, out, B, Hd, Wd, C, H, W, remap);
+    else hipLaunchKernelGGL((head_final_k3_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, (const T*)x4, w, bias, out, B, Hd, Wd, C, H, W, remap);
+    return (int)hipGetLastError();
+}
+template int launch_head_final_k3<f16>(int, const void*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+template int launch_head_final_k3<float>(int, const void*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+
 // head_final on the maps of the fused output conv (conv_pp.hip, EPI bit 5): the 1x1 output conv (modules.py:231) and the pre-composed level-4
 // input block (modules.py:245) were applied per high-res pixel by the resampler kernels, so what is left is 4 + 4 floats per tap:
 // bilinear resize (v2.py:170; linear: it commutes with the convs), bias, remap (v2.py:173-180).  One thread per output pixel.

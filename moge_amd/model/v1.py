@@ -35,10 +35,13 @@ class MoGeModel(_MoGeModelV2):
             raise ValueError(f"Invalid remap output type: {remap_output}")
         if encoder not in _VIT:
             raise NotImplementedError(f"backbone {encoder} is not supported (ViT-S/B/L-14 only)")
-        if last_res_blocks != 0 or last_conv_size != 1:
-            raise NotImplementedError("MoGe-1 output blocks: only the default layout (and configs/train/v1.json's) is implemented - no last res blocks, 1x1 last conv")
+        if not isinstance(last_res_blocks, int) or not 0 <= last_res_blocks <= 8 or last_conv_size not in (1, 3):
+            raise NotImplementedError(f"MoGe-1 output blocks: last_res_blocks 0 ... 8 and last_conv_size 1 or 3 (got {last_res_blocks}, {last_conv_size})")
         if res_block_norm not in ("group_norm", "layer_norm"):
             raise NotImplementedError(f"res_block_norm {res_block_norm}: group_norm or layer_norm (v1.py:25)")
+        if last_res_blocks > 0 and (last_conv_channels not in (32, 64) or last_conv_channels * (dim_times_res_block_hidden if isinstance(dim_times_res_block_hidden, int) else 1)
+                                    not in (32, 64, 128, 256, 512, 1024)):
+            raise NotImplementedError("last residual blocks need last_conv_channels 32 or 64 and a power-of-two hidden width up to 1024 (GroupNorm slab kernels)")
         if not isinstance(dim_times_res_block_hidden, int) or not 1 <= dim_times_res_block_hidden <= 8:
             raise NotImplementedError(f"dim_times_res_block_hidden {dim_times_res_block_hidden} unsupported (an integer 1 ... 8)")
         D, depth, heads = _VIT[encoder]
@@ -69,6 +72,7 @@ class MoGeModel(_MoGeModelV2):
         cfg.num_res_blocks, cfg.last_conv_channels = num_res_blocks, last_conv_channels
         cfg.remap_output = L.REMAP[remap_output]
         cfg.mask_threshold = float(mask_threshold)
+        cfg.last_res_blocks, cfg.last_conv_size = last_res_blocks, last_conv_size             # v1.py:103-109
         cfg.hidden_mult = dim_times_res_block_hidden                                      # v1.py:85 (configs/train/v1.json:31 trains with 2)
         cfg.res_block_norm = L.RES_NORM[res_block_norm]                                   # hidden norm: GroupNorm(Ch / 32, Ch) or GroupNorm(1, Ch), v1.py:47
         self._cfg = cfg

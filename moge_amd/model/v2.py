@@ -101,8 +101,10 @@ class MoGeModel:
                 continue
             r, rs, nm = _check_stack(name, sc, dims, False)
             do = sc.get("dim_out")
-            if not isinstance(do, (list, tuple)) or list(do[:4]) != [None] * 4 or do[4] != cout:
-                raise NotImplementedError(f"{name}: dim_out must be [null,null,null,null,{cout}]")
+            # only the LAST level's output is used (v2.py:166 takes `[-1]`); output convs a config declares at levels 0 ... 3 produce maps the
+            # reference computes and drops - their weights are accepted in the state dict and never read
+            if not isinstance(do, (list, tuple)) or len(do) != 5 or do[4] != cout or any(d is not None and (not isinstance(d, int) or d <= 0) for d in do[:4]):
+                raise NotImplementedError(f"{name}: dim_out must be a list of 5 ending in {cout} (levels 0 ... 3: null or a channel count)")
             if head_res is not None and (r != head_res or rs != head_rs or nm != head_norm):
                 raise NotImplementedError("all heads must share num_res_blocks, resamplers and residual-block options")
             head_res, head_rs, head_norm = r, rs, nm

@@ -29,13 +29,13 @@ PATCH = O2.PATCH
 
 def make_config(encoder: str = "dinov2_vitl14", intermediate_layers=4, dim_proj: int = 512, dim_upsample=(256, 128, 128), num_res_blocks: int = 1,
                 remap_output: str = "exp", num_tokens_range=(1200, 2500), last_conv_channels: int = 32, mask_threshold: float = 0.5,
-                dim_times_res_block_hidden: int = 1, res_block_norm: str = "group_norm") -> dict:
+                dim_times_res_block_hidden: int = 1, res_block_norm: str = "group_norm", last_res_blocks: int = 0, last_conv_size: int = 1) -> dict:
     """`model_config` of a MoGe-1 checkpoint (v1.py:148-163).  The defaults are the class's; what Ruicheng/moge-vitl carries lives in the
     (unreachable) HF checkpoint - the repo's own training recipe configs/train/v1.json:27-36 uses dim_upsample [256, 128, 64],
     dim_times_res_block_hidden 2, num_res_blocks 2 ("moge-vitl-train-config" below)."""
     return dict(encoder=encoder, intermediate_layers=intermediate_layers, dim_proj=dim_proj, dim_upsample=list(dim_upsample),
                 dim_times_res_block_hidden=dim_times_res_block_hidden, num_res_blocks=num_res_blocks, remap_output=remap_output, res_block_norm=res_block_norm,
-                num_tokens_range=list(num_tokens_range), last_res_blocks=0, last_conv_channels=last_conv_channels, last_conv_size=1,
+                num_tokens_range=list(num_tokens_range), last_res_blocks=last_res_blocks, last_conv_channels=last_conv_channels, last_conv_size=last_conv_size,
                 mask_threshold=mask_threshold)
 
 
@@ -47,6 +47,10 @@ def named_configs() -> Dict[str, dict]:
         "moge-vitl-train-config": make_config("dinov2_vitl14", 4, 512, (256, 128, 64), 2, "exp", (1200, 2500), dim_times_res_block_hidden=2),
         "tiny-v1-vits-x2": make_config("dinov2_vits14", 4, 128, (64, 64, 32), 2, "exp", (60, 200), dim_times_res_block_hidden=2),
         "tiny-v1-vits-x4-layer": make_config("dinov2_vits14", 4, 128, (64, 32, 32), 1, "exp", (60, 200), dim_times_res_block_hidden=4, res_block_norm="layer_norm"),
+        # output-block options (v1.py:103-109): residual blocks on the last_conv_channels map, a 3x3 last conv
+        "tiny-v1-vits-last": make_config("dinov2_vits14", 4, 128, (64, 64, 32), 1, "exp", (60, 200), dim_times_res_block_hidden=2, last_res_blocks=2, last_conv_size=3),
+        "tiny-v1-vits-last-b": make_config("dinov2_vits14", 4, 128, (64, 32, 32), 1, "exp", (60, 200), last_conv_channels=64, res_block_norm="layer_norm", last_res_blocks=1),
+        "tiny-v1-vits-last-c": make_config("dinov2_vits14", 4, 128, (64, 32, 32), 1, "exp", (60, 200), last_conv_size=3),
     }
 
 
@@ -80,9 +84,16 @@ def state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
             r = f"{u}{1 + j}.layers."
             out += [(r + "0.weight", (co,)), (r + "0.bias", (co,)), (r + "2.weight", (ch, co, 3, 3)), (r + "2.bias", (ch,)),
                     (r + "3.weight", (ch,)), (r + "3.bias", (ch,)), (r + "5.weight", (co, ch, 3, 3)), (r + "5.bias", (co,))]
+    nl, ks, ch4 = cfg.get("last_res_blocks", 0), cfg.get("last_conv_size", 1), c4 * cfg.get("dim_times_res_block_hidden", 1)
     for o, dim_out in enumerate((3, 1)):
+        # nn.Sequential(conv3x3, *ResidualConvBlock x last_res_blocks, ReLU, Conv2d(k = last_conv_size))   (v1.py:103-109)
         b = f"head.output_block.{o}."
-        out += [(b + "0.weight", (c4, ups[-1] + 2, 3, 3)), (b + "0.bias", (c4,)), (b + "2.weight", (dim_out, c4, 1, 1)), (b + "2.bias", (dim_out,))]
+        out += [(b + "0.weight", (c4, ups[-1] + 2, 3, 3)), (b + "0.bias", (c4,))]
+        for j in range(nl):
+            r = f"{b}{1 + j}.layers."
+            out += [(r + "0.weight", (c4,)), (r + "0.bias", (c4,)), (r + "2.weight", (ch4, c4, 3, 3)), (r + "2.bias", (ch4,)),
+                    (r + "3.weight", (ch4,)), (r + "3.bias", (ch4,)), (r + "5.weight", (c4, ch4, 3, 3)), (r + "5.bias", (c4,))]
+        out += [(b + f"{nl + 2}.weight", (dim_out, c4, ks, ks)), (b + f"{nl + 2}.bias", (dim_out,))]
     out += [("image_mean", (1, 3, 1, 1)), ("image_std", (1, 3, 1, 1))]
     return out
 
@@ -114,6 +125,7 @@ def synth_state_dict(cfg: dict, seed: int = 0, sane_geometry: bool = True) -> Di
             t = gain * torch.randn(shape, generator=g) / math.sqrt(fan_in)
         sd[key] = t.float().contiguous()
     c_last = cfg["dim_upsample"][-1]
+    last, kc = cfg.get("last_res_blocks", 0) + 2, cfg.get("last_conv_size", 1) // 2          # index of the last conv in its Sequential, its centre tap
     if sane_geometry:
         w0 = sd["head.output_block.0.0.weight"]             # (c4, C + 2, 3, 3): channels C, C+1 are (u, v)
         w0.mul_(0.3)
@@ -121,13 +133,13 @@ def synth_state_dict(cfg: dict, seed: int = 0, sane_geometry: bool = True) -> Di
         w0[1, c_last + 1, 1, 1] = 4.0
         w0[2, c_last, 1, 1] = -4.0                          # relu(+u), relu(-u): both signs survive the ReLU
         w0[3, c_last + 1, 1, 1] = -4.0
-        w2 = sd["head.output_block.0.2.weight"]
+        w2 = sd[f"head.output_block.0.{last}.weight"]
         w2.mul_(0.05)
-        w2[0, 0, 0, 0], w2[0, 2, 0, 0] = 0.3, -0.3
-        w2[1, 1, 0, 0], w2[1, 3, 0, 0] = 0.3, -0.3
-        sd["head.output_block.0.2.bias"].copy_(torch.tensor([0.0, 0.0, 0.4]))
-    sd["head.output_block.1.2.weight"].mul_(3.0)
-    sd["head.output_block.1.2.bias"].fill_(0.9)
+        w2[0, 0, kc, kc], w2[0, 2, kc, kc] = 0.3, -0.3
+        w2[1, 1, kc, kc], w2[1, 3, kc, kc] = 0.3, -0.3
+        sd[f"head.output_block.0.{last}.bias"].copy_(torch.tensor([0.0, 0.0, 0.4]))
+    sd[f"head.output_block.1.{last}.weight"].mul_(3.0)
+    sd[f"head.output_block.1.{last}.bias"].fill_(0.9)
     return sd
 
 
@@ -196,8 +208,14 @@ def forward(cfg: dict, sd: Dict[str, torch.Tensor], image: torch.Tensor, num_tok
     outs2 = []
     for o in range(2):
         b = f"head.output_block.{o}."
-        y = F.relu(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), sd[b + "0.weight"], sd[b + "0.bias"]))
-        outs2.append(F.conv2d(y, sd[b + "2.weight"], sd[b + "2.bias"]))
+        y = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), sd[b + "0.weight"], sd[b + "0.bias"])
+        nl, ks = cfg.get("last_res_blocks", 0), cfg.get("last_conv_size", 1)
+        for j in range(nl):                                   # v1.py:106
+            y = res_block(y, sd, f"{b}{1 + j}.layers.", cfg.get("res_block_norm", "group_norm"))
+        y = F.relu(y)
+        if ks > 1:
+            y = F.pad(y, (ks // 2,) * 4, mode="replicate")
+        outs2.append(F.conv2d(y, sd[b + f"{nl + 2}.weight"], sd[b + f"{nl + 2}.bias"]))
     points = F.interpolate(outs2[0], (H, W), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
     mask = F.interpolate(outs2[1], (H, W), mode="bilinear", align_corners=False).squeeze(1)
     return {"points": O2.remap_points(points, cfg["remap_output"]), "mask": mask}

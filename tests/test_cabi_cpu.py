@@ -103,8 +103,8 @@ def test_mirror_maps_every_convstack_option_it_supports():
 
 
 def test_v1_mirror_maps_the_head_options():
-    """v1.py:62-75: dim_times_res_block_hidden (configs/train/v1.json:31 trains with 2) and res_block_norm reach the C ABI; the output-block
-    options no config uses (last_res_blocks, last_conv_size 3) are refused at construction."""
+    """v1.py:62-75: dim_times_res_block_hidden (configs/train/v1.json:31 trains with 2), res_block_norm and the output-block options
+    (last_res_blocks, last_conv_size) reach the C ABI; values outside the kernels' range are refused at construction."""
     from moge_amd import _lib as L
     from moge_amd.model import import_model_class_by_version
     from oracle import moge_oracle_v1 as O1
@@ -116,7 +116,9 @@ def test_v1_mirror_maps_the_head_options():
     x4 = M1(**O1.named_configs()["tiny-v1-vits-x4-layer"])._cfg
     assert (x4.hidden_mult, x4.res_block_norm) == (4, L.RES_NORM["layer_norm"])
     base = O1.named_configs()["tiny-v1-vits"]
-    for key, value in (("last_res_blocks", 1), ("last_conv_size", 3), ("res_block_norm", "instance_norm"), ("dim_times_res_block_hidden", 3),
+    last = M1(**O1.named_configs()["tiny-v1-vits-last"])._cfg
+    assert (last.last_res_blocks, last.last_conv_size, last.hidden_mult) == (2, 3, 2) and (rel.last_res_blocks, rel.last_conv_size) == (0, 1)
+    for key, value in (("last_res_blocks", 9), ("last_conv_size", 5), ("res_block_norm", "instance_norm"), ("dim_times_res_block_hidden", 3),
                        ("dim_times_res_block_hidden", 0)):
         with pytest.raises(NotImplementedError):
             M1(**{**base, key: value})
