@@ -134,6 +134,9 @@ class MoGeModel(_MoGeModelV2):
             image = image.unsqueeze(0)
         image = self._prep_image(image)
         B, _, H, W = image.shape
+        return self._infer_v1(image, self._img_dtype(image), B, H, W, omit_batch_dim, fov_x, resolution_level, num_tokens, apply_mask, force_projection, use_fp16)
+
+    def _infer_v1(self, image, img_dtype, B, H, W, omit_batch_dim, fov_x, resolution_level, num_tokens, apply_mask, force_projection, use_fp16):
         if num_tokens is None:
             lo, hi = self.num_tokens_range
             num_tokens = int(lo + (resolution_level / 9) * (hi - lo))
@@ -157,12 +160,25 @@ class MoGeModel(_MoGeModelV2):
                     raise ValueError(f"fov_x has {fov.numel()} elements for a batch of {B} images")
                 fov_ptr = fov.data_ptr()
             flags = (L.FORCE_PROJECTION if force_projection else 0) | (L.APPLY_MASK if apply_mask else 0)
-            L.check(L.lib.moge_v1_infer(self._handle, image.data_ptr(), self._img_dtype(image), B, H, W, rh, rw, fov_ptr, flags, C.byref(o), L.stream_ptr(dev)))
+            L.check(L.lib.moge_v1_infer(self._handle, image.data_ptr(), img_dtype, B, H, W, rh, rw, fov_ptr, flags, C.byref(o), L.stream_ptr(dev)))
             if self.sync_on_infer:
                 L.check(L.lib.moge_sync(self._handle, L.stream_ptr(dev)))
         if omit_batch_dim:
             res = {k: v.squeeze(0) for k, v in res.items()}
         return res
 
-    def infer_uint8(self, *a, **k):
-        raise NotImplementedError("infer_uint8 is provided for the MoGe-2 model only")
+    @torch.inference_mode()
+    def infer_uint8(self, image: torch.Tensor, fov_x: Optional[Union[Number, torch.Tensor]] = None, resolution_level: int = 9, num_tokens: int = None,
+                    apply_mask: bool = True, force_projection: bool = True, use_fp16: bool = True) -> Dict[str, torch.Tensor]:
+        """`infer` for uint8 (H, W, 3) / (B, H, W, 3) RGB images as a decoder produces them: what the reference's caller feeds after
+        `torch.tensor(image / 255, dtype=torch.float32).permute(2, 0, 1)` (scripts/infer.py:98), with the division, layout change and model-dtype
+        cast done on the device (moge_v1_infer's img_dtype 2; float32(i / 255.0) == float32(i) / float32(255) for every byte value)."""
+        self._require_ready()
+        if image.dtype != torch.uint8 or image.shape[-1] != 3 or image.dim() not in (3, 4):
+            raise ValueError("infer_uint8 expects a uint8 tensor of shape (H, W, 3) or (B, H, W, 3)")
+        omit_batch_dim = image.dim() == 3
+        if omit_batch_dim:
+            image = image.unsqueeze(0)
+        image = image.to(device=self._device, non_blocking=True).contiguous()
+        B, H, W, _ = image.shape
+        return self._infer_v1(image, 2, B, H, W, omit_batch_dim, fov_x, resolution_level, num_tokens, apply_mask, force_projection, use_fp16)

@@ -1,12 +1,12 @@
 """`python -m moge_amd.scripts.infer` - the reference's `moge infer` caller loop (moge/scripts/infer.py:18-156) on the MI355X path.
 
-Same flags where the step exists here (`--input/-i`, `--output/-o`, `--pretrained`, `--fov_x`, `--resize`, `--resolution_level`,
-`--num_tokens`, `--threshold`, `--maps`, `--ply`, `--fp16`, `--device`); images of equal size are batched (`--batch`) and run through
+Same flags (`--input/-i`, `--output/-o`, `--pretrained` with the reference's per-version default, `--version {v1,v2}`, `--fov_x`, `--resize`,
+`--resolution_level`, `--num_tokens`, `--threshold`, `--maps`, `--glb`, `--ply`, `--fp16`, `--device`; `--show` is accepted and warns: no viewer here);
+images of equal size are batched (`--batch`) and run through
 `moge_amd.pipeline.InferPipeline` (uint8 upload, transfers overlapped with compute).  Differences, all forced by what this image ships:
 decode / resize use PIL instead of cv2 (BOX filter for `--resize`, the closest PIL has to INTER_AREA); `depth.exr` / `points.exr` are
 written by moge_amd.io.save_exr (uncompressed float32 OpenEXR, same channels as cv2 writes); `mesh.glb` by moge_amd.io.save_glb (glTF 2.0
-binary written directly - trimesh is not installed; same material parameters as moge/utils/io.py:18-42); `--show` (trimesh viewer) is not
-provided.  Mesh and point cloud are built from `mask & ~depth_map_edge(depth, rtol=threshold)` exactly as scripts/infer.py:127-149 does.
+binary written directly - trimesh is not installed; same material parameters as moge/utils/io.py:18-42).  Mesh and point cloud are built from `mask & ~depth_map_edge(depth, rtol=threshold)` exactly as scripts/infer.py:127-149 does.
 """
 from __future__ import annotations
 
@@ -23,7 +23,9 @@ import numpy as np
 @click.option("--input", "-i", "input_path", type=click.Path(exists=True), required=True, help="Input image or folder.")
 @click.option("--fov_x", "fov_x_", type=float, default=None, help="Horizontal FoV in degrees; recovered from the point map if unset.")
 @click.option("--output", "-o", "output_path", default="./output", type=click.Path(), help='Output folder, default "./output".')
-@click.option("--pretrained", "pretrained_model_name_or_path", type=str, required=True, help="Checkpoint path or Hugging Face repo id.")
+@click.option("--pretrained", "pretrained_model_name_or_path", type=str, default=None,
+              help='Checkpoint path or Hugging Face repo id. Defaults to "Ruicheng/moge-vitl" (v1) / "Ruicheng/moge-2-vitl-normal" (v2), which needs network access.')
+@click.option("--version", "model_version", type=click.Choice(["v1", "v2"]), default="v2", help='Model version. Defaults to "v2".')
 @click.option("--device", "device_name", type=str, default="cuda", help='Device, default "cuda".')
 @click.option("--fp16", "use_fp16", is_flag=True, help="fp16 inference.")
 @click.option("--resize", "resize_to", type=int, default=None, help="Resize the long side to this size before inference.")
@@ -33,9 +35,10 @@ import numpy as np
 @click.option("--maps", "save_maps_", is_flag=True, help="Save depth / points / mask / normal maps and fov.json.")
 @click.option("--glb", "save_glb_", is_flag=True, help="Save a textured mesh (.glb).")
 @click.option("--ply", "save_ply_", is_flag=True, help="Save a coloured point cloud (.ply).")
+@click.option("--show", "show", is_flag=True, help="Accepted for compatibility: the reference opens a trimesh viewer here, which this image does not ship.")
 @click.option("--batch", "batch", type=int, default=8, help="Images of equal size per infer() call.")
-def main(input_path, fov_x_, output_path, pretrained_model_name_or_path, device_name, use_fp16, resize_to, resolution_level, num_tokens,
-         threshold, save_maps_, save_glb_, save_ply_, batch):
+def main(input_path, fov_x_, output_path, pretrained_model_name_or_path, model_version, device_name, use_fp16, resize_to, resolution_level, num_tokens,
+         threshold, save_maps_, save_glb_, save_ply_, show, batch):
     import torch
     from PIL import Image
 
@@ -51,7 +54,12 @@ def main(input_path, fov_x_, output_path, pretrained_model_name_or_path, device_
         image_paths, root = [Path(input_path)], Path(input_path).parent
     if len(image_paths) == 0:
         raise FileNotFoundError(f"No image files found in {input_path}")
-    model = import_model_class_by_version("v2").from_pretrained(pretrained_model_name_or_path).to(torch.device(device_name)).eval()
+    if show:
+        import warnings
+        warnings.warn("--show: no viewer in this environment (trimesh is not installed); the requested files are still written")
+    if pretrained_model_name_or_path is None:                         # scripts/infer.py:76-81
+        pretrained_model_name_or_path = {"v1": "Ruicheng/moge-vitl", "v2": "Ruicheng/moge-2-vitl-normal"}[model_version]
+    model = import_model_class_by_version(model_version).from_pretrained(pretrained_model_name_or_path).to(torch.device(device_name)).eval()
     if use_fp16:
         model.half()
     if not (save_maps_ or save_glb_ or save_ply_):

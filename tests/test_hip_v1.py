@@ -135,3 +135,57 @@ def test_panorama_pipeline_runs_end_to_end_on_the_gpu(tmp_path_factory):
     x = torch.tensor(out["views"][7] / 255, dtype=torch.float32).permute(2, 0, 1)
     one = model.infer(x, fov_x=90.0, apply_mask=False, num_tokens=64)
     assert np.array_equal(one["points"].norm(dim=-1).cpu().numpy(), out["view_distance"][7])
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_v1_infer_uint8_equals_infer_of_the_callers_float_tensor(tmp_path_factory, fp16):
+    """scripts/infer.py:98 with --version v1: `torch.tensor(image / 255, dtype=torch.float32).permute(2, 0, 1)` then infer(); infer_uint8 does the
+    division, layout change and dtype cast on the device (moge_v1_infer img_dtype 2) - bit-identical outputs, batch and single image."""
+    import numpy as np
+    model = get_model(CASE_BY_NAME["v1_tiny_b2"], tmp_path_factory)
+    rng = np.random.default_rng(11)
+    imgs = (rng.random((2, 84, 112, 3)) * 255).astype(np.uint8)
+    x = torch.stack([torch.tensor(im / 255, dtype=torch.float32).permute(2, 0, 1) for im in imgs]).cuda()
+    try:
+        m = model.half() if fp16 else model.float()
+        ref = m.infer(x, num_tokens=100, use_fp16=fp16)
+        out = m.infer_uint8(torch.from_numpy(imgs), num_tokens=100, use_fp16=fp16)
+        one = m.infer_uint8(torch.from_numpy(imgs[1]), num_tokens=100, use_fp16=fp16)
+    finally:
+        model.float()
+    assert set(out) == set(ref) == {"points", "depth", "intrinsics", "mask"}
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+        assert torch.equal(one[k], ref[k][1]), k
+    with pytest.raises(ValueError):
+        model.infer_uint8(torch.zeros(3, 70, 98, dtype=torch.uint8))
+
+
+def test_cli_runs_the_v1_model(tmp_path, tmp_path_factory):
+    """`moge infer --version v1` (scripts/infer.py:22, 82): the CLI picks the class by version; --show is accepted (no viewer here) and warns."""
+    import numpy as np
+    from PIL import Image
+    from click.testing import CliRunner
+    from moge_amd import io as IO
+    from moge_amd.scripts.infer import main as cli
+    from oracle import moge_oracle_v1 as O1
+    cfg = O1.named_configs()["tiny-v1-vits"]
+    ckpt = str(tmp_path / "model.pt")
+    O1.save_checkpoint(ckpt, cfg, O1.synth_state_dict(cfg, 0, True))
+    rng = np.random.default_rng(6)
+    src = tmp_path / "in"
+    src.mkdir()
+    im = (rng.random((84, 112, 3)) * 255).astype(np.uint8)
+    Image.fromarray(im).save(src / "a.png")
+    out = tmp_path / "out"
+    with pytest.warns(UserWarning, match="no viewer"):
+        r = CliRunner().invoke(cli, ["-i", str(src), "-o", str(out), "--pretrained", ckpt, "--version", "v1", "--num_tokens", "100", "--maps", "--ply", "--show"],
+                               catch_exceptions=False)
+    assert r.exit_code == 0, r.output
+    d = out / "a"
+    for f in ("image.jpg", "depth_vis.png", "depth.exr", "points.exr", "mask.png", "fov.json", "pointcloud.ply"):
+        assert (d / f).exists(), f
+    assert not (d / "normal.png").exists() and not (d / "mesh.glb").exists()          # MoGe-1 has no normal head; --glb was not asked for
+    model = get_model(CASE_BY_NAME["v1_tiny_b2"], tmp_path_factory)                   # same config and seed as the checkpoint above
+    ref = model.float().infer_uint8(torch.from_numpy(im), num_tokens=100, use_fp16=False)
+    assert np.array_equal(IO.read_exr(d / "depth.exr"), ref["depth"].cpu().numpy())
