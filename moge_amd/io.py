@@ -55,6 +55,18 @@ def save_ply(path: Union[str, Path], vertices: np.ndarray, faces: Optional[np.nd
 # Image mesh (scripts/infer.py:128-145: utils3d.np.build_mesh_from_map + uv_map; utils3d is an un-vendored dependency, so the algorithm is
 # restated from the call site: "parity unpinned", like depth_map_edge)
 # ---------------------------------------------------------------------------------------------------------------------------------------
+def depth_map_edge(depth: np.ndarray, rtol: float) -> np.ndarray:
+    """utils3d.np.depth_map_edge as the reference's callers use it (scripts/infer.py:127, infer_baseline.py:123): a pixel is an edge when the
+    spread of depth in its 3x3 neighbourhood (max - min, borders padded with the pixel's own side: -inf for the max pools) exceeds rtol x its
+    own depth.  Host-side numpy for callers that hold no model handle; `MoGeModel.depth_edge_mask` is the same test on the device."""
+    def pool(a):
+        p = np.pad(a, 1, mode="constant", constant_values=-np.inf)
+        H, W = a.shape
+        return np.max(np.stack([p[i:i + H, j:j + W] for i in range(3) for j in range(3)]), axis=0)
+    with np.errstate(all="ignore"):
+        return (pool(depth) + pool(-depth)) / depth > rtol
+
+
 def uv_map(height: int, width: int) -> np.ndarray:
     """Pixel-centre texture coordinates (H, W, 2), u right / v down in [0, 1] (utils3d.np.uv_map as the reference's caller uses it: the
     export step flips v afterwards, scripts/infer.py:149)."""

@@ -4,7 +4,7 @@ Same flags where the step exists here (`--input/-i`, `--output/-o`, `--pretraine
 `--batch_size`, `--splitted`, `--maps`, `--glb`, `--ply`), plus `--version v1|v2` (the reference script is MoGe-1 only) and `--fp16`.  The
 equirectangular image is split into 12 views, the views go through `MoGeModel.infer(views, fov_x=90, apply_mask=False)` in batches on the
 GPU, the distance maps are merged on the host (moge_amd/panorama.py).  Differences, all forced by what this image ships: decode / resize use
-PIL (BOX filter for `--resize`), EXR / GLB / PLY are written by moge_amd.io, `--show` is not provided, and the mesh mask is
+PIL (BOX filter for `--resize`), EXR / GLB / PLY are written by moge_amd.io, `--show` is accepted and warns (no viewer here), and the mesh mask is
 `mask & ~depth_map_edge(distance, rtol=threshold)` - the reference additionally requires a normal-map edge (utils3d.np.normal_map_edge, not
 restated here), so this removes a superset of the reference's edge pixels.  Mirrored quirks of the reference script: `--resolution_level` is accepted
 but not passed to `infer()` (infer_panorama.py:101), the GLB gets the mesh builder's uvs unflipped (:147; `scripts/infer.py:148` is the one that flips v), and `points.exr` carries R, G, B = z, y, x (:132 writes the
@@ -21,7 +21,8 @@ import numpy as np
 @click.command(help="Inference script for panorama images (MI355X)")
 @click.option("--input", "-i", "input_path", type=click.Path(exists=True), required=True, help="Input equirectangular image or folder.")
 @click.option("--output", "-o", "output_path", type=click.Path(), default="./output", help='Output folder, default "./output".')
-@click.option("--pretrained", "pretrained_model_name_or_path", type=str, required=True, help="Checkpoint path or Hugging Face repo id.")
+@click.option("--pretrained", "pretrained_model_name_or_path", type=str, default="Ruicheng/moge-vitl",
+              help='Checkpoint path or Hugging Face repo id. Defaults to "Ruicheng/moge-vitl" as in the reference script (needs network access).')
 @click.option("--version", "model_version", type=click.Choice(["v1", "v2"]), default="v1", help="Model class (the reference script uses v1).")
 @click.option("--device", "device_name", type=str, default="cuda", help='Device, default "cuda".')
 @click.option("--fp16", "use_fp16", is_flag=True, help="fp16 inference (model.half()).")
@@ -33,8 +34,9 @@ import numpy as np
 @click.option("--maps", "save_maps_", is_flag=True, help="Save image, depth (EXR + visualisation), points (EXR) and mask.")
 @click.option("--glb", "save_glb_", is_flag=True, help="Save a textured mesh (.glb).")
 @click.option("--ply", "save_ply_", is_flag=True, help="Save a coloured mesh (.ply).")
+@click.option("--show", "show", is_flag=True, help="Accepted for compatibility: the reference opens a trimesh viewer here, which this image does not ship.")
 def main(input_path, output_path, pretrained_model_name_or_path, model_version, device_name, use_fp16, resize_to, resolution_level, threshold,
-         batch_size, save_splitted, save_maps_, save_glb_, save_ply_):
+         batch_size, save_splitted, save_maps_, save_glb_, save_ply_, show):
     import torch
     from PIL import Image
 
@@ -50,6 +52,9 @@ def main(input_path, output_path, pretrained_model_name_or_path, model_version, 
         image_paths, root = [Path(input_path)], Path(input_path).parent
     if len(image_paths) == 0:
         raise FileNotFoundError(f"No image files found in {input_path}")
+    if show:
+        import warnings
+        warnings.warn("--show: no viewer in this environment (trimesh is not installed); the requested files are still written")
     if not (save_maps_ or save_glb_ or save_ply_):
         save_maps_ = save_glb_ = save_ply_ = True
     model = import_model_class_by_version(model_version).from_pretrained(pretrained_model_name_or_path).to(torch.device(device_name)).eval()

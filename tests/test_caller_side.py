@@ -253,3 +253,79 @@ def test_cli_writes_every_output_the_reference_cli_writes(tmp_path):
         fov = json.load(open(d / "fov.json"))
         assert 1.0 < fov["fov_x"] < 179.0 and 1.0 < fov["fov_y"] < 179.0
         assert (d / "mesh.glb").read_bytes()[:4] == b"glTF"
+
+
+def test_host_depth_map_edge_equals_the_restatement_the_device_kernel_is_tested_against():
+    """moge_amd.io.depth_map_edge (host numpy for callers without a model handle, scripts/infer_baseline.py) = oracle/caller_side's restatement of
+    utils3d.np.depth_map_edge, incl. infinite (masked) pixels and the image border."""
+    from moge_amd.io import depth_map_edge
+    rng = np.random.default_rng(0)
+    d = rng.random((37, 53)).astype(np.float32) + 0.5
+    d[3, 4] = np.inf
+    d[10:12, 20] = np.inf
+    d[0, :5] = 3.0
+    for r in (0.03, 0.2, 0.5):
+        assert np.array_equal(depth_map_edge(d, r), CS.depth_map_edge(d, r)), r
+
+
+def test_cli_group_lists_the_commands_of_the_reference_group_that_exist_here():
+    """moge/scripts/cli.py:14-22: `moge <command>`; here infer, infer_baseline, infer_panorama (same option names as the reference's commands)."""
+    from click.testing import CliRunner
+    from moge_amd.scripts import cli as C
+    from moge_amd.scripts import infer, infer_baseline, infer_panorama
+    for mod, name in ((infer, "infer"), (infer_baseline, "infer_baseline"), (infer_panorama, "infer_panorama")):
+        C.cli.add_command(mod.main, name=name)
+    r = CliRunner().invoke(C.cli, ["--help"])
+    assert r.exit_code == 0 and all(n in r.output for n in ("infer", "infer_baseline", "infer_panorama"))
+    opts = {o for p in infer.main.params for o in p.opts}
+    assert {"--input", "--fov_x", "--output", "--pretrained", "--version", "--device", "--fp16", "--resize", "--resolution_level", "--num_tokens", "--threshold",
+            "--maps", "--glb", "--ply", "--show"} <= opts                                                          # scripts/infer.py:18-33
+    opts = {o for p in infer_baseline.main.params for o in p.opts}
+    assert opts == {"--baseline", "--input", "-i", "--output", "-o", "--size", "--skip", "--maps", "--ply", "--glb", "--threshold"}      # infer_baseline.py:17-26
+    opts = {o for p in infer_panorama.main.params for o in p.opts}
+    assert {"--input", "--output", "--pretrained", "--device", "--resize", "--resolution_level", "--threshold", "--batch_size", "--splitted", "--maps", "--glb",
+            "--ply", "--show"} <= opts                                                                              # infer_panorama.py:15-28
+
+
+@pytest.mark.gpu
+def test_infer_baseline_cli_drives_the_plugin_by_path(tmp_path):
+    """`moge infer_baseline --baseline baselines/moge_mi355x.py ...` (infer_baseline.py:16-137): the plugin file is loaded by path, its own options
+    come after the script's, every key it returns is written under the reference's file names; EXR contents equal the plugin's infer()."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import importlib.util
+    import json
+    from PIL import Image
+    from click.testing import CliRunner
+    from moge_amd import io as IO
+    from moge_amd.scripts.infer_baseline import main as cli
+    from oracle import moge_oracle as O
+    cfg = O.named_configs()["tiny-vits-normal"]
+    ckpt = str(tmp_path / "model.pt")
+    O.save_checkpoint(ckpt, cfg, O.synth_state_dict(cfg, 0, True))
+    rng = np.random.default_rng(8)
+    src = tmp_path / "in"
+    (src / "sub").mkdir(parents=True)
+    im = (rng.random((84, 112, 3)) * 255).astype(np.uint8)
+    Image.fromarray(im).save(src / "sub" / "a.png")
+    plug = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "baselines", "moge_mi355x.py")
+    out = tmp_path / "out"
+    args = ["--baseline", plug, "-i", str(src), "-o", str(out), "--maps", "--ply", "--glb", "--pretrained", ckpt, "--version", "v2", "--num_tokens", "108"]
+    r = CliRunner().invoke(cli, args, catch_exceptions=False)
+    assert r.exit_code == 0, r.output
+    d = out / "sub" / "a"
+    for f in ("image.jpg", "points_metric.exr", "depth_metric.exr", "depth_metric_vis.png", "fov.json", "mesh.ply", "mesh.glb"):
+        assert (d / f).exists(), f
+    spec = importlib.util.spec_from_file_location("moge_mi355x_plugin_cli", plug)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    base = mod.Baseline.load.main(["--pretrained", ckpt, "--version", "v2", "--num_tokens", "108"], standalone_mode=False)
+    ref = base.infer(torch.from_numpy(im.astype(np.float32) / 255.0).permute(2, 0, 1).cuda())
+    assert np.array_equal(IO.read_exr(d / "depth_metric.exr"), ref["depth_metric"].cpu().numpy())
+    assert np.array_equal(IO.read_exr(d / "points_metric.exr"), ref["points_metric"].cpu().numpy())
+    fov = json.load(open(d / "fov.json"))
+    assert np.allclose(np.array(fov["intrinsics"]), ref["intrinsics"].cpu().numpy()) and 1.0 < fov["fov_x"] < 179.0
+    assert (d / "mesh.glb").read_bytes()[:4] == b"glTF"
+    mtime = (d / "fov.json").stat().st_mtime_ns
+    r = CliRunner().invoke(cli, args + ["--skip"], catch_exceptions=False)                    # --skip: an existing output folder is left alone
+    assert r.exit_code == 0 and (d / "fov.json").stat().st_mtime_ns == mtime
