@@ -273,10 +273,12 @@ def test_cli_group_lists_the_commands_of_the_reference_group_that_exist_here():
     from click.testing import CliRunner
     from moge_amd.scripts import cli as C
     from moge_amd.scripts import infer, infer_baseline, infer_panorama
-    for mod, name in ((infer, "infer"), (infer_baseline, "infer_baseline"), (infer_panorama, "infer_panorama")):
-        C.cli.add_command(mod.main, name=name)
     r = CliRunner().invoke(C.cli, ["--help"])
     assert r.exit_code == 0 and all(n in r.output for n in ("infer", "infer_baseline", "infer_panorama"))
+    assert C.cli.get_command(None, "infer") is infer.main and C.cli.get_command(None, "infer_baseline") is infer_baseline.main
+    assert C.cli.get_command(None, "infer_panorama") is infer_panorama.main and C.cli.get_command(None, "train") is None
+    r = CliRunner().invoke(C.cli, ["infer_baseline", "--help"])
+    assert r.exit_code == 0 and "--baseline" in r.output
     opts = {o for p in infer.main.params for o in p.opts}
     assert {"--input", "--fov_x", "--output", "--pretrained", "--version", "--device", "--fp16", "--resize", "--resolution_level", "--num_tokens", "--threshold",
             "--maps", "--glb", "--ply", "--show"} <= opts                                                          # scripts/infer.py:18-33
