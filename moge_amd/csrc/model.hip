@@ -59,6 +59,7 @@ struct moge_handle {
     size_t master_floats = 0;
     float* master = nullptr;
     bool master_ready = false;
+    long long* bcast_rec = nullptr;                              // 5-word status record of moge_broadcast_weights (allocated once, at create)
     // derived fp32 vectors (bias sums, uv columns, expanded convT biases)
     std::map<std::string, size_t> aux_off;
     size_t aux_floats = 0;
@@ -615,7 +616,7 @@ static Plan make_plan(const moge_config& c, int prec, int B, int H, int W, int r
     int nheads = 0;
     for (int k = 0; k < 3; k++) nheads += (c.heads & HEAD_BITS[k]) ? 1 : 0;
     // (normalised residual blocks share ONE GroupNorm scratch per plan: heads then run one after the other)
-    p.head_sets = (nheads > 1 && moge_tune_get("HEAD_STREAMS", 1) != 0 && B <= moge_tune_get("HEAD_STREAMS_MAX_B", 1) && !stack_generic_blocks(c, false)) ? nheads : 1;
+    p.head_sets = (nheads > 1 && moge_tune_get("HEAD_STREAMS", 1) != 0 && B <= moge_tune_get("HEAD_STREAMS_MAX_B", 1) && !stack_has_norm(c, false)) ? nheads : 1;      // (only the shared norm-statistics scratch `gn` serialises the heads: activation-only blocks keep their streams)
     for (int i = 0; i < 3 * p.head_sets; i++) p.scratch[i] = take(p, mx * s);
     if (stack_has_norm(c, true) || stack_has_norm(c, false)) {
         size_t gmax = 0;
@@ -773,7 +774,9 @@ static int res_blocks(moge_handle* h, const std::string& name, int l, int n, T* 
             // generic block (modules.py:47-67): [norm ->] act -> 3x3 (C -> Ch) -> [norm ->] act -> 3x3 (Ch -> C), + x.  "layer_norm" = GroupNorm(1, C),
             // "group_norm" = GroupNorm(C / 32, C), "instance_norm" = InstanceNorm2d (per channel, no affine); the norm + activation pairs run on
             // MoGe-1's deterministic slab kernels (elementwise.hip).  ReLU without a norm stays fused in the conv (input side / epilogue).
-            if (!tmp2 || (!gn && (in_norm || hid_norm))) return fail(MOGE_ERR_INVALID, "res_blocks: generic blocks need a second scratch map");
+            // (the second scratch map is only touched when the first norm / activation pass writes `oth`; a hidden norm alone is applied in place)
+            if ((!tmp2 && (in_norm || act != MOGE_ACT_RELU)) || (!gn && (in_norm || hid_norm)))
+                return fail(MOGE_ERR_INVALID, "res_blocks: generic blocks need a second scratch map (and the norm statistics scratch)");
             const std::string r = name + S(".res_blocks.%d.%d.layers.", l, j);
             auto affine = [&](int mode, const char* key) -> const float* { return (mode == MOGE_NORM_LAYER || mode == MOGE_NORM_GROUP) ? M(h, r + key) : nullptr; };
             const T* in1 = cur;
@@ -1529,6 +1532,8 @@ int moge_create(const moge_config* cfg, int device, moge_handle** out) {
     hipError_t e = hipMalloc(&h->d_status, sizeof(int));
     if (e != hipSuccess) { delete h; return fail(MOGE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     hipMemset(h->d_status, 0, sizeof(int));
+    e = hipMalloc(&h->bcast_rec, 5 * sizeof(long long));                                           // status record of moge_broadcast_weights
+    if (e != hipSuccess) { hipFree(h->d_status); delete h; return fail(MOGE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     *out = h;
     return 0;
 }
@@ -1584,6 +1589,8 @@ int moge_create_v1(const moge_v1_config* cfg, int device, moge_handle** out) {
     hipError_t e = hipMalloc(&h->d_status, sizeof(int));
     if (e != hipSuccess) { delete h; return fail(MOGE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     hipMemset(h->d_status, 0, sizeof(int));
+    e = hipMalloc(&h->bcast_rec, 5 * sizeof(long long));                                           // status record of moge_broadcast_weights
+    if (e != hipSuccess) { hipFree(h->d_status); delete h; return fail(MOGE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     *out = h;
     return 0;
 }
@@ -1599,6 +1606,7 @@ void moge_destroy(moge_handle* h) {
     if (h->u8_stage) hipFree(h->u8_stage);
     for (auto& e : h->pos_cache) hipFree(e.ptr);
     if (h->d_status) hipFree(h->d_status);
+    if (h->bcast_rec) hipFree(h->bcast_rec);
     for (int i = 0; i < moge_handle::MAX_SPLIT; i++) { if (h->split_st[i]) hipStreamDestroy(h->split_st[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     for (int i = 0; i < moge_handle::MAX_SPLIT; i++) {
@@ -1680,17 +1688,18 @@ const RcclApi* rccl_api(std::string& why) {
 }
 }  // namespace
 
-// Every rank of the communicator must call this.  A rank whose LOCAL preconditions fail (the root has no weights, bad root, allocation failure) does
-// not return early - the others would already sit in ncclBroadcast - but takes part in a 5-word status all-reduce first: all ranks learn that someone
-// is not ready, or that the ranks disagree on the blob size (different model configs) or on the root, and ALL return an error before any payload moves.
-// (A rank that cannot reach RCCL at all, or whose communicator is broken, still returns alone: then abort the communicator on the other ranks.)
+// Every rank of the communicator must call this.  A rank whose LOCAL preconditions fail (the root has no weights, bad root, allocation failure, the
+// device cannot be selected) does not return early - the others would already sit in ncclBroadcast - but takes part in a 5-word status all-reduce
+// first: all ranks learn that someone is not ready, or that the ranks disagree on the blob size (different model configs) or on the root, and ALL return
+// an error before any payload moves.  The status record lives in the handle (allocated at create: no hipMalloc / hipFree - an implicit device-wide
+// synchronisation - per call).  The only solo returns are the two cases in which no collective can be issued at all: RCCL cannot be loaded, or the
+// communicator itself is broken (rank / size query fails) - then abort the communicator on the other ranks.
 int moge_broadcast_weights(moge_handle* h, void* nccl_comm, int root, void* stream) {
     if (!h || !nccl_comm) return fail(MOGE_ERR_INVALID, "null argument");
     std::string why;
     const RcclApi* apip = rccl_api(why);
     if (!apip) return fail(MOGE_ERR_INVALID, "RCCL not available: librccl.so.1 could not be loaded (%s)", why.c_str());
     const RcclApi& api = *apip;
-    HIPCHK(hipSetDevice(h->device));
     int rank = -1, n = 0;
     int rc = api.user_rank(nccl_comm, &rank);
     if (rc == 0) rc = api.count(nccl_comm, &n);
@@ -1699,13 +1708,13 @@ int moge_broadcast_weights(moge_handle* h, void* nccl_comm, int root, void* stre
     // ---- local checks, recorded instead of returned
     int local_status = 0;
     std::string local_msg;
-    if (root < 0 || root >= n) { local_status = MOGE_ERR_INVALID; local_msg = "root " + std::to_string(root) + " is not a rank of a " + std::to_string(n) + "-rank communicator"; }
+    if (hipSetDevice(h->device) != hipSuccess) { local_status = MOGE_ERR_HIP; local_msg = "hipSetDevice(" + std::to_string(h->device) + ") failed"; }
+    else if (root < 0 || root >= n) { local_status = MOGE_ERR_INVALID; local_msg = "root " + std::to_string(root) + " is not a rank of a " + std::to_string(n) + "-rank communicator"; }
     else if (rank == root && !h->master_ready) { local_status = MOGE_ERR_NOT_LOADED; local_msg = "the root rank has no weights to broadcast (moge_load_weights first)"; }
     else if (moge_alloc_master(h) != 0) { local_status = MOGE_ERR_HIP; local_msg = std::string("master blob allocation failed: ") + moge_last_error(); }
     // ---- agreement: min over ranks of {ok, floats, -floats, root, -root}
     long long rec[5] = {local_status == 0 ? 1 : 0, (long long)h->master_floats, -(long long)h->master_floats, root, -(long long)root};
-    long long* drec = nullptr;
-    HIPCHK(hipMalloc(&drec, sizeof(rec)));
+    long long* drec = h->bcast_rec;
     const int NCCL_INT64 = 4, NCCL_MIN = 3;                     // rccl.h ncclDataType_t / ncclRedOp_t
     hipError_t he = hipMemcpyAsync(drec, rec, sizeof(rec), hipMemcpyHostToDevice, st);
     if (he == hipSuccess) {
@@ -1713,7 +1722,6 @@ int moge_broadcast_weights(moge_handle* h, void* nccl_comm, int root, void* stre
         if (rc == 0) he = hipMemcpyAsync(rec, drec, sizeof(rec), hipMemcpyDeviceToHost, st);
         if (rc == 0 && he == hipSuccess) he = hipStreamSynchronize(st);
     }
-    hipFree(drec);
     if (rc != 0) return fail(MOGE_ERR_HIP, "ncclAllReduce (status agreement) failed: %s", api.errstr ? api.errstr(rc) : "?");
     HIPCHK(he);
     if (local_status != 0) return fail(local_status, "%s", local_msg.c_str());

@@ -55,16 +55,25 @@ def save_ply(path: Union[str, Path], vertices: np.ndarray, faces: Optional[np.nd
 # Image mesh (scripts/infer.py:128-145: utils3d.np.build_mesh_from_map + uv_map; utils3d is an un-vendored dependency, so the algorithm is
 # restated from the call site: "parity unpinned", like depth_map_edge)
 # ---------------------------------------------------------------------------------------------------------------------------------------
-def depth_map_edge(depth: np.ndarray, rtol: float) -> np.ndarray:
-    """utils3d.np.depth_map_edge as the reference's callers use it (scripts/infer.py:127, infer_baseline.py:123): a pixel is an edge when the
-    spread of depth in its 3x3 neighbourhood (max - min, borders padded with the pixel's own side: -inf for the max pools) exceeds rtol x its
-    own depth.  Host-side numpy for callers that hold no model handle; `MoGeModel.depth_edge_mask` is the same test on the device."""
+def depth_map_edge(depth: np.ndarray, rtol: float, mask: Optional[np.ndarray] = None) -> np.ndarray:
+    """utils3d.np.depth_map_edge as the reference's callers use it: a pixel is an edge when the spread of depth in its 3x3 neighbourhood
+    (max - min; positions outside the image do not take part) exceeds rtol x its own depth.  Without `mask` (scripts/infer.py:127) every in-image
+    neighbour counts, so a valid pixel next to a +inf (masked-out) depth is an edge; with `mask` (infer_baseline.py:123 passes `mask=mask`)
+    masked-out neighbours are excluded from both pools like out-of-image ones, and masked-out pixels are never edges.  Host-side numpy for callers
+    that hold no model handle; `MoGeModel.depth_edge_mask` is the same test on the device (it skips NaN neighbours: hand it NaN at masked pixels for
+    the `mask=` semantics)."""
     def pool(a):
         p = np.pad(a, 1, mode="constant", constant_values=-np.inf)
         H, W = a.shape
         return np.max(np.stack([p[i:i + H, j:j + W] for i in range(3) for j in range(3)]), axis=0)
+    depth = np.asarray(depth)
     with np.errstate(all="ignore"):
-        return (pool(depth) + pool(-depth)) / depth > rtol
+        if mask is None:
+            return (pool(depth) + pool(-depth)) / depth > rtol
+        m = np.asarray(mask).astype(bool)
+        hi = pool(np.where(m, depth, -np.inf))
+        lo = pool(np.where(m, -depth, -np.inf))
+        return m & ((hi + lo) / depth > rtol)
 
 
 def uv_map(height: int, width: int) -> np.ndarray:

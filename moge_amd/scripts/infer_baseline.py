@@ -101,13 +101,16 @@ def main(ctx, baseline_code_path, input_path, output_path, image_size, skip, sav
         if save_ply_ or save_glb_:
             assert any(k in output for k in POINT_KEYS), "No point map found in output"
             points = next(output[k] for k in POINT_KEYS if k in output)
-            mask = output["mask"].astype(bool) if "mask" in output else np.isfinite(points).all(axis=-1)
-            z = np.where(mask, points[..., 2], np.inf).astype(np.float32)
+            # (no mask from the plugin: all-ones, like infer_baseline.py:119)
+            mask = output["mask"].astype(bool) if "mask" in output else np.ones(points.shape[:-1], dtype=bool)
+            # depth_map_edge(depth, rtol, mask=mask) (infer_baseline.py:123): masked-out neighbours take no part in the 3x3 max / min, so the mesh is NOT
+            # eroded along mask borders.  The device kernel skips NaN neighbours (fmaxf / fminf), which gives the same semantics with NaN at masked pixels.
             on_device = getattr(getattr(baseline, "model", None), "depth_edge_mask", None)          # a moge_amd model behind the plugin: the device kernel
             if on_device is not None:
+                z = np.where(mask, points[..., 2], np.nan).astype(np.float32)
                 clean = on_device(torch.from_numpy(z), torch.from_numpy(mask), rtol=threshold).cpu().numpy()
             else:
-                clean = mask & ~depth_map_edge(z, threshold)
+                clean = mask & ~depth_map_edge(points[..., 2].astype(np.float32), threshold, mask=mask)
             faces, vertices, vertex_colors, vertex_uvs = build_mesh_from_map(np.where(mask[..., None], points, 0).astype(np.float32), image_np.astype(np.float32) / 255,
                                                                              uv_map(height, width), mask=clean, tri=True)
             # OpenGL conventions for the export (infer_baseline.py:127-130): x right, y up, z backward; (0, 0) = left-bottom of the texture

@@ -6,9 +6,12 @@ equirectangular image is split into 12 views, the views go through `MoGeModel.in
 GPU, the distance maps are merged on the host (moge_amd/panorama.py).  Differences, all forced by what this image ships: decode / resize use
 PIL (BOX filter for `--resize`), EXR / GLB / PLY are written by moge_amd.io, `--show` is accepted and warns (no viewer here), and the mesh mask is
 `mask & ~depth_map_edge(distance, rtol=threshold)` - the reference additionally requires a normal-map edge (utils3d.np.normal_map_edge, not
-restated here), so this removes a superset of the reference's edge pixels.  Mirrored quirks of the reference script: `--resolution_level` is accepted
-but not passed to `infer()` (infer_panorama.py:101), the GLB gets the mesh builder's uvs unflipped (:147; `scripts/infer.py:148` is the one that flips v), and `points.exr` carries R, G, B = z, y, x (:132 writes the
-array without the RGB -> BGR conversion of `scripts/infer.py:114`)."""
+restated here), so this removes a superset of the reference's edge pixels.  `--resolution_level` is accepted but not passed to `infer()`, as in the
+reference (infer_panorama.py:101).  File conventions: by default the outputs are the physically consistent ones of `moge infer` (points.exr with
+R, G, B = x, y, z; the GLB's uvs in the v-up convention `moge_amd.io.save_glb` expects, so the texture is upright).  The reference's panorama script
+differs from its own `scripts/infer.py` in two places - :132 writes `points` through cv2 without the RGB -> BGR conversion of `infer.py:114` (file channels
+R, G, B = z, y, x) and :147 passes the mesh builder's uvs unflipped (`infer.py:148` flips v) - and whether the second one shows as a mirrored texture depends on
+the un-vendored utils3d / trimesh conventions; `--reference_compat` reproduces both byte conventions for callers that parse the reference's files."""
 from __future__ import annotations
 
 import itertools
@@ -35,8 +38,10 @@ import numpy as np
 @click.option("--glb", "save_glb_", is_flag=True, help="Save a textured mesh (.glb).")
 @click.option("--ply", "save_ply_", is_flag=True, help="Save a coloured mesh (.ply).")
 @click.option("--show", "show", is_flag=True, help="Accepted for compatibility: the reference opens a trimesh viewer here, which this image does not ship.")
+@click.option("--reference_compat", "reference_compat", is_flag=True,
+              help="Write points.exr (R, G, B = z, y, x) and the GLB uvs (unflipped) exactly as the reference's panorama script does; default: the conventions of `moge infer`.")
 def main(input_path, output_path, pretrained_model_name_or_path, model_version, device_name, use_fp16, resize_to, resolution_level, threshold,
-         batch_size, save_splitted, save_maps_, save_glb_, save_ply_, show):
+         batch_size, save_splitted, save_maps_, save_glb_, save_ply_, show, reference_compat=False):
     import torch
     from PIL import Image
 
@@ -85,15 +90,17 @@ def main(input_path, output_path, pretrained_model_name_or_path, model_version, 
             Image.fromarray(image).save(save_path / "image.jpg")
             Image.fromarray(colorize_depth(depth, mask=mask)).save(save_path / "depth_vis.png")
             save_exr(save_path / "depth.exr", depth)
-            # The reference's PANORAMA script hands `points` to cv2.imwrite as they are (infer_panorama.py:132), and cv2 takes the last axis as B, G, R: its file
-            # has R = z, G = y, B = x - unlike scripts/infer.py:114, which converts RGB -> BGR first (R, G, B = x, y, z).  Mirrored, not fixed.
-            save_exr(save_path / "points.exr", points[..., ::-1])
+            # R, G, B = x, y, z like `moge infer`; --reference_compat: the reference's PANORAMA script hands `points` to cv2.imwrite as they are
+            # (infer_panorama.py:132), cv2 takes the last axis as B, G, R, so its file has R = z, G = y, B = x
+            save_exr(save_path / "points.exr", points[..., ::-1] if reference_compat else points)
             Image.fromarray((mask * 255).astype(np.uint8)).save(save_path / "mask.png")
         if save_glb_ or save_ply_:
             cleaned = model.depth_edge_mask(torch.from_numpy(depth)[None], torch.from_numpy(mask)[None], rtol=threshold).cpu().numpy()[0]
             faces, vertices, vertex_colors, vertex_uvs = build_mesh_from_map(points, image.astype(np.float32) / 255, uv_map(H, W), mask=cleaned, tri=True)
             if save_glb_:
-                save_glb(save_path / "mesh.glb", vertices, faces, vertex_uvs, image)      # uvs as built, like infer_panorama.py:147 (it is scripts/infer.py:148 that flips v)
+                # save_glb takes OpenGL (v-up) uvs and flips them back to glTF's top-left origin: hand it v-up uvs so the texture is upright
+                # (--reference_compat: the builder's v-down uvs as infer_panorama.py:147 passes them)
+                save_glb(save_path / "mesh.glb", vertices, faces, vertex_uvs if reference_compat else vertex_uvs * [1, -1] + [0, 1], image)
             if save_ply_:
                 save_ply(save_path / "mesh.ply", vertices, faces, vertex_colors)
 

@@ -59,8 +59,10 @@ FP16_FACTOR = 1.6
 FP16_FACTOR_BY_KEY = dict(intrinsics=2.0, metric_scale=2.0, mask=2.0, normal=1.75)      # (normals of the random tiny nets: worst p99.9 1.5 x, tiny_no_points_head autocast; profiles/r05a_gate_lines.log)
 # ... and NO pixel further than a small multiple of that band (the p99.9 gate alone would let 0.1 % of the pixels - a tile corner, a border row - be
 # arbitrarily wrong).  Observed max / reference drift over all fixtures, both fp16 forms: points / depth <= 1.9, normals <= 12 (unit vectors of a random
-# tiny net: a pixel whose raw normal is nearly 0 turns by a large angle; the reference's own fp16 outputs show <= 6.4 there).  In units of the band:
-FP16_MAX_FACTOR = dict(points=2.0, depth=2.0, intrinsics=2.0, metric_scale=2.0, normal=11.0)
+# tiny net: a pixel whose raw normal is nearly 0 turns by a large angle; the reference's own fp16 outputs show <= 6.4 there).  In units of the band
+# (normals: 8 x 1.75 = 14 x the reference's drift, under the 16 x the gate carried before round 5 - round 6: the 11.0 of round 5 made it 19.25 x while
+# EXPERIMENTS R5.5 called it unchanged; the worst observed max is 3.9 bands (tiny_fov_nomask_noproj, profiles/r05v_gate_lines.log), so 8.0 holds everywhere):
+FP16_MAX_FACTOR = dict(points=2.0, depth=2.0, intrinsics=2.0, metric_scale=2.0, normal=8.0)
 FLIP_SLACK = 4              # pixels
 FP16_FLOOR = dict(points=5e-4, depth=5e-4, normal=2e-3, intrinsics=1e-4, metric_scale=5e-4, mask=1e-4)   # where the reference's drift is ~0 (e.g. fov_x given)
 

@@ -268,6 +268,54 @@ def test_host_depth_map_edge_equals_the_restatement_the_device_kernel_is_tested_
         assert np.array_equal(depth_map_edge(d, r), CS.depth_map_edge(d, r)), r
 
 
+def _edge_with_mask_loops(d, rtol, m):
+    """depth_map_edge(depth, rtol, mask=mask) by plain loops: only in-image, unmasked neighbours take part; masked pixels are never edges."""
+    H, W = d.shape
+    out = np.zeros((H, W), bool)
+    for y in range(H):
+        for x in range(W):
+            if not m[y, x]:
+                continue
+            vals = [d[yy, xx] for yy in range(max(0, y - 1), min(H, y + 2)) for xx in range(max(0, x - 1), min(W, x + 2)) if m[yy, xx]]
+            out[y, x] = (np.float32(max(vals)) + np.float32(-min(vals))) / d[y, x] > rtol
+    return out
+
+
+def test_host_depth_map_edge_with_mask_ignores_masked_neighbours():
+    """infer_baseline.py:123 calls depth_map_edge(depth, rtol, mask=mask) - a valid pixel beside a masked one is NOT an edge for that reason
+    alone (without the argument the +inf neighbour makes it one and the mesh is eroded along every mask border)."""
+    from moge_amd.io import depth_map_edge
+    rng = np.random.default_rng(1)
+    d = (rng.random((29, 41)).astype(np.float32) * 0.02 + 1.0)
+    d[:, 20:] += 1.0                                     # one real step edge
+    m = np.ones(d.shape, bool)
+    m[5:9, 3:12] = False
+    m[0, :] = False
+    m[14, 19:23] = False
+    dm = np.where(m, d, np.inf).astype(np.float32)
+    for r in (0.01, 0.03, 0.3):
+        got = depth_map_edge(dm, r, mask=m)
+        assert np.array_equal(got, _edge_with_mask_loops(d, r, m)), r
+        assert not got[~m].any()
+    smooth = depth_map_edge(dm, 0.3, mask=m)
+    assert not smooth[4, 3:12].any() and not smooth[1, :18].any() and not smooth[1, 22:].any()      # rows next to the holes: no erosion (the real step sits at columns 19 / 20)
+    assert depth_map_edge(dm, 0.3)[4, 3:12].all()                          # ... which the mask-less form does erode
+
+
+@pytest.mark.gpu
+def test_device_depth_edge_mask_with_nan_at_masked_pixels_equals_the_mask_aware_host_form(model):
+    """what scripts/infer_baseline.py hands the device kernel: NaN at masked pixels = depth_map_edge(..., mask=mask) (fmaxf / fminf skip NaN)"""
+    from moge_amd.io import depth_map_edge
+    rng = np.random.default_rng(2)
+    d = (rng.random((83, 57)).astype(np.float32) * 0.05 + 1.0)
+    d[:, 30:] *= 1.5
+    m = rng.random(d.shape) > 0.2
+    z = np.where(m, d, np.nan).astype(np.float32)
+    for r in (0.02, 0.1):
+        got = model.depth_edge_mask(torch.from_numpy(z), torch.from_numpy(m), rtol=r).cpu().numpy()
+        assert np.array_equal(got, m & ~depth_map_edge(d, r, mask=m)), r
+
+
 def test_cli_group_lists_the_commands_of_the_reference_group_that_exist_here():
     """moge/scripts/cli.py:14-22: `moge <command>`; here infer, infer_baseline, infer_panorama (same option names as the reference's commands)."""
     from click.testing import CliRunner

@@ -178,20 +178,42 @@ def test_cli_is_importable_without_a_gpu_and_lists_the_reference_flags():
         assert flag in r.output, flag
 
 
-def test_cli_mirrors_the_reference_scripts_file_conventions(tmp_path, monkeypatch):
-    """the panorama CLI's EXR channel order and GLB uv convention, pinned against what the two reference scripts do.
-    scripts/infer.py:114 writes points through cv2.cvtColor(RGB2BGR) -> file channels R, G, B = x, y, z and flips v for the GLB (:148);
-    scripts/infer_panorama.py:132,147 does neither -> R, G, B = z, y, x and the mesh builder's uvs as they are."""
+def test_cli_file_conventions_default_is_consistent_and_reference_compat_is_opt_in(tmp_path, monkeypatch):
+    """the panorama CLI writes the physically consistent files by default (points.exr R, G, B = x, y, z; GLB texture upright) and the
+    reference panorama script's two byte conventions (infer_panorama.py:132,147: no RGB -> BGR conversion, unflipped uvs) only with --reference_compat."""
     import inspect
+    import json
+    import struct
     from moge_amd.scripts import infer as S, infer_panorama as SP
     src_p, src_i = inspect.getsource(SP), inspect.getsource(S)
-    assert 'save_exr(save_path / "points.exr", points[..., ::-1])' in src_p          # B, G, R = x, y, z as cv2 writes an un-converted array
+    assert 'points[..., ::-1] if reference_compat else points' in src_p
     assert 'save_exr(save_path / "points.exr", out["points"][j])' in src_i           # R, G, B = x, y, z
-    assert "vertex_uvs * [1, -1] + [0, 1]" in src_i and "vertex_uvs * [1, -1]" not in src_p
+    assert "vertex_uvs * [1, -1] + [0, 1]" in src_i and "vertex_uvs if reference_compat else vertex_uvs * [1, -1] + [0, 1]" in src_p
     assert "resolution_level=resolution_level" not in src_p                          # accepted, not forwarded (infer_panorama.py:101)
-    # and the writer itself: channel R of the file is array[..., 0]
+    from click.testing import CliRunner
+    assert "--reference_compat" in CliRunner().invoke(SP.main, ["--help"]).output
+    # the writers themselves: channel R of the EXR is array[..., 0] ...
     from moge_amd import io as IO
     pts = np.arange(2 * 3 * 3, dtype=np.float32).reshape(2, 3, 3)
-    IO.save_exr(tmp_path / "p.exr", pts[..., ::-1])
+    IO.save_exr(tmp_path / "p.exr", pts)
     back = IO.read_exr(tmp_path / "p.exr")                                            # (H, W, 3) in R, G, B order
-    assert np.array_equal(back[..., 0], pts[..., 2]) and np.array_equal(back[..., 2], pts[..., 0])
+    assert np.array_equal(back, pts)
+    # ... and the GLB texture orientation: a mesh built from a map whose TOP row is red must sample red at its top vertices.  glTF's uv origin is the
+    # image's top-left corner, so the stored v of a top-row vertex must be < 0.5 when the caller passes v-up uvs (what the CLI now does)
+    H, W = 4, 6
+    img = np.zeros((H, W, 3), np.uint8)
+    img[0] = (255, 0, 0)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    points = np.stack([xx, -yy, np.ones_like(xx)], -1)                                # y up: the top image row has the largest y
+    faces, vertices, colors, uvs = IO.build_mesh_from_map(points, img.astype(np.float32) / 255, IO.uv_map(H, W), tri=True)
+    IO.save_glb(tmp_path / "m.glb", vertices, faces, uvs * [1, -1] + [0, 1], img)
+    raw = (tmp_path / "m.glb").read_bytes()
+    jlen = struct.unpack_from("<I", raw, 12)[0]
+    gltf = json.loads(raw[20:20 + jlen])
+    bin0 = 20 + jlen + 8
+    acc = gltf["accessors"][gltf["meshes"][0]["primitives"][0]["attributes"]["TEXCOORD_0"]]
+    bv = gltf["bufferViews"][acc["bufferView"]]
+    st = np.frombuffer(raw, "<f4", acc["count"] * 2, bin0 + bv["byteOffset"]).reshape(-1, 2)
+    top = vertices[:, 1] == vertices[:, 1].max()
+    assert top.any() and (st[top, 1] < 0.5).all() and (st[~top, 1] > st[top, 1].max()).all()
+    assert (colors[top][:, 0] > 0.99).all()                                           # and those vertices are the red ones
