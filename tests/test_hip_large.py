@@ -21,9 +21,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("H,W,tokens", [(1000, 1500, 1200), (3000, 4000, 1800)])
 def test_native_size_images_match_the_oracle_fp32(MoGeModel, tmp_path_factory, H, W, tokens):
-    """1.5 MP (the example images' native size) and 12 MP, batch 2, fp32 mode vs the oracle: every pixel within 1e-3, mask bit-exact.  Knife-edge
-    pixels (mask logit or z + shift within float rounding of its threshold, identified from the ORACLE's own margins) are exempt and counted:
-    at most 2 per million."""
+    """1.5 MP (the example images' native size) and 12 MP, batch 2, fp32 mode vs the oracle: every pixel within 1e-3, mask bit-exact except knife-edge
+    pixels (see below: identified from the oracle's own margins, at most 2 per million)."""
     from oracle import moge_oracle as O
     model, cfg, sd = get_model(MoGeModel, "tiny-vits-normal", 0, True, tmp_path_factory)
     x = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(H + W))
@@ -31,11 +30,16 @@ def test_native_size_images_match_the_oracle_fp32(MoGeModel, tmp_path_factory, H
     trace = {}
     ref = O.infer(cfg, sd, x, num_tokens=tokens, trace=trace)
     assert out["points"].shape == (2, H, W, 3) and out["mask"].shape == (2, H, W)
+    # mask = sigmoid > 0.5 and z + shift > 0 (v2.py:253,268): at 3-24 M pixels a handful land within the fp32 forward noise (5e-6 relative) of a threshold.
+    # ONLY pixels whose mask actually differs are exempt, each must sit within 2e-5 of a threshold by the ORACLE's own margins, and there may be at most
+    # 3 + 2 per million of them
     prob = trace["forward"]["mask"].reshape(2, H, W)
     z = trace["forward"]["points"].reshape(2, H, W, 3)[..., 2] + trace["shift"].reshape(2, 1, 1)
-    knife = ((prob - 0.5).abs() < 2e-6) | (z.abs() < 2e-6 * z.abs().median())
-    assert int(knife.sum()) <= 3 + 2 * (2 * H * W) // 1000000, int(knife.sum())
+    near = ((prob - 0.5).abs() < 2e-5) | (z.abs() < 2e-5 * z.abs().median())
     res = {k: v.cpu().clone() for k, v in out.items()}
+    knife = res["mask"] != ref["mask"]
+    assert not bool((knife & ~near).any()), f"{int((knife & ~near).sum())} mask pixels differ away from any threshold"
+    assert int(knife.sum()) <= 3 + 2 * (2 * H * W) // 1000000, int(knife.sum())
     for k in ("points", "depth", "mask", "normal"):
         if k in res:
             res[k][knife] = ref[k][knife]

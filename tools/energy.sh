@@ -44,10 +44,10 @@ PY
 }
 {
   echo "# tools/energy.sh: steady-state socket power (rocm-smi, 0.25 s samples) while tools/kbench repeats ONE kernel; J/TFLOP = W / (TF/s); random operands"
-  for s in qkv proj.h16 fc1 fc2.h16 outproj; do KB_EXACT=1 KB_P=1 KB_ROUNDS=1 run "gemm $s (persistent, fused epilogue)" timeout 120 ./tools/kbench gemm $s ${EN_ITERS:-2500}; done
-  run "attention vitl b32 N3601 (mq<4>)" timeout 120 ./tools/kbench attn "vitl b32 N3601" ${EN_ATTN_ITERS:-600}
+  for s in ${EN_SHAPES:-qkv proj.h16 fc1 fc2.h16 outproj}; do KB_EXACT=1 KB_P=1 KB_ROUNDS=1 run "gemm $s (persistent, fused epilogue)" timeout 120 ./tools/kbench gemm $s ${EN_ITERS:-2500}; done
+  [ -z "$EN_NO_ATTN" ] && run "attention vitl b32 N3601 (mq<4>)" timeout 120 ./tools/kbench attn "vitl b32 N3601" ${EN_ATTN_ITERS:-600}
   echo "# bare MFMA chains for comparison (tools/mfma_power, MFMA_POWER_SECONDS=3):"
-  [ -x tools/mfma_power ] && MFMA_POWER_SECONDS=3 ./tools/mfma_power 2>&1 | tail -12
+  [ -z "$EN_NO_ATTN" ] && [ -x tools/mfma_power ] && MFMA_POWER_SECONDS=3 ./tools/mfma_power 2>&1 | tail -12
 } > $out 2>&1
 cat $out
 rm -f /tmp/smi.$$ /tmp/kb.$$

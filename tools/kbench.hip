@@ -190,6 +190,7 @@ static int bench_gemm(const char* filter, int iters) {
                                        {"stagger 8", 1, 2, 0, 2, 0, 3, 512, 8}, {"stagger 16", 1, 2, 0, 2, 0, 3, 512, 16}, {"stagger 32", 1, 2, 0, 2, 0, 3, 512, 32}};      // start-phase groups of the persistent GEMM (round 5)
     if (getenv("KB_P")) variants = {{"pp128p", 1, 2, 0, 2, 0}};      // the product kernel alone (A-B of two library builds: tools/gpu_call.sh kb_ab)
     if (getenv("KB_PPX")) variants = {{"pp128p", 1, 2, 0, 2, 0}, {"x:pp128p-mrg", 1, 2, 0, 3, 0}, {"x:pp128p-wm", 1, 2, 0, 4, 0}};      // --experiments builds
+    if (getenv("KB_DBG")) for (Variant& v : variants) v.dbg = atoi(getenv("KB_DBG"));      // tile columns per group of the persistent walk (PP_DBG), every variant
     int fails = 0;
     for (const Shape& s : shapes) {
         if (filter && (getenv("KB_EXACT") ? strcmp(s.name, filter) != 0 : !strstr(s.name, filter))) continue;      // KB_EXACT: the one shape of that name
