@@ -665,6 +665,7 @@ __global__ __launch_bounds__(256, QB > 2 ? 2 : 3) void attn_pp16mq_kernel(const 
 }
 
 #ifdef MOGE_EXPERIMENTS
+#include "../../tools/experiments/attention_pp16s_exp.inc"     // attn_pp16s_kernel: block-pipelined single-stream form (round 6; bit-identical, 11-27 % slower)
 #include "../../tools/experiments/attention_pp16x_exp.inc"     // attn_pp16x_kernel: the 8-wave ping-pong form (round 5; bit-identical, 13 % slower: DESIGN.md)
 #endif
 
@@ -716,6 +717,28 @@ static int launch_attn_pp16(const void* q, const void* k, const void* v, void* o
                 hipLaunchKernelGGL(attn_pp16x_kernel<0>, dim3(nblk, B * nh), dim3(512), smem_x, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr);
             }
             const int covered = nblk * 512;
+            if (covered < Ntok) {
+                if (int rc = set_dyn_lds<attn_pp16mq_kernel<4>>(smem)) return rc;
+                hipLaunchKernelGGL(attn_pp16mq_kernel<4>, dim3((Ntok - covered + 255) / 256, B * nh), dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr, covered);
+            }
+            return (int)hipGetLastError();
+        }
+#endif
+#ifdef MOGE_EXPERIMENTS
+        // attn_pp16s_kernel (software-pipelined, one wave per SIMD): the FULL 256-query blocks of every head; the rest of a head (N = 3601: 17 queries) on
+        // attn_pp16mq<4>'s tail path.  Bit-identical to attn_pp16mq<2> / <4>.  ATTN_KERN 6 forces it (7: its two-workgroups-per-CU build)
+        const int sfull = Ntok / 256;
+        if ((akern == 6 || akern == 7) && sfull > 0 && Ntok > 128) {
+            constexpr int smem_s = APS_NSTG * AP_STAGE + 4 * 8192;      // ring + the four waves' Q fragments
+            if (akern == 6) {
+                if (int rc = set_dyn_lds<attn_pp16s_kernel<1>>(smem_s)) return rc;
+                hipLaunchKernelGGL(attn_pp16s_kernel<1>, dim3(sfull, B * nh), dim3(256), smem_s, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr);
+            } else {
+                constexpr int smem_s2 = 5 * AP_STAGE;
+                if (int rc = set_dyn_lds<attn_pp16s_kernel<2>>(smem_s2)) return rc;
+                hipLaunchKernelGGL(attn_pp16s_kernel<2>, dim3(sfull, B * nh), dim3(256), smem_s2, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr);
+            }
+            const int covered = sfull * 256;
             if (covered < Ntok) {
                 if (int rc = set_dyn_lds<attn_pp16mq_kernel<4>>(smem)) return rc;
                 hipLaunchKernelGGL(attn_pp16mq_kernel<4>, dim3((Ntok - covered + 255) / 256, B * nh), dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr, covered);

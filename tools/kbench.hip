@@ -415,6 +415,8 @@ static int bench_attn(const char* filter, int iters) {
         struct Var { const char* name; int kind, exp, var; int kern = 0; };
         // kern 4 = attn_pp16x_kernel (ping-pong wave groups) [+ attn_pp16mq on the queries beyond the last full 512-block]; 5 = the same with s_setprio 1 in the M phase
         std::vector<Var> vars = {{"pp16", 1, 0, 0, 0}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}};
+        // kern 6 / 7 = attn_pp16s_kernel (software-pipelined; one / two workgroups per CU) [+ attn_pp16mq<4> on the queries beyond the last full 256-block]
+        if (getenv("KB_S")) vars = {{"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"s1", 1, 0, 0, 6}, {"s2", 1, 0, 0, 7}, {"mq<4>", 1, 0, 0, 2}, {"s1", 1, 0, 0, 6}, {"s2", 1, 0, 0, 7}};
 #ifdef MOGE_EXPERIMENTS
         if (getenv("KB_X")) vars = {{"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"x+prio", 1, 0, 0, 5}};
 #endif
