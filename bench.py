@@ -24,6 +24,8 @@ Prints ONE JSON line on rank 0.  Extra objects:
   fp16_forms      the reference has two fp16 forms: `value` is model.half(); the rate of infer(use_fp16=True) on fp32 weights (= torch.autocast:
                   fp32 residual stream) is reported beside it, never as `value`
   rccl            N>1: ranks RCCL saw (all-reduce of ones), bytes and seconds of the one-time weight broadcast
+  roofline_classes  the same object for the attention and decoder-conv classes (achieved / frac from the profiled pass, clock / MFMA-busy / fabric traffic
+                  per launch from the committed PMC passes: moge_amd/pmc_traffic.json "classes", which names its profiles/ files)
   kernel_classes  per-class ms/step, TFLOP/s, GB/s of that profiled pass;  whole_path: end-to-end MFMA fraction
   pcie_inclusive  images/s of the caller-side pipeline (host uint8 in, all maps back to pinned host memory) - N=1 only, never `value`
   load_seconds    from_pretrained(.pt) vs from_blob(packed master blob) to a ready model
@@ -489,6 +491,27 @@ def main():
                 res["roofline"]["sustained_peak"] = sj["tflops"]
                 res["roofline"]["frac_of_sustained"] = round(ach / sj["tflops"], 4)
                 res["roofline"]["sustained_source"] = sj["source"]
+            # the other two MFMA classes of the step, each reproducible from this line + the named profiles/ files: achieved = algorithmic
+            # FLOPs / HIP-event time of the class in the profiled pass above; clock, MFMA-busy and fabric traffic per launch from the committed rocprofv3 passes
+            res["roofline_classes"] = {}
+            tj_classes = {}
+            if default_workload and os.path.exists(tpath):
+                with open(tpath) as f:
+                    tj_classes = json.load(f).get("classes", {})
+            for cname, pkey, what in (("attn", "attn", "attn_pp16mq_kernel<4> (flash attention, head_dim 64; bound: MFMA + transcendental issue)"),
+                                      ("conv", "conv", "conv_pp_kernel (3x3 / 4-phase resampler convs) + ConvTranspose2d-as-GEMM + 1x1 input blocks of the decoder")):
+                pv = prof[pkey]
+                if not pv["launches"] or pv["ms"] <= 0:
+                    continue
+                a = pv["flops"] / (pv["ms"] * 1e-3) / 1e12
+                rc = {"bound": "mfma", "kernel": what, "achieved": round(a, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(a / PEAK_F16_TFLOPS, 4),
+                      "ms_per_step": round(pv["ms"] / args.steps, 3), "launches_per_step": pv["launches"] // args.steps,
+                      "algorithmic_bytes_per_launch": round(pv["bytes"] / pv["launches"]), "traffic": None}
+                tc = tj_classes.get(cname)
+                if tc:
+                    rc.update({"traffic": round(tc["traffic_bytes"] / tc["launches"]), "traffic_unit": "bytes per launch (fabric reads x2-corrected + writes), full-size launches of the PMC pass",
+                               "clock_ghz": tc.get("clock_ghz"), "mfma_busy_at_that_clock": tc.get("mfma_busy_at_that_clock"), "profiles": tc.get("files")})
+                res["roofline_classes"][cname] = rc
             tot_ms = sum(v["ms"] for v in prof.values())
             tot_fl = sum(v["flops"] for v in prof.values())
             res["kernel_classes"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),

@@ -46,11 +46,58 @@ def main(tag):
             if "gemm_pp128p" in p[0] and int(rec["blocks"]) >= 256 and "clock_ghz" in rec:
                 w = int(rec["calls"]) * float(rec["avg_us"])
                 clock += w * float(rec["clock_ghz"]); util += w * float(rec["mfma_util"]); tw += w
+    # ---- the other two MFMA classes of the step: attention and the decoder convolutions, full-size (batch-32) launches only -
+    # per class: launches, summed time, fabric bytes (same corrections), time-weighted clock and MFMA-busy fraction
+    def cls_of(name, blocks, avg_us):
+        if avg_us < 100:                                  # the batch-1 launches of the latency leg
+            return None
+        if "attn_pp16" in name:
+            return "attn"
+        if "conv_pp_kernel" in name or "gemm_pp128p_kernel<4" in name or "gemm_pp128m16_kernel<4" in name:      # <4> = EPK_CONVT: ConvTranspose2d as a GEMM
+            return "conv"
+        return None
+    classes = {}
+    mrows = {}
+    if os.path.exists(mpath):
+        lines = open(mpath).read().strip().splitlines()
+        hdr = lines[0].split(",")
+        for ln in lines[1:]:
+            p = ln.rsplit(",", len(hdr) - 1)
+            mrows[(p[0], int(p[1]))] = dict(zip(hdr[1:], p[1:]))
+    for k, (c, f) in F.items():
+        if k not in W:
+            continue
+        # FETCH pass: avg_us column is p[3]; reload it
+        cl = None
+        for ln in open(os.path.join(ROOT, "profiles", f"{tag}_pmc_FETCH_SIZE.csv")).read().strip().splitlines()[1:]:
+            q = ln.rsplit(",", 4)
+            if (q[0], int(q[1])) == k:
+                cl = cls_of(k[0], k[1], float(q[3]))
+                avg_us = float(q[3])
+                break
+        if not cl:
+            continue
+        d = classes.setdefault(cl, {"launches": 0, "us": 0.0, "fetch_bytes": 0.0, "write_bytes": 0.0, "_cw": 0.0, "_uw": 0.0, "_tw": 0.0, "kernels": []})
+        d["launches"] += c; d["us"] += c * avg_us
+        d["fetch_bytes"] += c * f * 1024 * 2; d["write_bytes"] += c * W[k][1] * 1024
+        d["kernels"].append(f"{k[0]} x{k[1]}")
+        m = mrows.get(k)
+        if m and "clock_ghz" in m:
+            w = int(m["calls"]) * float(m["avg_us"])
+            d["_cw"] += w * float(m["clock_ghz"]); d["_uw"] += w * float(m["mfma_util"]); d["_tw"] += w
+    cls_out = {}
+    for cl, d in classes.items():
+        cls_out[cl] = {"launches": d["launches"], "kernel_ms": round(d["us"] / 1e3, 3),
+                       "traffic_bytes": round(d["fetch_bytes"] + d["write_bytes"]), "fetch_bytes": round(d["fetch_bytes"]), "write_bytes": round(d["write_bytes"]),
+                       "clock_ghz": round(d["_cw"] / d["_tw"], 3) if d["_tw"] else None, "mfma_busy_at_that_clock": round(d["_uw"] / d["_tw"], 3) if d["_tw"] else None,
+                       "kernels": sorted(set(d["kernels"])),
+                       "files": [f"profiles/{tag}_pmc_FETCH_SIZE.csv", f"profiles/{tag}_pmc_WRITE_SIZE.csv", f"profiles/{tag}_pmc_MFMA.csv", f"profiles/{tag}_kernels_by_grid.csv"]}
     out = {
         "kernel": "gemm_pp128p_kernel", "launches": calls,
         "clock_ghz": round(clock / tw, 3) if tw else None, "mfma_busy_at_that_clock": round(util / tw, 3) if tw else None,
         "fetch_bytes_per_launch": round(fb / calls), "write_bytes_per_launch": round(wb / calls),
         "traffic_bytes_per_launch": round((fb + wb) / calls),
+        "classes": cls_out,
         "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs, --kernel-trace only) of `python bench.py --steps 2 "
                   f"--warmup 1` with MOGE_BATCH_SPLIT=0; profiles/{tag}_pmc_FETCH_SIZE.csv + profiles/{tag}_pmc_WRITE_SIZE.csv; KiB -> bytes; "
                   "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); Infinity-Cache hits are "
