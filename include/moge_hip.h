@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MOGE_ABI_VERSION 4
+#define MOGE_ABI_VERSION 5
 #define MOGE_MAX_TAPS 8
 #define MOGE_LEVELS 5
 
@@ -309,6 +309,18 @@ typedef struct moge_test_conv_args {
     const float* dot_w; int32_t dot_rows;    /* up2 + fused 1x1 output conv (fp16, Cin 64, Cout 32): dot_w (dot_rows <= 4, 32) fp32; y is then (B,2H,2W,4) */
 } moge_test_conv_args;
 int moge_test_conv_ex(const moge_test_conv_args* args, void* stream);
+/* ConvTranspose2d(k2, s2) + the 3x3 replicate-padded conv behind it (modules.py:160-165) through the fused path of the fp16 decoder (conv_pp.hip CT3: one composed
+ * 4-phase conv on the low-res map + the border ring; Cin = 2 Cout, Cout 128 or 64; precision must be MOGE_FP16):
+ *   y = conv3x3(convT(x; wt, bt); w3, b3) [+ side_w . side] [+ wu u + wv v at the output resolution]                 y, side (B,2H,2W,Cout)
+ * no_border = 1 skips the border correction (tests: the interior must already be exact).  All pointers DEVICE fp32, NHWC maps, torch weight layouts. */
+typedef struct moge_test_ct3_args {
+    int32_t precision, B, H, W, Cin, Cout, no_border;
+    const float* x; const float* wt; const float* bt; const float* w3; const float* b3;
+    const float* side; const float* side_w;
+    const float* wu; const float* wv; float u0, u1, v0, v1;
+    float* y;
+} moge_test_ct3_args;
+int moge_test_ct3(const moge_test_ct3_args* args, void* stream);
 /* ConvTranspose2d k2 s2, NHWC: x (B,H,W,Cin), w (Cin,Cout,2,2) torch layout, y (B,2H,2W,Cout) */
 int moge_test_convt2x2(int precision, const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
                        int Cin, int Cout, void* stream);

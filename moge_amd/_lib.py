@@ -21,7 +21,7 @@ RES_NORM = {"none": 0, "layer_norm": 1, "group_norm": 2, "instance_norm": 3}    
 ACTIVATION = {"relu": 0, "leaky_relu": 1, "silu": 2, "elu": 3}                          # moge_activation (modules.py:31-40)
 ERR_NONFINITE = -5
 KC_NAMES = ["gemm", "attn", "conv", "norm", "pre", "post", "recover", "gemm_pp"]
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class MogeConfig(C.Structure):
@@ -77,6 +77,13 @@ class TestConvArgs(C.Structure):
                 ("w2", C.c_void_p), ("bias2", C.c_void_p), ("y", C.c_void_p), ("dot_w", C.c_void_p), ("dot_rows", C.c_int32)]
 
 
+class TestCt3Args(C.Structure):
+    """moge_test_ct3_args (tests only): ConvTranspose2d + 3x3 through the fused path of the fp16 decoder."""
+    _fields_ = [("precision", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("no_border", C.c_int32),
+                ("x", C.c_void_p), ("wt", C.c_void_p), ("bt", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p), ("side", C.c_void_p), ("side_w", C.c_void_p),
+                ("wu", C.c_void_p), ("wv", C.c_void_p), ("u0", C.c_float), ("u1", C.c_float), ("v0", C.c_float), ("v1", C.c_float), ("y", C.c_void_p)]
+
+
 class MogeError(RuntimeError):
     pass
 
@@ -120,6 +127,7 @@ def _load() -> C.CDLL:
         "moge_test_conv3x3": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, vp]),
         "moge_test_conv_ex": (C.c_int, [C.POINTER(TestConvArgs), vp]),
         "moge_test_convt2x2": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, vp]),
+        "moge_test_ct3": (C.c_int, [C.POINTER(TestCt3Args), vp]),
         "moge_test_preprocess": (C.c_int, [f32p, f32p, i32, i32, i32, i32, i32, vp]),
         "moge_test_resize_bicubic_aa": (C.c_int, [f32p, f32p, i32, i32, i32, i32, i32, vp]),
         "moge_test_groupnorm_relu": (C.c_int, [i32, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, vp]),
@@ -144,7 +152,7 @@ lib = _load()
 EXPORTS = ["moge_abi_version", "moge_last_error", "moge_create", "moge_create_v1", "moge_v1_forward", "moge_v1_infer", "moge_destroy", "moge_load_weights", "moge_alloc_master",
            "moge_master_blob", "moge_master_ready", "moge_broadcast_weights", "moge_set_precision", "moge_set_onnx_compatible_mode", "moge_workspace_bytes", "moge_forward", "moge_infer",
            "moge_postprocess", "moge_depth_edge_mask", "moge_cast_f16", "moge_sync", "moge_profile_enable", "moge_profile_read", "moge_debug_tap", "moge_tune_set", "moge_test_gemm",
-           "moge_test_gemm_ex", "moge_test_layernorm", "moge_test_attention", "moge_test_conv3x3", "moge_test_conv_ex", "moge_test_convt2x2", "moge_test_preprocess",
+           "moge_test_gemm_ex", "moge_test_layernorm", "moge_test_attention", "moge_test_conv3x3", "moge_test_conv_ex", "moge_test_convt2x2", "moge_test_ct3", "moge_test_preprocess",
            "moge_test_resize_bicubic_aa", "moge_test_groupnorm_relu", "moge_test_norm_act", "moge_test_posembed", "moge_test_recover",
            "moge_align_l1", "moge_align_l1_anchored", "moge_align_select", "moge_align_lstsq"]
 

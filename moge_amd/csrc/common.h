@@ -247,6 +247,10 @@ struct GemmArgs {
     const void* dot_tab;
     float* dot_out;
     int dot_nd;
+    // conv_pp.hip CT3 (round 6): ConvTranspose2d(k2, s2) + the 3x3 conv behind it as one 4-phase 2x2-tap conv on the low-res map: a = (B, H, W, C) low-res input,
+    // w = composed weights [4 Cout][4 C] (row = phase * Cout + co, column = tap * C + ci), N = 4 Cout, K = 4 C, epi = EPI_CONVT, a2 = optional HIGH-res side map
+    // (B, 2H, 2W, Cout) with w2 [Cout][Cout].  The border ring is corrected afterwards by launch_ct3_border.
+    int ct3;
 };
 
 // Opt a kernel into more than 64 KiB of dynamic LDS.  The attribute is per DEVICE and a process may drive several (one host thread per
@@ -286,6 +290,12 @@ bool gemm_runs_pp(const GemmArgs& g);       // launch_gemm<f16>(g, AMODE_LINEAR)
 int launch_gemm_pp(const GemmArgs& g, hipStream_t st);
 bool conv_pp_eligible(const GemmArgs& g);
 int launch_conv_pp(const GemmArgs& g, hipStream_t st);
+// one composed weight block of the CT3 forms = a signed sum of basic products P(k, s) (elementwise.hip ct3_combine_kernel): term = k | s << 4 | (negative ? 256 : 0)
+struct Ct3Slot { int rowblk, colblk, nterms; int term[13]; };
+int launch_ct3_combine(const float* P, const Ct3Slot* slots_dev, int nslots, int Cout, int Cin, void* out, int ld, hipStream_t st);
+// CT3 border: out (B, 2H, 2W, Cout) f16 += difference between replicate padding and what the composed conv computes on the outermost ring of output pixels;
+// dw = border weights [12 classes][Cout][2 Cin] f16 (elementwise.hip compose_ct3), in = low-res input (B, H, W, Cin) f16
+int launch_ct3_border(const void* in, const void* dw, void* out, int B, int H, int W, int Cin, int Cout, hipStream_t st);
 bool conv_rb_eligible(const GemmArgs& g);   // conv_rb.hip: fp16 residual block with the intermediate map kept in LDS (C = 64)
 int launch_conv_rb(const GemmArgs& g, hipStream_t st);
 // runtime tuning / A-B switches (tests, tools/kbench): see tune.cpp-style table in gemm.hip

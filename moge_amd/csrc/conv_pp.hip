@@ -74,6 +74,17 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     // 2 x 1.9 GB written and 4 x 1.9 GB read per step (head_final) for 3 + 1 useful channels.
     constexpr bool DOT = (EPI & 32) != 0;
     static_assert(!DOT || (CONVT && M16 && BN == 128), "fused output conv: the 64 -> 4 x 32 pixel-shuffle resampler");
+    // EPI bit 6 (with bits 1 and 3; round 6): CT3 - ConvTranspose2d(k2, s2) and the 3x3 conv behind it (modules.py:160-165) as ONE conv on the LOW-res map.
+    // Output pixel (2y + py, 2x + px) sees the low-res pixels (y + py - 1 + tdy, x + px - 1 + tdx), tdy, tdx in {0, 1}: four taps per phase, the weights
+    // of (phase, tap) pre-composed at pack time (sum over the 3x3 taps that fall on that low-res pixel of W3 . WT, elementwise.hip compose_ct3).  A workgroup
+    // owns ONE phase (BN = Cout; column block = phase), its K loop is 4 taps x Cin / 64 chunks on the same 18 x 18 halo image the 3x3 kernel loads, the
+    // pixel-shuffle epilogue stores (B, 2H, 2W, Cout).  16 Cin Cout MACs per output pixel instead of 2 Cin Cout + 9 Cout Cout... (Cin = 2 Cout: 16 vs 22 Cout^2),
+    // and the (B, 2H, 2W, Cout) map between the two never exists.  The fused 1x1 side input (heads) reads the HIGH-res map a2 at (2y + py, 2x + px).
+    // Replicate padding does not commute with the transposed conv: on the outermost ring of output pixels the composed form equals a REFLECTING pad;
+    // launch_ct3_border (below) adds the difference for those pixels afterwards.
+    constexpr bool CT3 = (EPI & 64) != 0;
+    static_assert(!CT3 || (CONVT && M16 && !DOT && !RELU_IN && !SIDE_REG && NH == 2), "fused ConvTranspose2d + 3x3: pixel-shuffle store, 16x16x32 form, two halo buffers");
+    constexpr int NTAP = CT3 ? 4 : 9;
     static_assert(!SIDE_REG || (M16 && BN == 64 && NH == 1), "register side input: single-image 64-channel form");
     constexpr int WN = BN / 64, WM = 8 / WN, TM = TW * 16 / 32 / WM, TN = 2;
     constexpr int HALO_W = Halo<TW>::W, HALO_PX = Halo<TW>::PX, HALO_PIECES = Halo<TW>::PIECES, HALO_BYTES = Halo<TW>::BYTES, HPW = Halo<TW>::HPW;
@@ -117,8 +128,9 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     if (li >= cnt) return;
     int b, y0, x0, n0;                                  // the tile this workgroup is computing / storing
     const int nchunks = NH == 1 ? 1 : (C >> 6);        // NH == 1: Cin == 64, straight-line 9-step K loop
-    const int nside = SIDE_REG ? 1 : ((NH > 1 && g.a2) ? (C >> 6) : 0);  // fused 1x1 side input: one centre-tap K-step per 64 channels of a2
-    const int nkt1 = nchunks * 9;
+    const int C2 = CT3 ? g.Cout : C;                   // channels of the side map (CT3: the high-res map has Cout channels)
+    const int nside = SIDE_REG ? 1 : ((NH > 1 && g.a2) ? (C2 >> 6) : 0);  // fused 1x1 side input: one centre-tap K-step per 64 channels of a2
+    const int nkt1 = nchunks * NTAP;
     const int nkt = nkt1 + nside;
 
     // ---- DMA sources ----------------------------------------------------------------------------------------------
@@ -128,6 +140,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     const char* w_b;
     const char* w2_b;                   // [N][C] 1x1 weights of the side input
     unsigned hoff[HPW];                 // byte offset of this lane's source chunk for halo piece i (chunk 0 of Cin)
+    unsigned hoff2[CT3 ? HPW : 1];      // CT3: the same for the side map (high-res pixel (2 yy + py, 2 xx + px), Cout channels)
     int sb, sy0, sx0, sn0;              // coordinates of that tile
     auto setup = [&](int idx) {
         // (opaque per call: the per-piece halo coordinates below are tile-invariant, and hoisted out of the tile loop they cost ~20 VGPRs that the
@@ -141,9 +154,10 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
         const int ty = t % ty_n;
         sb = t / ty_n; sy0 = ty * 16; sx0 = tx * TW; sn0 = bn_ * BN;
         in_b = reinterpret_cast<const char*>(g.a) + (size_t)sb * H * W * C * 2;
-        in2_b = reinterpret_cast<const char*>(g.a2) + (size_t)sb * H * W * C * 2;
+        in2_b = reinterpret_cast<const char*>(g.a2) + (size_t)sb * H * W * C2 * (CT3 ? 8 : 2);
         w_b = reinterpret_cast<const char*>(g.w) + (size_t)sn0 * g.ldw * 2;
-        w2_b = reinterpret_cast<const char*>(g.w2) + (size_t)sn0 * C * 2;
+        w2_b = reinterpret_cast<const char*>(g.w2) + (CT3 ? (size_t)0 : (size_t)sn0 * C * 2);      // CT3: BN = Cout, every phase block multiplies by all rows of w2
+        const int spy = CT3 ? (sn0 / BN) >> 1 : 0, spx = CT3 ? (sn0 / BN) & 1 : 0;
 #pragma unroll
         for (int i = 0; i < HPW; i++) {
             int piece = wave + 8 * i;
@@ -160,6 +174,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
             yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);                    // replicate padding (modules.py:53)
             xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
             hoff[i] = (unsigned)(((yy * W + xx) * C) * 2 + ((pch_t ^ sw) << 4));
+            if constexpr (CT3) hoff2[i] = (unsigned)((((2 * yy + spy) * (2 * W) + 2 * xx + spx) * C2) * 2 + ((pch_t ^ sw) << 4));
         }
     };
     int wrow[NWP];                      // weight-tile row and swizzled chunk offset of this lane in piece i
@@ -172,19 +187,22 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     auto issue_halo = [&](int c) {               // chunk c of the conv input, or chunk c - nchunks of the side input
         char* dst = smem + (c & (NH - 1)) * HALO_BYTES;
         const char* src = uniform_ptr(c < nchunks ? in_b + (size_t)c * 128 : in2_b + (size_t)(c - nchunks) * 128);
+        const bool side2 = CT3 && c >= nchunks;
 #pragma unroll
         for (int i = 0; i < HPW; i++) {
             int piece = wave + 8 * i;
             piece = piece < HALO_PIECES ? piece : HALO_PIECES - 1;
-            __builtin_amdgcn_global_load_lds(CP_GPTR(src + cp_opaque(hoff[i])), CP_LPTR(dst + piece * 1024), 16, 0, 0);
+            unsigned off = hoff[i];
+            if constexpr (CT3) off = side2 ? hoff2[i] : off;
+            __builtin_amdgcn_global_load_lds(CP_GPTR(src + cp_opaque(off)), CP_LPTR(dst + piece * 1024), 16, 0, 0);
         }
     };
     auto issue_w = [&](int kt) {                 // K-step kt = chunk * 9 + tap  ->  weight columns (tap * C + chunk * 64); side steps follow
         char* dst = smem + LDS_W + (kt & 3) * WSLOT;
         const bool side = kt >= nkt1;
-        const int c = kt / 9, tap = kt - c * 9;
+        const int c = CT3 ? kt >> 2 : kt / 9, tap = CT3 ? kt & 3 : kt - c * 9;
         const char* src = uniform_ptr(side ? w2_b + (size_t)(kt - nkt1) * 128 : w_b + ((size_t)tap * C + c * 64) * 2);
-        const int rowb = side ? C * 2 : g.ldw * 2;                   // row pitch of the side weights [N][C] / conv weights [N][9C]
+        const int rowb = side ? C2 * 2 : g.ldw * 2;                  // row pitch of the side weights [N][C2] / conv weights [N][9C] (CT3: [4 Cout][4 Cin])
 #pragma unroll
         for (int i = 0; i < NWP; i++) {
             const unsigned off = (unsigned)(wrow[i] * rowb) + wsw[i];
@@ -223,15 +241,18 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     // recomputation was ~20 VALU in every read segment - issued beside the partner wave's priority-1 MFMAs they cost ~10-20 clocks each and
     // made the READ segment the longer one: 128-channel K-steps 1780 clocks for 2 x 32 MFMAs.)
     int abase[3][2];
+    int tpy = 0;                                                          // CT3: row phase of the tile being computed (halo row offset of its taps)
     auto set_abase = [&]() {
+        const int tpx = CT3 ? (n0 / BN) & 1 : 0;
+        if constexpr (CT3) tpy = (n0 / BN) >> 1;
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            const int hx = l15t + d;                                       // halo column of tap dx = d - 1
+            // halo column of tap dx = d - 1;  CT3: d = 0, 1 are the phase's two taps (low-res column x + px - 1 + d), d = 2 the centre (side input)
+            const int hx = l15t + (CT3 ? (d == 2 ? 1 : tpx + d) : d);
             const int a = wm * (2 * TM * HALO_W * 128) + hx * 128 + ((g4 ^ (hx & 7)) << 4);
             abase[d][0] = a; abase[d][1] = a ^ 64;
         }
     };
-    if constexpr (M16) set_abase();
     u32x4 sidef[SIDE_REG ? 2 * TM : 1][2];      // SIDE_REG: B fragments of the side map (pixel block i, K-step ks)
     auto kstep = [&](const char* halo, int dy, int dx, bool first_of_image, int image, bool relu, bool from_regs = false) {
         const char* wsl = smem + LDS_W + (kt & 3) * WSLOT;
@@ -342,6 +363,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     for (;;) {                                      // ======== one tile per iteration ========
     b = sb; y0 = sy0; x0 = sx0; n0 = sn0;
     if constexpr (PERSIST) { asm volatile("" : "+v"(l15t)); if constexpr (M16) set_abase(); }
+    else if constexpr (M16) set_abase();
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -372,12 +394,18 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
 
     for (int c = 0; c < nchunks; c++) {
         const char* halo = smem + (c & (NH - 1)) * HALO_BYTES;
+        if constexpr (CT3) {
+            const char* hp = halo + tpy * (HALO_W * 128);             // taps (tdy, tdx): halo rows i + py + tdy, columns l15 + px + tdx (abase[tdx])
+#pragma unroll
+            for (int tap = 0; tap < 4; tap++) kstep(hp, (tap >> 1) - 1, (tap & 1) - 1, tap == 0, c, true);
+        } else {
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) kstep(halo, tap / 3 - 1, tap % 3 - 1, tap == 0, c, true);
+        }
     }
     if constexpr (SIDE_REG) kstep(smem, 0, 0, false, nchunks, false, true);
     else
-    for (int c2 = 0; c2 < nside; c2++) kstep(smem + ((nchunks + c2) & (NH - 1)) * HALO_BYTES, 0, 0, true, nchunks + c2, false);
+    for (int c2 = 0; c2 < nside; c2++) kstep(smem + ((nchunks + c2) & (NH - 1)) * HALO_BYTES, 0, CT3 ? 1 : 0, true, nchunks + c2, false);
 
     // ---- epilogue: bias / uv / ReLU in registers, transpose through LDS, (residual add,) 16-byte pixel-row stores -------------
     // Staging region of this wave: in the WEIGHT RING (every wave has passed the last barrier: all fragment reads are done), so that both halo
@@ -613,6 +641,14 @@ int launch_conv_cfg(const GemmArgs& g, hipStream_t st) {
 
 // AMODE_CONV3 problems the halo kernel takes (f16): Cin multiple of 64, N = 64 or a multiple of 128, plain / pixel-shuffle store
 bool conv_pp_eligible(const GemmArgs& g) {
+    if (g.ct3) {            // fused ConvTranspose2d + 3x3 (see the kernel): one phase per column block, BN = Cout
+        if ((g.C & 63) || g.K != 4 * g.C || g.ldw != 4 * g.C || !g.bias || g.epi != EPI_CONVT || g.N != 4 * g.Cout) return false;
+        if (g.Cout != 128 && g.Cout != 64) return false;
+        if (g.add || g.act != ACT_NONE || g.relu_in || g.dot_tab || (g.a2 && !g.w2)) return false;
+        if (g.H < 1 || g.W < 1 || (long)g.M % ((long)g.H * g.W) != 0) return false;
+        if ((long)g.H * g.W * g.C * 2 >= (1L << 31) || (long)g.H * g.W * g.Cout * 8 >= (1L << 31)) return false;      // 32-bit halo offsets (input / side map)
+        return true;
+    }
     if ((g.C & 63) || g.K != 9 * g.C || g.ldw != 9 * g.C || !g.bias) return false;
     if (g.N != 64 && (g.N & 127)) return false;
     if (g.H < 1 || g.W < 1 || (long)g.M % ((long)g.H * g.W) != 0) return false;
@@ -664,7 +700,87 @@ static int launch_conv_epi(const GemmArgs& g, hipStream_t st) {
     return -1;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// CT3 border (round 6).  The composed conv of conv_pp_kernel<..., CT3> indexes the LOW-res map with clamped coordinates, which on the high-res side is a
+// REFLECTING pad (row -1 -> row 1: low-res row 0 with the transposed conv's sy = 1), where the reference pads the ConvTranspose2d OUTPUT by replication
+// (row -1 -> row 0, modules.py:163).  The two agree everywhere except on the outermost ring of output pixels, where
+//     exact - composed = sum over the 3x3 taps (ky, kx) that leave the image of  P(ky, kx; parity of the replicated coordinate) . L(its cell)
+//                                                                               - P(ky, kx; parity of the reflected coordinate) . L(its cell),
+// P(ky, kx; sy, sx) = W3[:, :, ky, kx] . WT[:, :, sy, sx]^T.  Per border class (4 edges x 2 parities along the edge + 4 corners) these sums involve at most two
+// low-res cells and are pre-summed at pack time into dw[class][co][slot * Cin + ci]; this kernel evaluates them as small MFMA GEMMs (16 border pixels per
+// wave, A fragments straight from global: the weights are shared by every wave, 4 W + 4 H - 4 pixels per image) and adds the result to the stored output.
+// Classes: 0 / 1 top, px = 0 / 1 (cells (0, x + px - 1), (0, x + px));  2 / 3 bottom;  4 / 5 left, py = 0 / 1 (cells (y + py - 1, 0), (y + py, 0));  6 / 7 right;
+// 8 ... 11 corners TL TR BL BR (one cell).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int NJ>      // Cout / 16
+__global__ __launch_bounds__(256) void ct3_border_kernel(const f16* __restrict__ in, const f16* __restrict__ dw, f16* __restrict__ out, int B, int H, int W, int Cin) {
+    constexpr int Cout = NJ * 16;
+    const int cls = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int n_c = cls < 4 ? W - 1 : (cls < 8 ? H - 1 : 1);
+    const long Mc = (long)B * n_c;
+    const long m0 = (long)blockIdx.x * 64 + wave * 16;
+    if (m0 >= Mc) return;
+    long m = m0 + l15;
+    const bool valid = m < Mc;
+    m = valid ? m : Mc - 1;
+    const int b = (int)(m / n_c), idx = (int)(m - (long)b * n_c);
+    int Y, X, cy0, cx0, cy1, cx1;
+    if (cls < 4) {                                   // top / bottom edge
+        const int px = cls & 1, x = px ? idx : idx + 1;
+        Y = cls < 2 ? 0 : 2 * H - 1; X = 2 * x + px;
+        cy0 = cy1 = cls < 2 ? 0 : H - 1; cx0 = x + px - 1; cx1 = x + px;
+    } else if (cls < 8) {                            // left / right edge
+        const int py = cls & 1, y = py ? idx : idx + 1;
+        X = cls < 6 ? 0 : 2 * W - 1; Y = 2 * y + py;
+        cx0 = cx1 = cls < 6 ? 0 : W - 1; cy0 = y + py - 1; cy1 = y + py;
+    } else {                                         // corners
+        Y = (cls & 2) ? 2 * H - 1 : 0; X = (cls & 1) ? 2 * W - 1 : 0;
+        cy0 = cy1 = (cls & 2) ? H - 1 : 0; cx0 = cx1 = (cls & 1) ? W - 1 : 0;
+    }
+    f32x4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f16* wbase = dw + ((size_t)cls * Cout + l15) * (2 * Cin) + 8 * g4;
+    const int nslot = cls < 8 ? 2 : 1;
+    for (int slot = 0; slot < nslot; slot++) {
+        const f16* pp = in + (((size_t)b * H + (slot ? cy1 : cy0)) * W + (slot ? cx1 : cx0)) * Cin + 8 * g4;
+        const f16* wp = wbase + slot * Cin;
+        for (int kc = 0; kc < Cin; kc += 32) {
+            const u32x4 pf = *reinterpret_cast<const u32x4*>(pp + kc);
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const u32x4 wf = *reinterpret_cast<const u32x4*>(wp + (size_t)j * 16 * (2 * Cin) + kc);
+                mma16<f16>(acc[j], wf, pf);
+            }
+        }
+    }
+    if (!valid) return;
+    f16* op = out + (((size_t)b * 2 * H + Y) * (2 * W) + X) * Cout + 4 * g4;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        f16x4 v = *reinterpret_cast<const f16x4*>(op + j * 16);
+        v = f16x4{(f16)((float)v[0] + acc[j][0]), (f16)((float)v[1] + acc[j][1]), (f16)((float)v[2] + acc[j][2]), (f16)((float)v[3] + acc[j][3])};
+        *reinterpret_cast<f16x4*>(op + j * 16) = v;
+    }
+}
+
+int launch_ct3_border(const void* in, const void* dw, void* out, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+    if ((Cin & 31) || (Cout != 128 && Cout != 64) || H < 1 || W < 1) return -1;
+    const long mmax = (long)B * ((W > H ? W : H) - 1 > 1 ? (W > H ? W : H) - 1 : 1);
+    const dim3 grid((unsigned)((mmax + 63) / 64), 12);
+    if (Cout == 128) hipLaunchKernelGGL(ct3_border_kernel<8>, grid, dim3(256), 0, st, (const f16*)in, (const f16*)dw, (f16*)out, B, H, W, Cin);
+    else hipLaunchKernelGGL(ct3_border_kernel<4>, grid, dim3(256), 0, st, (const f16*)in, (const f16*)dw, (f16*)out, B, H, W, Cin);
+    return (int)hipGetLastError();
+}
+
 int launch_conv_pp(const GemmArgs& g, hipStream_t st) {
+    if (g.ct3) {
+        if (g.Cout == 128) return g.uv.wu ? launch_conv_cfg<128, 16, 2, 8 | 2 | 64 | 1>(g, st) : launch_conv_cfg<128, 16, 2, 8 | 2 | 64>(g, st);
+        return g.uv.wu ? launch_conv_cfg<64, 16, 2, 8 | 2 | 64 | 1>(g, st) : launch_conv_cfg<64, 16, 2, 8 | 2 | 64>(g, st);
+    }
     // a single halo image: one buffer.  A 64-channel layer with a side input runs on the single-buffer form too (side fragments in registers)
     const bool side_reg = g.C == 64 && g.N == 64 && g.a2 && !g.uv.wu && !g.relu_in && g.epi == EPI_STORE && moge_tune_get("CONV_SIDE_REG", 1);
     const bool one_image = g.C == 64 && (!g.a2 || side_reg);

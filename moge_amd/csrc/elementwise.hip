@@ -473,6 +473,33 @@ __global__ void repack_kernel(const float* src, TD* dst, int n0, int n1, int n2,
         dst[i0 * ds0 + i1 * ds1 + i2 * ds2 + i3] = (TD)src[i0 * ss0 + i1 * ss1 + i2 * ss2 + i3 * ss3];
     }
 }
+
+// --------------------------------------------------------------------------------------------
+// CT3 (conv_pp.hip, round 6): composed weights of ConvTranspose2d(k2, s2) + 3x3.  P[(k * Cout + co)][s * Cin + ci] (fp32) holds the 36 basic products
+// W3[:, :, k] . WT[:, :, s]^T (k = ky * 3 + kx, s = sy * 2 + sx; one fp32 GEMM in model.hip); every composed matrix - the 16 (phase, tap) blocks of the interior
+// conv, the 12 x 2 (border class, cell) blocks of the border correction - is a short signed sum of them, listed per output block in a term table built on
+// the host (model.hip ct3_slots).  One rounding to fp16 per composed weight.
+// --------------------------------------------------------------------------------------------
+__global__ void ct3_combine_kernel(const float* __restrict__ P, const Ct3Slot* __restrict__ slots, int Cout, int Cin, f16* __restrict__ out, int ld) {
+    const Ct3Slot sl = slots[blockIdx.y];
+    const long total = (long)Cout * Cin;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i / Cin), ci = (int)(i - (long)co * Cin);
+        float a = 0.f;
+        for (int t = 0; t < sl.nterms; t++) {
+            const int term = sl.term[t], k = term & 15, sidx = (term >> 4) & 3;
+            const float v = P[((size_t)k * Cout + co) * (4 * (size_t)Cin) + (size_t)sidx * Cin + ci];
+            a += (term & 256) ? -v : v;
+        }
+        out[((size_t)sl.rowblk * Cout + co) * ld + (size_t)sl.colblk * Cin + ci] = (f16)a;
+    }
+}
+int launch_ct3_combine(const float* P, const Ct3Slot* slots_dev, int nslots, int Cout, int Cin, void* out, int ld, hipStream_t st) {
+    if (nslots <= 0) return 0;
+    hipLaunchKernelGGL(ct3_combine_kernel, dim3((unsigned)(((long)Cout * Cin + 255) / 256), (unsigned)nslots), dim3(256), 0, st, P, slots_dev, Cout, Cin, (f16*)out, ld);
+    return (int)hipGetLastError();
+}
+
 template <typename TD>
 int launch_repack(const float* src, void* dst, int n0, int n1, int n2, int n3, long ss0, long ss1, long ss2, long ss3, long ds0, long ds1,
                   long ds2, hipStream_t st) {

@@ -29,6 +29,8 @@ template <typename TD>
 int launch_repack(const float* src, void* dst, int n0, int n1, int n2, int n3, long ss0, long ss1, long ss2, long ss3, long ds0, long ds1,
                   long ds2, hipStream_t st);
 
+// CT3 (conv_pp.hip): composed weights of ConvTranspose2d + 3x3 from the fp32 torch-layout weights (model.hip): wc f16 [4 co][4 ci], dw f16 [12][co][2 ci]
+int ct3_compose_device(const float* w3, const float* wt, int ci, int co, void* wc, void* dw, hipStream_t st);
 template <typename T> int launch_pack_phase_conv(const float* w, void* dst, int Cout, int Cin, hipStream_t st, int nearest = 0);      // nearest: x2 nearest instead of bilinear
 int launch_pack_dot_table(const float* w, int rows, int nd, void* tab, hipStream_t st);      // GemmArgs::dot_tab from fp32 rows [rows][32]
 // head_final on the fused output-conv maps (conv_pp.hip DOT): y (B,Hd,Wd,4) fp32 = Wo . x4, z (B,Hd,Wd,zld) fp32 with this head's group at

@@ -184,6 +184,61 @@ static bool stack_generic_blocks(const moge_config& c, bool neck) { return stack
 // groups of a residual-block norm on a C-channel map (modules.py:47-58)
 static int norm_groups(int mode, int C) { return mode == MOGE_NORM_LAYER ? 1 : mode == MOGE_NORM_INSTANCE ? C : (C / 32 > 0 ? C / 32 : 1); }
 
+
+// ---- CT3: ConvTranspose2d(k2, s2) + 3x3 composed (conv_pp.hip, round 6) ----------------------------------------------------------------------------
+// Worth it where the composed conv is cheaper than the pair: 16 Cin Cout MACs per output pixel against 2 Cin Cout + 9 Cout^2 -> Cin = 2 Cout (the released layout's
+// 256 -> 128 and 128 -> 64 resamplers; 1024 -> 256 would cost 23 % MORE).  One phase per column block of the kernel: Cout = 128 or 64.
+static bool ct3_shape(int ci, int co) { return ci == 2 * co && (co == 128 || co == 64); }
+// Term tables of the composed weight blocks (Ct3Slot, elementwise.hip ct3_combine_kernel).  P(k = ky * 3 + kx, s = sy * 2 + sx) = W3[:, :, ky, kx] . WT[:, :, sy, sx]^T.
+// Interior, phase (py, px), tap (tdy, tdx) = low-res pixel (y + py - 1 + tdy, x + px - 1 + tdx): the 3x3 taps whose high-res row 2y + py + ky - 1 lies in that
+// low-res row, with the parity it has there:   py = 0: tdy = 0 <- (ky 0, sy 1);  tdy = 1 <- (ky 1, sy 0), (ky 2, sy 1);   py = 1: tdy = 0 <- (ky 0, sy 0), (ky 1, sy 1);
+// tdy = 1 <- (ky 2, sy 0) - and the same along x.
+static void ct3_interior_slots(std::vector<Ct3Slot>& v) {
+    auto members = [](int p, int td, int (&kk)[2], int (&ss)[2]) -> int {
+        if (p == 0 && td == 0) { kk[0] = 0; ss[0] = 1; return 1; }
+        if (p == 0 && td == 1) { kk[0] = 1; ss[0] = 0; kk[1] = 2; ss[1] = 1; return 2; }
+        if (p == 1 && td == 0) { kk[0] = 0; ss[0] = 0; kk[1] = 1; ss[1] = 1; return 2; }
+        kk[0] = 2; ss[0] = 0; return 1;
+    };
+    for (int py = 0; py < 2; py++) for (int px = 0; px < 2; px++) for (int tdy = 0; tdy < 2; tdy++) for (int tdx = 0; tdx < 2; tdx++) {
+        Ct3Slot sl; memset(&sl, 0, sizeof(sl));
+        sl.rowblk = py * 2 + px; sl.colblk = tdy * 2 + tdx;
+        int ky[2], sy[2], kx[2], sx[2];
+        const int ny = members(py, tdy, ky, sy), nx = members(px, tdx, kx, sx);
+        for (int a = 0; a < ny; a++) for (int b2 = 0; b2 < nx; b2++) sl.term[sl.nterms++] = (ky[a] * 3 + kx[b2]) | ((sy[a] * 2 + sx[b2]) << 4);
+        v.push_back(sl);
+    }
+}
+// Border classes (conv_pp.hip ct3_border_kernel): exact (replicate-padded high-res map) minus composed (= reflecting pad), evaluated symbolically on a 4 x 4
+// low-res map for one representative pixel per class; every term lands on one of the class's two cells.
+static int ct3_border_slots(std::vector<Ct3Slot>& v) {
+    const int H = 4, W = 4;
+    struct Rep { int Y, X, cy0, cx0, cy1, cx1; };
+    const Rep reps[12] = {{0, 4, 0, 1, 0, 2}, {0, 3, 0, 1, 0, 2}, {7, 4, 3, 1, 3, 2}, {7, 3, 3, 1, 3, 2},
+                          {4, 0, 1, 0, 2, 0}, {3, 0, 1, 0, 2, 0}, {4, 7, 1, 3, 2, 3}, {3, 7, 1, 3, 2, 3},
+                          {0, 0, 0, 0, -1, -1}, {0, 7, 0, 3, -1, -1}, {7, 0, 3, 0, -1, -1}, {7, 7, 3, 3, -1, -1}};
+    for (int cls = 0; cls < 12; cls++) {
+        const Rep& r = reps[cls];
+        Ct3Slot sl[2]; memset(sl, 0, sizeof(sl));
+        sl[0].rowblk = sl[1].rowblk = cls; sl[0].colblk = 0; sl[1].colblk = 1;
+        for (int ky = 0; ky < 3; ky++) for (int kx = 0; kx < 3; kx++) {
+            const int rr = r.Y + ky - 1, cc = r.X + kx - 1;
+            const int r_rep = rr < 0 ? 0 : (rr > 2 * H - 1 ? 2 * H - 1 : rr), c_rep = cc < 0 ? 0 : (cc > 2 * W - 1 ? 2 * W - 1 : cc);
+            const int r_ref = rr < 0 ? 1 : (rr > 2 * H - 1 ? 2 * H - 2 : rr), c_ref = cc < 0 ? 1 : (cc > 2 * W - 1 ? 2 * W - 2 : cc);
+            if (r_rep == r_ref && c_rep == c_ref) continue;
+            for (int side = 0; side < 2; side++) {            // + replicated, - reflected
+                const int ry = side ? r_ref : r_rep, cx = side ? c_ref : c_rep;
+                const int cy = ry >> 1, cxx = cx >> 1, sidx = (ry & 1) * 2 + (cx & 1);
+                const int slot = (cy == r.cy0 && cxx == r.cx0) ? 0 : ((cy == r.cy1 && cxx == r.cx1) ? 1 : -1);
+                if (slot < 0 || sl[slot].nterms >= 13) return -1;
+                sl[slot].term[sl[slot].nterms++] = (ky * 3 + kx) | (sidx << 4) | (side ? 256 : 0);
+            }
+        }
+        v.push_back(sl[0]); v.push_back(sl[1]);
+    }
+    return 0;
+}
+
 static void build_tables_v2_decoder(moge_handle* h) {
     const moge_config& c = h->cfg;
     const int D = c.embed_dim, c0 = c.dims[0];
@@ -230,6 +285,12 @@ static void build_tables_v2_decoder(moge_handle* h) {
                 padd(h, name + S(".rs%d.w3", l), (int64_t)co * 9 * co);
                 aadd(h, name + S(".rs%d.biasT", l), 4 * co);
                 if (!neck) aadd(h, name + S(".rs%d.bias_in", l), co);     // resampler conv bias + next level's input-block bias (fused path)
+                if (ct3_shape(ci, co)) {
+                    // fp16 path (round 6): ConvTranspose2d + 3x3 composed into ONE 4-phase 2x2-tap conv on the low-res map (conv_pp.hip CT3) + its border weights
+                    padd(h, name + S(".rs%d.wc", l), (int64_t)4 * co * 4 * ci);
+                    padd(h, name + S(".rs%d.dw", l), (int64_t)12 * co * 2 * ci);
+                    aadd(h, name + S(".rs%d.bias_ct3", l), 4 * co);
+                }
                 if (!neck && l == 0 && nres[0] == 0) {
                     // fp16 path: a head without level-0 residual blocks applies its ConvTranspose2d directly to its level-0 input block
                     // (modules.py:245-250): both linear, composed at pack time into one [4 co][c0] matrix on the neck's level-0 map
@@ -338,6 +399,26 @@ static int build_aux(moge_handle* h, hipStream_t st) {
                     HIPCHK(hipMemcpyAsync(A(h, name + S(".rs%d.bias_in", l)), a.data(), co * sizeof(float), hipMemcpyHostToDevice, st));
                     HIPCHK(hipStreamSynchronize(st));
                 }
+                if (ct3_shape(c.dims[l], co)) {
+                    // CT3: the ConvTranspose2d bias passes through all nine taps of the 3x3 (replicate padding: at the border too):
+                    // bias_ct3 = (3x3 bias + next level's input-block bias) + sum_{m, k} W3[o][m][k] bT[m], once per phase
+                    std::vector<float> w3((size_t)co * co * 9), bt(co), base(co), b4((size_t)4 * co);
+                    HIPCHK(hipMemcpyAsync(w3.data(), M(h, name + S(".resamplers.%d.1.weight", l)), w3.size() * 4, hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipMemcpyAsync(bt.data(), M(h, name + S(".resamplers.%d.0.bias", l)), (size_t)co * 4, hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipMemcpyAsync(base.data(), neck ? A(h, S("neck.rs%d.bias2", l)) : A(h, name + S(".rs%d.bias_in", l)), (size_t)co * 4, hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    for (int o = 0; o < co; o++) {
+                        double a = base[o];
+                        for (int m = 0; m < co; m++) {
+                            double t = 0;
+                            for (int k9 = 0; k9 < 9; k9++) t += w3[((size_t)o * co + m) * 9 + k9];
+                            a += t * bt[m];
+                        }
+                        for (int q = 0; q < 4; q++) b4[(size_t)q * co + o] = (float)a;
+                    }
+                    HIPCHK(hipMemcpyAsync(A(h, name + S(".rs%d.bias_ct3", l)), b4.data(), b4.size() * 4, hipMemcpyHostToDevice, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                }
             } else if (rs_is_phase(rs[l])) {
                 // up-sample x2 + 3x3 as a 4-phase conv: bias replicated per phase; the neck adds its next level's input-block bias (rs%d.bias2)
                 const float* b4 = neck ? A(h, S("neck.rs%d.bias2", l)) : M(h, name + S(".resamplers.%d.1.bias", l));
@@ -437,6 +518,45 @@ static int dev_matmul_f32(const float* Am, long lda, const float* Bm, long ldb, 
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.a = Ac; g.lda = Kc; g.w = Bt; g.ldw = Kc; g.M = Mr; g.N = Nc; g.K = Kc; g.epi = EPI_STORE; g.out = Cm; g.ldc = Nc;
     LCHK(launch_gemm<float>(g, AMODE_LINEAR, st));
+    return 0;
+}
+
+
+// CT3 weights of one ConvTranspose2d + 3x3 resampler (fp16 path): P = the 36 basic products in ONE exact-fp32 GEMM ([9 Cout][Cout] x [Cout][4 Cin]), then the
+// interior blocks -> wc [4 Cout][4 Cin] and the border blocks -> dw [12][Cout][2 Cin] as signed sums of them, one rounding to fp16 each.
+// w3 = Conv2d weight [co][co][3][3], wt = ConvTranspose2d weight [ci][co][2][2] (fp32, device).  Also the test entry's (test_api.hip).
+int ct3_compose_device(const float* w3, const float* wt, int ci, int co, void* wc, void* dw, hipStream_t st) {
+    std::vector<Ct3Slot> slots;
+    ct3_interior_slots(slots);
+    const int n_int = (int)slots.size();
+    if (ct3_border_slots(slots) != 0) return -2;
+    const size_t nA = (size_t)9 * co * co, nB = (size_t)4 * ci * co, nP = (size_t)9 * co * 4 * ci;
+    float* arena = nullptr;
+    if (hipMalloc(&arena, (nA + nB + nP) * sizeof(float) + slots.size() * sizeof(Ct3Slot)) != hipSuccess) return -3;
+    float* A9 = arena; float* Bt = A9 + nA; float* P = Bt + nB;
+    Ct3Slot* dsl = reinterpret_cast<Ct3Slot*>(P + nP);
+    int rc = 0;
+    hipError_t e = hipMemcpyAsync(dsl, slots.data(), slots.size() * sizeof(Ct3Slot), hipMemcpyHostToDevice, st);
+    do {
+        if (e != hipSuccess) { rc = (int)e; break; }
+        // A9[(k, o)][m] = W3[o][m][k];  Bt[(s, i)][m] = WT[i][m][s]   (both K-contiguous rows: what the GEMM kernels contract)
+        if ((rc = launch_repack<float>(w3, A9, 9, co, 1, co, 1, (long)co * 9, 0, 9, (long)co * co, co, 0, st))) break;
+        if ((rc = launch_repack<float>(wt, Bt, 4, ci, 1, co, 1, (long)co * 4, 0, 4, (long)ci * co, co, 0, st))) break;
+        GemmArgs g; memset(&g, 0, sizeof(g));
+        g.a = A9; g.lda = co; g.w = Bt; g.ldw = co; g.M = 9 * co; g.N = 4 * ci; g.K = co; g.epi = EPI_STORE; g.out = P; g.ldc = 4 * ci;
+        if ((rc = launch_gemm<float>(g, AMODE_LINEAR, st))) break;
+        if ((rc = launch_ct3_combine(P, dsl, n_int, co, ci, wc, 4 * ci, st))) break;
+        if ((rc = launch_ct3_combine(P, dsl + n_int, (int)slots.size() - n_int, co, ci, dw, 2 * ci, st))) break;
+    } while (0);
+    hipError_t e2 = hipStreamSynchronize(st);      // (the host-side term table must outlive its copy; pack time, not the hot path)
+    hipFree(arena);
+    if (rc) return rc;
+    return e2 == hipSuccess ? 0 : (int)e2;
+}
+static int compose_ct3_f16(moge_handle* h, const std::string& name, int l, int ci, int co, hipStream_t st) {
+    const int rc = ct3_compose_device(M(h, name + S(".resamplers.%d.1.weight", l)), M(h, name + S(".resamplers.%d.0.weight", l)), ci, co,
+                                      Pm<f16>(h, name + S(".rs%d.wc", l)), Pm<f16>(h, name + S(".rs%d.dw", l)), st);
+    if (rc) return fail(rc < 0 ? MOGE_ERR_INVALID : MOGE_ERR_HIP, "composing the ConvTranspose2d + 3x3 weights of %s level %d failed (%d)", name.c_str(), l, rc);
     return 0;
 }
 
@@ -545,7 +665,16 @@ static int pack_weights(moge_handle* h, hipStream_t st) {
     CHK(stack("neck", true, c.neck_res_blocks));
     for (int k = 0; k < 3; k++)
         if (c.heads & HEAD_BITS[k]) CHK(stack(HEAD_NAMES[k], false, c.head_res_blocks));
-    if constexpr (std::is_same<T, f16>::value) CHK(compose_weights_f16(h, st));
+    if constexpr (std::is_same<T, f16>::value) {
+        CHK(compose_weights_f16(h, st));
+        for (int kk = -1; kk < 3; kk++) {                                 // neck, then the heads
+            if (kk >= 0 && !(c.heads & HEAD_BITS[kk])) continue;
+            const std::string name = kk < 0 ? "neck" : HEAD_NAMES[kk];
+            const int* rs = stack_rs(c, kk < 0);
+            for (int l = 0; l < MOGE_LEVELS - 1; l++)
+                if (rs[l] == MOGE_RS_CONV_TRANSPOSE && ct3_shape(c.dims[l], c.dims[l + 1])) CHK(compose_ct3_f16(h, name, l, c.dims[l], c.dims[l + 1], st));
+        }
+    }
     h->pk_ready[pr] = true;
     return 0;
 }
@@ -755,6 +884,33 @@ static int convT2(moge_handle* h, const T* in, const T* w, const float* biasT, T
     g.M = B * Hh * Ww; g.N = 4 * Cout; g.K = Cin;
     g.epi = EPI_CONVT; g.bias = biasT; g.out = out; g.Cout = Cout; g.pixW = Ww; g.pixH = Hh;
     return run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_CONV, st);
+}
+
+// ConvTranspose2d(k2, s2) + 3x3 conv (modules.py:160-165) as ONE composed conv on the low-res map (conv_pp.hip CT3; fp16 path, Cin = 2 Cout) + its border ring:
+// in (B, Hl, Wl, Cin) -> out (B, 2 Hl, 2 Wl, Cout); uv at the HIGH-res grid; side = high-res map of the fused 1x1 input block (heads).  *done = false: shape not taken
+// (nothing ran).  Profiler: the ALGORITHMIC work of the pair (2 Cin Cout + 9 Cout^2 [+ Cout^2] MACs per output pixel); the kernel executes 16 Cin Cout / 4 per pixel.
+template <typename T>
+static int convT_conv3_fused(moge_handle* h, const T* in, const T* wc, const T* dw, const float* bias4, T* out, int B, int Hl, int Wl, int Cin, int Cout,
+                             const UVTerm* uv, const T* side, const T* side_w, hipStream_t st, bool* done) {
+    *done = false;
+    if (!std::is_same<T, f16>::value || !moge_tune_get("FUSE_CT3", 1) || !moge_tune_get("CONV_PP", 1)) return 0;
+    GemmArgs g = gemm_args();
+    g.a = in; g.H = Hl; g.W = Wl; g.C = Cin; g.w = wc; g.ldw = 4 * Cin;
+    g.M = B * Hl * Wl; g.N = 4 * Cout; g.K = 4 * Cin;
+    g.epi = EPI_CONVT; g.bias = bias4; g.out = out; g.Cout = Cout; g.pixW = Wl; g.pixH = Hl; g.ct3 = 1;
+    if (uv) g.uv = *uv;
+    if (side) { g.a2 = side; g.w2 = side_w; }
+    if (!conv_pp_eligible(g)) return 0;
+    const double kalgo = ((2.0 * Cin * Cout + 9.0 * Cout * Cout) * 4 + (side ? 4.0 * Cout * Cout : 0.0)) / (4.0 * Cout);      // flops = 2 M N kalgo
+    {
+        const double flops = 2.0 * g.M * (double)g.N * kalgo;
+        const double bytes = ((double)g.N * g.K + (double)g.M * Cin + (double)g.M * 4 * Cout * (side ? 2 : 1)) * sizeof(T);
+        ProfScope ps(h, st, MOGE_KC_CONV, flops, bytes);
+        LCHK(launch_conv_pp(g, st));
+        LCHK(launch_ct3_border(in, dw, out, B, Hl, Wl, Cin, Cout, st));
+    }
+    *done = true;
+    return 0;
 }
 
 // n residual blocks x = x + conv2(relu(conv1(relu(x))))   (modules.py:47-68 with norms = Identity) on x, tmp = scratch of the same size.
@@ -1048,9 +1204,15 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
             // level l's input block sees the (u, v) planes only (v2.py:154-160): a rank-2 term + bias, carried by the epilogue of the resampler's LAST conv
             UVTerm uvl = uv_term(A(h, S("neck.in%d.wu", l)), A(h, S("neck.in%d.wv", l)), Ww, Hh, aspect);
             if (rsl == MOGE_RS_CONV_TRANSPOSE) {
+                bool fused = false;
+                if (std::is_same<T, f16>::value && ct3_shape(ci, co))
+                    CHK(convT_conv3_fused<T>(h, N[l - 1], P<T>(h, S("neck.rs%d.wc", l - 1)), P<T>(h, S("neck.rs%d.dw", l - 1)), A(h, S("neck.rs%d.bias_ct3", l - 1)), N[l], B,
+                                             Hh / 2, Ww / 2, ci, co, &uvl, nullptr, nullptr, st, &fused));
+                if (!fused) {
                 CHK(convT2<T>(h, N[l - 1], P<T>(h, S("neck.rs%d.wT", l - 1)), A(h, S("neck.rs%d.biasT", l - 1)), Sc[0], B, Hh / 2, Ww / 2, ci, co, st));
                 CHK(conv3x3<T>(h, Sc[0], P<T>(h, S("neck.rs%d.w3", l - 1)), A(h, S("neck.rs%d.bias2", l - 1)), N[l], B, Hh, Ww, co, co, 0, ACT_NONE, nullptr,
                                &uvl, st));
+                }
             } else if (rsl == MOGE_RS_PIXEL_SHUFFLE) {
                 // Conv2d(ci, 4 co) + PixelShuffle = a 3x3 conv on the low-res map stored through the pixel-shuffle epilogue, then the second 3x3 conv
                 CHK(conv_up2_phase<T>(h, N[l - 1], P<T>(h, S("neck.rs%d.w3p", l - 1)), A(h, S("neck.rs%d.bias4", l - 1)), Sc[0], B, Hh / 2, Ww / 2, ci, co, nullptr, st));
@@ -1123,6 +1285,16 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
             const int rsl = c.head_resamplers[l - 1];
             int nxt;
             bool in_fused = false;
+            bool ct3_done = false;
+            if (rsl == MOGE_RS_CONV_TRANSPOSE && std::is_same<T, f16>::value && ct3_shape(ci, co) && !(l == 1 && compose0) && moge_tune_get("FUSE_IN", 1) != 0 &&
+                !(l == MOGE_LEVELS - 1 && fuse_l4)) {
+                // ConvTranspose2d + 3x3 + the head's `x + in_l(neck_l)` (modules.py:160-165, 245) in one composed conv: Sc[cur] (low-res) -> Sc[b2] (high-res)
+                CHK(convT_conv3_fused<T>(h, Sc[cur], P<T>(h, name + S(".rs%d.wc", l - 1)), P<T>(h, name + S(".rs%d.dw", l - 1)), A(h, name + S(".rs%d.bias_ct3", l - 1)), Sc[b2], B,
+                                         Hh / 2, Ww / 2, ci, co, nullptr, N[l], P<T>(h, name + S(".in%d.w", l)), st, &ct3_done));
+                if (ct3_done) { in_fused = true; nxt = b2; }
+            }
+            if (ct3_done) {
+            } else
             if (rsl == MOGE_RS_CONV_TRANSPOSE || rsl == MOGE_RS_PIXEL_SHUFFLE) {
                 if (rsl == MOGE_RS_PIXEL_SHUFFLE)
                     CHK(conv_up2_phase<T>(h, Sc[cur], P<T>(h, name + S(".rs%d.w3p", l - 1)), A(h, name + S(".rs%d.bias4", l - 1)), Sc[a], B, Hh / 2, Ww / 2, ci, co, nullptr, st));

@@ -276,7 +276,56 @@ static int t_groupnorm(const float* x, const float* gamma, const float* beta, fl
     TCHK(hipStreamSynchronize(st));
     return 0;
 }
+
+// fused ConvTranspose2d + 3x3 (conv_pp.hip CT3 + border), fp16 only: x (B,H,W,Cin), wt (Cin,Cout,2,2), bt (Cout), w3 (Cout,Cout,3,3), b3 (Cout), optional
+// side (B,2H,2W,Cout) with side_w (Cout,Cout), optional uv at the output resolution -> y (B,2H,2W,Cout)
+static int t_ct3(const moge_test_ct3_args& a, hipStream_t st) {
+    const int B = a.B, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    const size_t nx = (size_t)B * H * W * Cin, ny = (size_t)B * 4 * H * W * Cout;
+    DevBuf xb, yb, wc, dw, b4, sb, sw;
+    TCHK(xb.alloc(nx * 2)); TCHK(yb.alloc(ny * 2)); TCHK(wc.alloc((size_t)16 * Cout * Cin * 2)); TCHK(dw.alloc((size_t)24 * Cout * Cin * 2)); TCHK(b4.alloc((size_t)4 * Cout * 4));
+    TL(to_t<f16>(a.x, xb.p, (long)nx, st));
+    TL(ct3_compose_device(a.w3, a.wt, Cin, Cout, wc.p, dw.p, st));
+    std::vector<float> w3((size_t)Cout * Cout * 9), bt(Cout), b3(Cout), bias4((size_t)4 * Cout);
+    TCHK(hipMemcpyAsync(w3.data(), a.w3, w3.size() * 4, hipMemcpyDeviceToHost, st));
+    TCHK(hipMemcpyAsync(bt.data(), a.bt, (size_t)Cout * 4, hipMemcpyDeviceToHost, st));
+    TCHK(hipMemcpyAsync(b3.data(), a.b3, (size_t)Cout * 4, hipMemcpyDeviceToHost, st));
+    TCHK(hipStreamSynchronize(st));
+    for (int o = 0; o < Cout; o++) {
+        double acc = b3[o];
+        for (int m = 0; m < Cout; m++) {
+            double t9 = 0;
+            for (int k = 0; k < 9; k++) t9 += w3[((size_t)o * Cout + m) * 9 + k];
+            acc += t9 * bt[m];
+        }
+        for (int q = 0; q < 4; q++) bias4[(size_t)q * Cout + o] = (float)acc;
+    }
+    TCHK(hipMemcpyAsync(b4.p, bias4.data(), bias4.size() * 4, hipMemcpyHostToDevice, st));
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.a = xb.p; g.H = H; g.W = W; g.C = Cin; g.w = wc.p; g.ldw = 4 * Cin; g.M = B * H * W; g.N = 4 * Cout; g.K = 4 * Cin;
+    g.epi = EPI_CONVT; g.bias = (const float*)b4.p; g.out = yb.p; g.Cout = Cout; g.pixW = W; g.pixH = H; g.ct3 = 1;
+    if (a.side) {
+        TCHK(sb.alloc(ny * 2)); TCHK(sw.alloc((size_t)Cout * Cout * 2));
+        TL(to_t<f16>(a.side, sb.p, (long)ny, st));
+        TL(to_t<f16>(a.side_w, sw.p, (long)Cout * Cout, st));
+        g.a2 = sb.p; g.w2 = sw.p;
+    }
+    if (a.wu) { g.uv.wu = a.wu; g.uv.wv = a.wv; g.uv.u0 = a.u0; g.uv.u1 = a.u1; g.uv.v0 = a.v0; g.uv.v1 = a.v1;
+                g.uv.ustep = 2 * W > 1 ? (a.u1 - a.u0) / (float)(2 * W - 1) : 0.f; g.uv.vstep = 2 * H > 1 ? (a.v1 - a.v0) / (float)(2 * H - 1) : 0.f; }
+    if (!conv_pp_eligible(g)) return MOGE_ERR_INVALID;
+    TL(launch_conv_pp(g, st));
+    if (!a.no_border) TL(launch_ct3_border(xb.p, dw.p, yb.p, B, H, W, Cin, Cout, st));
+    TL(from_t<f16>(yb.p, a.y, (long)ny, st));
+    TCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
 extern "C" {
+
+int moge_test_ct3(const moge_test_ct3_args* args, void* stream) {
+    if (!args || args->precision != MOGE_FP16) return MOGE_ERR_INVALID;
+    return t_ct3(*args, (hipStream_t)stream);
+}
 
 int moge_test_gemm(int precision, const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act, void* stream) {
     hipStream_t st = (hipStream_t)stream;

@@ -203,3 +203,32 @@ def conv_ex(x_nhwc, w, bias, prec=1, relu_in=False, act=0, add=None, side=None, 
     a.y = y.data_ptr()
     L.check(L.lib.moge_test_conv_ex(C.byref(a), st()))
     return y
+
+
+def ct3(x_nhwc, wt, bt, w3, b3, side=None, side_w=None, uv=None, no_border=False):
+    """ConvTranspose2d(k2, s2) + 3x3 replicate conv through the fused fp16 path (moge_test_ct3): x (B,H,W,Cin), wt (Cin,Cout,2,2), w3 (Cout,Cout,3,3)
+    -> (B,2H,2W,Cout).  side (B,2H,2W,Cout) / side_w (Cout,Cout): the fused 1x1 input block; uv = (wu, wv, u0, u1, v0, v1) at the output resolution."""
+    import ctypes as C
+    keep = []
+
+    def dev(t):
+        if t is None:
+            return None
+        t = _f(t)
+        keep.append(t)
+        return t.data_ptr()
+
+    x = _f(x_nhwc)
+    B, H, W, Cin = x.shape
+    Cout = w3.shape[0]
+    y = torch.empty((B, 2 * H, 2 * W, Cout), device="cuda", dtype=torch.float32)
+    a = L.TestCt3Args()
+    a.precision, a.B, a.H, a.W, a.Cin, a.Cout, a.no_border = 1, B, H, W, Cin, Cout, int(bool(no_border))
+    a.x, a.wt, a.bt, a.w3, a.b3 = x.data_ptr(), dev(wt), dev(bt), dev(w3), dev(b3)
+    a.side, a.side_w = dev(side), dev(side_w)
+    if uv is not None:
+        wu, wv, u0, u1, v0, v1 = uv
+        a.wu, a.wv, a.u0, a.u1, a.v0, a.v1 = dev(wu), dev(wv), u0, u1, v0, v1
+    a.y = y.data_ptr()
+    L.check(L.lib.moge_test_ct3(C.byref(a), st()))
+    return y

@@ -16,7 +16,7 @@ def test_library_exports_match_header():
     assert declared == sorted(L.EXPORTS)
     for name in declared:
         assert hasattr(L.lib, name), f"libmoge_hip.so does not export {name}"
-    assert L.lib.moge_abi_version() == L.ABI_VERSION == 4
+    assert L.lib.moge_abi_version() == L.ABI_VERSION == 5
 
 
 def test_config_struct_layout():

@@ -210,3 +210,74 @@ def test_decoder_sized_maps(H, what):
         out = H.conv_ex(x, w, b, up2=True).double().cpu()
         ref = ref.double().cpu()
         assert float((out - ref).abs().max()) <= 2.5e-3 * float(ref.abs().max())
+
+
+# ---- fused ConvTranspose2d(k2, s2) + 3x3 (conv_pp.hip CT3 + ct3_border_kernel; round 6) ---------------------------------------------------------------
+def ct3_ref(x_nhwc, wt, bt, w3, b3, side=None, side_w=None, uv=None):
+    """modules.py:160-165 in fp32 on the same operands: ConvTranspose2d -> replicate-padded 3x3 [+ 1x1 side input, + uv term]."""
+    x = x_nhwc.permute(0, 3, 1, 2).cuda()
+    hi = F.conv_transpose2d(x, wt.cuda(), bt.cuda(), stride=2)
+    y = F.conv2d(F.pad(hi, (1, 1, 1, 1), mode="replicate"), w3.cuda(), b3.cuda())
+    if side is not None:
+        y = y + F.conv2d(side.permute(0, 3, 1, 2).cuda(), side_w.cuda()[:, :, None, None])
+    if uv is not None:
+        wu, wv, u0, u1, v0, v1 = uv
+        Ho, Wo = y.shape[-2:]
+        u = torch.linspace(u0, u1, Wo, device="cuda")
+        v = torch.linspace(v0, v1, Ho, device="cuda")
+        y = y + wu.cuda()[None, :, None, None] * u[None, None, None, :] + wv.cuda()[None, :, None, None] * v[None, None, :, None]
+    return y.permute(0, 2, 3, 1)
+
+
+def mk_ct3(B, Hh, Ww, Cout, seed):
+    Cin = 2 * Cout
+    g = torch.Generator().manual_seed(seed)
+    x = r16(torch.randn(B, Hh, Ww, Cin, generator=g))
+    wt = torch.randn(Cin, Cout, 2, 2, generator=g) / Cin ** 0.5
+    bt = torch.randn(Cout, generator=g) * 0.5
+    w3 = torch.randn(Cout, Cout, 3, 3, generator=g) / (9 * Cout) ** 0.5
+    b3 = torch.randn(Cout, generator=g)
+    return g, x, wt, bt, w3, b3
+
+
+CT3_SHAPES = [(2, 17, 31, 128), (1, 16, 16, 128), (1, 33, 21, 64), (2, 5, 70, 64), (1, 1, 1, 128), (1, 2, 19, 64), (1, 40, 48, 128)]
+
+
+@pytest.mark.parametrize("B,Hh,Ww,Cout", CT3_SHAPES)
+def test_fused_convt_conv3_matches_the_pair(H, B, Hh, Ww, Cout):
+    """The composed 4-phase conv + its border ring against ConvTranspose2d -> replicate 3x3 in fp32: interior AND every border / corner pixel (tile-border
+    sizes, one-pixel and two-row maps).  Without the border pass the outermost ring must be the ONLY place that differs (the composed conv is a reflecting pad)."""
+    g, x, wt, bt, w3, b3 = mk_ct3(B, Hh, Ww, Cout, 31)
+    ref = ct3_ref(x, wt, bt, w3, b3)
+    out = H.ct3(x, wt, bt, w3, b3)
+    close(out, ref, "ct3")
+    raw = H.ct3(x, wt, bt, w3, b3, no_border=True)
+    inner_o, inner_r = raw[:, 1:-1, 1:-1], ref[:, 1:-1, 1:-1]
+    if inner_r.numel():
+        scale = float(ref.abs().max())
+        assert float((inner_o.cpu().double() - inner_r.cpu().double()).abs().max()) <= (1e-3 + 2.0 ** -11) * scale, "interior differs without the border pass"
+    ring = torch.ones(ref.shape[1:3], dtype=torch.bool)
+    ring[1:-1, 1:-1] = False
+    d = (raw.cpu() - ref.cpu()).abs().amax(dim=(0, 3))
+    if min(Hh, Ww) > 1:
+        assert float(d[ring].max()) > 10 * float(d[~ring].max() if (~ring).any() else 0.0), "the un-corrected ring should show the reflect / replicate difference"
+
+
+@pytest.mark.parametrize("B,Hh,Ww,Cout", [(2, 17, 31, 128), (1, 33, 21, 64), (1, 24, 24, 64)])
+def test_fused_convt_conv3_with_side_input_and_uv(H, B, Hh, Ww, Cout):
+    """the heads' form (fused 1x1 input block on the HIGH-res neck map, modules.py:245) and the neck's (uv term at the output resolution)"""
+    g, x, wt, bt, w3, b3 = mk_ct3(B, Hh, Ww, Cout, 32)
+    side = r16(torch.randn(B, 2 * Hh, 2 * Ww, Cout, generator=g))
+    side_w = r16(torch.randn(Cout, Cout, generator=g) / Cout ** 0.5)
+    out = H.ct3(x, wt, bt, w3, b3, side=side, side_w=side_w)
+    close(out, ct3_ref(x, wt, bt, w3, b3, side=side, side_w=side_w), "ct3 + side")
+    uv = (torch.randn(Cout, generator=g), torch.randn(Cout, generator=g), -0.7, 0.7, -0.6, 0.6)
+    out = H.ct3(x, wt, bt, w3, b3, uv=uv)
+    close(out, ct3_ref(x, wt, bt, w3, b3, uv=uv), "ct3 + uv")
+
+
+def test_fused_convt_conv3_at_the_decoder_sizes(H):
+    """the two resamplers of the released layout that take the fused form: 256 -> 128 at 120 x 120 and 128 -> 64 at 240 x 240 (one image)"""
+    for Hh, Cout in ((120, 128), (240, 64)):
+        g, x, wt, bt, w3, b3 = mk_ct3(1, Hh, Hh, Cout, 33)
+        close(H.ct3(x, wt, bt, w3, b3), ct3_ref(x, wt, bt, w3, b3), f"ct3 {Hh}")
