@@ -241,6 +241,7 @@ def main():
     ap.add_argument("--no-power", action="store_true", help="skip the untimed power-sampling pass (socket watts / joules per image)")
     ap.add_argument("--no-autocast-pass", action="store_true", help="skip the extra steps in the reference's other fp16 form (fp32 weights + use_fp16); "
                                                                      "rocprofv3 passes use it so that the trace holds the headline mode's kernels only")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency leg (rocprofv3 passes that want the batch-32 launches only)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="run only the cpu_baseline leg (no GPU needed) and print it")
     ap.add_argument("--print-launch", action="store_true", help="print the torch.distributed.run command --gpus N would re-execute as, and exit")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 (nccl = RCCL over xGMI: production; gloo: "
@@ -408,7 +409,7 @@ def main():
         # B=1 latency (p50), outside the timed region
         lat = []
         x1 = x[:1].contiguous()
-        for i in range(12):
+        for i in range(3 if args.no_latency else 12):
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             model.infer(x1, **kw)

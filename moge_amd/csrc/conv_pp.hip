@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     // EPI bit 6 (with bits 1 and 3; round 6): CT3 - ConvTranspose2d(k2, s2) and the 3x3 conv behind it (modules.py:160-165) as ONE conv on the LOW-res map.
     // Output pixel (2y + py, 2x + px) sees the low-res pixels (y + py - 1 + tdy, x + px - 1 + tdx), tdy, tdx in {0, 1}: four taps per phase, the weights
     // of (phase, tap) pre-composed at pack time (sum over the 3x3 taps that fall on that low-res pixel of W3 . WT, elementwise.hip compose_ct3).  A workgroup
-    // owns ONE phase (BN = Cout; column block = phase), its K loop is 4 taps x Cin / 64 chunks on the same 18 x 18 halo image the 3x3 kernel loads, the
+    // owns ONE phase (Cout = 128; column block = phase) or the two phases of a row parity (Cout = 64, see set_abase), its K loop is 4 taps x Cin / 64 chunks on the same 18 x 18 halo image the 3x3 kernel loads, the
     // pixel-shuffle epilogue stores (B, 2H, 2W, Cout).  16 Cin Cout MACs per output pixel instead of 2 Cin Cout + 9 Cout Cout... (Cin = 2 Cout: 16 vs 22 Cout^2),
     // and the (B, 2H, 2W, Cout) map between the two never exists.  The fused 1x1 side input (heads) reads the HIGH-res map a2 at (2y + py, 2x + px).
     // Replicate padding does not commute with the transposed conv: on the outermost ring of output pixels the composed form equals a REFLECTING pad;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
         in2_b = reinterpret_cast<const char*>(g.a2) + (size_t)sb * H * W * C2 * (CT3 ? 8 : 2);
         w_b = reinterpret_cast<const char*>(g.w) + (size_t)sn0 * g.ldw * 2;
         w2_b = reinterpret_cast<const char*>(g.w2) + (CT3 ? (size_t)0 : (size_t)sn0 * C * 2);      // CT3: BN = Cout, every phase block multiplies by all rows of w2
-        const int spy = CT3 ? (sn0 / BN) >> 1 : 0, spx = CT3 ? (sn0 / BN) & 1 : 0;
+        const int spy = CT3 ? (sn0 / BN) >> 1 : 0, spx = CT3 ? (sn0 / BN) & 1 : 0;      // (side input: one-phase-per-block form only, see conv_pp_eligible)
 #pragma unroll
         for (int i = 0; i < HPW; i++) {
             int piece = wave + 8 * i;
@@ -243,8 +243,11 @@ __global__ __launch_bounds__(512, (BN == 64 && TW == 16 && NH == 1) ? 4 : 2) voi
     int abase[3][2];
     int tpy = 0;                                                          // CT3: row phase of the tile being computed (halo row offset of its taps)
     auto set_abase = [&]() {
-        const int tpx = CT3 ? (n0 / BN) & 1 : 0;
-        if constexpr (CT3) tpy = (n0 / BN) >> 1;
+        // CT3 phases of this workgroup: BN = Cout -> one phase (py, px) = column block;  BN = 2 Cout (Cout = 64 on the 128-wide form) -> the two phases
+        // (py, 0), (py, 1) side by side: a wave's column half wn IS its px (same halo image, fragments shifted by one column), column block = py
+        const bool ph2 = CT3 && BN == 2 * g.Cout;
+        const int tpx = CT3 ? (ph2 ? wn : (n0 / BN) & 1) : 0;
+        if constexpr (CT3) tpy = ph2 ? (n0 / BN) & 1 : (n0 / BN) >> 1;
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             // halo column of tap dx = d - 1;  CT3: d = 0, 1 are the phase's two taps (low-res column x + px - 1 + d), d = 2 the centre (side input)
@@ -645,6 +648,7 @@ bool conv_pp_eligible(const GemmArgs& g) {
         if ((g.C & 63) || g.K != 4 * g.C || g.ldw != 4 * g.C || !g.bias || g.epi != EPI_CONVT || g.N != 4 * g.Cout) return false;
         if (g.Cout != 128 && g.Cout != 64) return false;
         if (g.add || g.act != ACT_NONE || g.relu_in || g.dot_tab || (g.a2 && !g.w2)) return false;
+        if (g.a2 && g.Cout == 64) return false;      // Cout = 64 runs two phases per 128-wide column block: the side image (one high-res pixel per low-res pixel) would differ per wave column
         if (g.H < 1 || g.W < 1 || (long)g.M % ((long)g.H * g.W) != 0) return false;
         if ((long)g.H * g.W * g.C * 2 >= (1L << 31) || (long)g.H * g.W * g.Cout * 8 >= (1L << 31)) return false;      // 32-bit halo offsets (input / side map)
         return true;
@@ -778,8 +782,8 @@ int launch_ct3_border(const void* in, const void* dw, void* out, int B, int H, i
 
 int launch_conv_pp(const GemmArgs& g, hipStream_t st) {
     if (g.ct3) {
-        if (g.Cout == 128) return g.uv.wu ? launch_conv_cfg<128, 16, 2, 8 | 2 | 64 | 1>(g, st) : launch_conv_cfg<128, 16, 2, 8 | 2 | 64>(g, st);
-        return g.uv.wu ? launch_conv_cfg<64, 16, 2, 8 | 2 | 64 | 1>(g, st) : launch_conv_cfg<64, 16, 2, 8 | 2 | 64>(g, st);
+        // one kernel form (128 output columns per workgroup: 64 px x 64 ch per wave): Cout = 128 -> one phase per column block, Cout = 64 -> two
+        return g.uv.wu ? launch_conv_cfg<128, 16, 2, 8 | 2 | 64 | 1>(g, st) : launch_conv_cfg<128, 16, 2, 8 | 2 | 64>(g, st);
     }
     // a single halo image: one buffer.  A 64-channel layer with a side input runs on the single-buffer form too (side fragments in registers)
     const bool side_reg = g.C == 64 && g.N == 64 && g.a2 && !g.uv.wu && !g.relu_in && g.epi == EPI_STORE && moge_tune_get("CONV_SIDE_REG", 1);

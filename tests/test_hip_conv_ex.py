@@ -265,12 +265,18 @@ def test_fused_convt_conv3_matches_the_pair(H, B, Hh, Ww, Cout):
 
 @pytest.mark.parametrize("B,Hh,Ww,Cout", [(2, 17, 31, 128), (1, 33, 21, 64), (1, 24, 24, 64)])
 def test_fused_convt_conv3_with_side_input_and_uv(H, B, Hh, Ww, Cout):
-    """the heads' form (fused 1x1 input block on the HIGH-res neck map, modules.py:245) and the neck's (uv term at the output resolution)"""
+    """the heads' form (fused 1x1 input block on the HIGH-res neck map, modules.py:245; Cout = 128 only: the 64-channel form runs two phases per workgroup and
+    refuses a side image - the decoder then keeps the unfused pair) and the neck's (uv term at the output resolution)"""
     g, x, wt, bt, w3, b3 = mk_ct3(B, Hh, Ww, Cout, 32)
     side = r16(torch.randn(B, 2 * Hh, 2 * Ww, Cout, generator=g))
     side_w = r16(torch.randn(Cout, Cout, generator=g) / Cout ** 0.5)
-    out = H.ct3(x, wt, bt, w3, b3, side=side, side_w=side_w)
-    close(out, ct3_ref(x, wt, bt, w3, b3, side=side, side_w=side_w), "ct3 + side")
+    if Cout == 128:
+        out = H.ct3(x, wt, bt, w3, b3, side=side, side_w=side_w)
+        close(out, ct3_ref(x, wt, bt, w3, b3, side=side, side_w=side_w), "ct3 + side")
+    else:
+        from moge_amd._lib import MogeError
+        with pytest.raises(MogeError):
+            H.ct3(x, wt, bt, w3, b3, side=side, side_w=side_w)
     uv = (torch.randn(Cout, generator=g), torch.randn(Cout, generator=g), -0.7, 0.7, -0.6, 0.6)
     out = H.ct3(x, wt, bt, w3, b3, uv=uv)
     close(out, ct3_ref(x, wt, bt, w3, b3, uv=uv), "ct3 + uv")
