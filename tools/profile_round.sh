@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 out=$root/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd $root
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-pcie --no-autocast-pass --no-power"
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-pcie --no-autocast-pass --no-power --no-latency"      # (--no-latency, round 6: batch-32 launches only - a persistent kernel has the same grid at batch 1)
 export MOGE_BATCH_SPLIT=0     # one stream: a kernel's trace interval then contains only that kernel
 timeout ${PROF_TIMEOUT:-240} rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o tr -- $CMD > $out/trace.log 2>&1
 python3 tools/trace_summary.py $out/trace/tr_kernel_trace.csv 60 > $out/kernels_by_grid.csv
