@@ -370,9 +370,12 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
 // to interleave.  Result and the reason it is / is not the default: DESIGN.md 4.3 (profiles/r03*_kbench_attn*.log).
 // ------------------------------------------------------------------------------------------------------------------------
 // The body for one workgroup: head `bh`, queries from `q_base` (this workgroup covers 64 * QB of them; wave w owns 16 * QB from q_base + 16 * QB * w).
-template <int QB>
-__device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v, f16* __restrict__ out,
-                                                 int Ntok, int nh, int bh, int q_base, char* smem) {
+// SK (attn_pp16sk_kernel, below): the body runs the key tiles [tb_in, te_in) only and leaves its unnormalised state (O, l relative to the running
+// max m) in *acc instead of storing the output; returns false for a wave without queries.  SK = false: all tiles, output stored (the code of rounds 2-5).
+template <int QB> struct AttnAcc { f32x4 o[4][QB]; float m[QB], l[QB]; };
+template <int QB, bool SK = false>
+__device__ __forceinline__ bool attn_pp16mq_body(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v, f16* __restrict__ out,
+                                                 int Ntok, int nh, int bh, int q_base, char* smem, int tb_in = 0, int te_in = 0, AttnAcc<QB>* acc = nullptr) {
     constexpr int NW = 4, NPW = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -395,6 +398,7 @@ __device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, cons
     // iteration of an issue-bound loop (the compiler merges the two sides of `t < ntiles - 1` and selects between the addresses).
     unsigned doff[NPW], doff_last[NPW];
     const int ntiles = (Ntok + 63) >> 6;
+    const int tb = SK ? tb_in : 0, te = SK ? te_in : ntiles;          // this call's key tiles
 #pragma unroll
     for (int i = 0; i < NPW; i++) {
         const int p = wave + NW * i;
@@ -406,7 +410,7 @@ __device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, cons
         doff_last[i] = doff[i] - (over > 0 ? (unsigned)over * 128u : 0u);
     }
     auto issue = [&](int t) {
-        char* st = smem + (t % 3) * AP_STAGE;
+        char* st = smem + ((SK ? t - tb : t) % 3) * AP_STAGE;
         const char* kt = uniform_ptr(kbase + (size_t)t * 8192);
         const char* vt = uniform_ptr(vbase + (size_t)t * 8192);
         const bool last = t >= ntiles - 1;
@@ -436,8 +440,8 @@ __device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, cons
         negs[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
         m_run[qb] = -1e30f; l_run[qb] = 0.f;
     }
-    issue(0);
-    if (ntiles > 1) issue(1);
+    issue(tb);
+    if (te - tb > 1) issue(tb + 1);
 
     int stage = 0;
     const char* ka[2];
@@ -445,11 +449,11 @@ __device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, cons
     f32x4 sc[4][QB];
     float psum[QB];
     auto tile_head = [&](int t, bool with_issue = true) {
-        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        if (t + 1 < te) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (with_issue && t + 2 < ntiles) issue(t + 2);
+        if (with_issue && t + 2 < te) issue(t + 2);
         const int so = stage * AP_STAGE;
         stage = stage == 2 ? 0 : stage + 1;
 #pragma unroll
@@ -543,18 +547,19 @@ __device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, cons
     // with the real queries has its SIMD to itself and the workgroup frees its slot sooner (its three idle waves used to redo a clamped
     // copy of query N - 1 at full cost).
     if (__builtin_amdgcn_readfirstlane(q0) >= Ntok) {
-        for (int tt = 0; tt < ntiles; tt++) tile_head(tt);
-        return;
+        for (int tt = tb; tt < te; tt++) tile_head(tt);
+        return false;
     }
-    tile_head(0);
+    tile_head(tb);
 #pragma unroll
-    for (int qb = 0; qb < QB; qb++) exact_block(0, ntiles == 1, qb);
-    int t = 1;
+    for (int qb = 0; qb < QB; qb++) exact_block(tb, tb == ntiles - 1, qb);
+    int t = tb + 1;
+    const int hot_end = SK ? (te < ntiles - 1 ? te : ntiles - 1) : ntiles - 1;      // (the sequence's last tile is masked: exact path)
     u32x4 pf[QB][2];                             // [query block][32-key step]: the tile's P^T operands
     f32x4 lt[QB];                                // this tile's row sums (every register / lane of a query holds the same number)
     for (;;) {
         bool hit = false;
-        for (; t < ntiles - 1; t++) {                // ---- hot loop ----
+        for (; t < hot_end; t++) {                   // ---- hot loop ----
             tile_head(t, false);
             u32x4 kf[4][2];
 #pragma unroll
@@ -565,7 +570,7 @@ __device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, cons
             }
             // tile t + 2's DMA requests BEHIND the K fragment reads: in front of them the four pieces' issue time sat between the barrier and the first MFMA
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < ntiles) issue(t + 2);
+            if (t + 2 < te) issue(t + 2);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int qb = 0; qb < QB; qb++) qk_block(qb, kf);
@@ -621,10 +626,19 @@ __device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, cons
         }
         t++;
     }
-    if (ntiles > 1) {
+    if (SK ? (te == ntiles && ntiles - 1 > tb) : (ntiles > 1)) {
         tile_head(ntiles - 1);
 #pragma unroll
         for (int qb = 0; qb < QB; qb++) exact_block(ntiles - 1, true, qb);
+    }
+    if constexpr (SK) {
+#pragma unroll
+        for (int qb = 0; qb < QB; qb++) {
+#pragma unroll
+            for (int db = 0; db < 4; db++) acc->o[db][qb] = o[db][qb];
+            acc->m[qb] = m_run[qb]; acc->l[qb] = l_run[qb];
+        }
+        return true;
     }
 #pragma unroll
     for (int qb = 0; qb < QB; qb++) {
@@ -637,6 +651,7 @@ __device__ __forceinline__ void attn_pp16mq_body(const f16* __restrict__ q, cons
                 store4(op + 16 * db + 4 * g4, o[db][qb][0] * inv, o[db][qb][1] * inv, o[db][qb][2] * inv, o[db][qb][3] * inv);
         }
     }
+    return true;
 }
 
 template <int QB>
@@ -665,6 +680,13 @@ __global__ __launch_bounds__(256, QB > 2 ? 2 : 3) void attn_pp16mq_kernel(const 
 }
 
 #ifdef MOGE_EXPERIMENTS
+#include "../../tools/experiments/attention_pp16sk_exp.inc"    // attn_pp16sk_kernel: attn_pp16mq's body over a stream-K partition of (query block, key tile) units (round 6; correct, 5-8 us SLOWER at one image)
+#else
+size_t attention_pp_ws_bytes(int, int, int) { return 0; }             // (the stream-K form and its workspace exist in --experiments builds only)
+size_t attention_pp_ws_counter_bytes(int, int, int) { return 0; }
+#endif
+
+#ifdef MOGE_EXPERIMENTS
 #include "../../tools/experiments/attention_pp16s_exp.inc"     // attn_pp16s_kernel: block-pipelined single-stream form (round 6; bit-identical, 11-27 % slower)
 #include "../../tools/experiments/attention_pp16x_exp.inc"     // attn_pp16x_kernel: the 8-wave ping-pong form (round 5; bit-identical, 13 % slower: DESIGN.md)
 #endif
@@ -673,8 +695,27 @@ __global__ __launch_bounds__(256, QB > 2 ? 2 : 3) void attn_pp16mq_kernel(const 
 // was written and measured: correct, 860 TF/s against 920 for the kernel above.  With the schedule left to the compiler the exps still
 // cluster (18 in a row between MFMAs) and the second S buffer costs register moves / spills; it needs a hand-placed instruction stream.)
 
-static int launch_attn_pp16(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
+static int launch_attn_pp16(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st, void* ws, size_t ws_bytes) {
     constexpr int smem = 3 * AP_STAGE;
+#ifdef MOGE_EXPERIMENTS
+    {
+        int QB, nx, gx;
+        if (ws && attn_sk_plan(B, nh, Ntok, &QB, &nx, &gx) && ws_bytes >= attention_pp_ws_bytes(B, nh, Ntok)) {
+            int* cnt = reinterpret_cast<int*>(ws);
+            float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + attention_pp_ws_counter_bytes(B, nh, Ntok));
+            if (QB == 4) {
+                if (int rc = set_dyn_lds<attn_pp16sk_kernel<4>>(smem)) return rc;
+                hipLaunchKernelGGL(attn_pp16sk_kernel<4>, dim3(nx * gx), dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, nx, B * nh / nx, part, cnt);
+            } else {
+                if (int rc = set_dyn_lds<attn_pp16sk_kernel<2>>(smem)) return rc;
+                hipLaunchKernelGGL(attn_pp16sk_kernel<2>, dim3(nx * gx), dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, nx, B * nh / nx, part, cnt);
+            }
+            return (int)hipGetLastError();
+        }
+    }
+#else
+    (void)ws; (void)ws_bytes;
+#endif
     dim3 grid((Ntok + 127) / 128, B * nh);
     // attn_pp16mq_kernel<QB>: row sums on the matrix pipe; QB = 4 (64 queries per wave, 2 waves per SIMD) when the grid still fills the chip
     // several times over, QB = 2 (3 waves per SIMD) otherwise - bit-identical results (see the kernel).  ATTN_KERN: 0 = attn_pp16_kernel,
@@ -793,8 +834,9 @@ static int launch_attn_pp_cfg(const void* q, const void* k, const void* v, void*
 }
 #endif
 
-// q, k, v: (B, nh, Ntok, 64) fp16 (q pre-scaled by log2(e)/8); out: (B, Ntok, nh*64) fp16
-int launch_attention_pp(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st) {
+// q, k, v: (B, nh, Ntok, 64) fp16 (q pre-scaled by log2(e)/8); out: (B, Ntok, nh*64) fp16.  ws (optional): attention_pp_ws_bytes(B, nh, Ntok) bytes whose first
+// attention_pp_ws_counter_bytes() are zero - enables the stream-K form on sub-round grids
+int launch_attention_pp(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st, void* ws, size_t ws_bytes) {
     if (Ntok < 1) return -1;
 #ifdef MOGE_EXPERIMENTS
     switch (moge_tune_get("ATTN_EXP", 0)) {            // tools/kbench A-B only
@@ -804,5 +846,5 @@ int launch_attention_pp(const void* q, const void* k, const void* v, void* out, 
     default: break;
     }
 #endif
-    return launch_attn_pp16(q, k, v, out, B, nh, Ntok, st);
+    return launch_attn_pp16(q, k, v, out, B, nh, Ntok, st, ws, ws_bytes);
 }

@@ -251,6 +251,11 @@ struct GemmArgs {
     // w = composed weights [4 Cout][4 C] (row = phase * Cout + co, column = tap * C + ci), N = 4 Cout, K = 4 C, epi = EPI_CONVT, a2 = optional HIGH-res side map
     // (B, 2H, 2W, Cout) with w2 [Cout][Cout].  The border ring is corrected afterwards by launch_ct3_border.
     int ct3;
+    // LN-fold producer, latency regime (gemm_glds_kernel only; round 6): the workgroup that completes a row block's last column tile turns the block's
+    // (sum, sum of squares) partials into (mean, rstd) itself - ln_finalize_kernel's arithmetic in ln_finalize_kernel's order, bit-identical - so that the
+    // separate 5 us launch between producer and consumer disappears at batch 1.  ln_cnt: one int per 64 rows, zero before the launch, left zero.
+    float* ln_mr_out;
+    int* ln_cnt;
 };
 
 // Opt a kernel into more than 64 KiB of dynamic LDS.  The attribute is per DEVICE and a process may drive several (one host thread per
@@ -286,6 +291,7 @@ inline int pp_device_cus() {
 template <typename T> int launch_gemm(const GemmArgs& g, int amode, hipStream_t st);
 bool gemm_pp_eligible(const GemmArgs& g);
 void moge_internal_set_error(const char* msg);      // model.hip: text behind moge_last_error()
+bool gemm_fuses_ln_finalize(const GemmArgs& g);      // launch_gemm<f16>(g, AMODE_LINEAR) will take gemm_glds_kernel, which can finalise the LN statistics itself (GemmArgs::ln_mr_out)
 bool gemm_runs_pp(const GemmArgs& g);       // launch_gemm<f16>(g, AMODE_LINEAR) will take the ping-pong throughput kernel (profiler class)
 int launch_gemm_pp(const GemmArgs& g, hipStream_t st);
 bool conv_pp_eligible(const GemmArgs& g);

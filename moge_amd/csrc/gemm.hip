@@ -230,7 +230,10 @@ __device__ __forceinline__ void epilogue_pair16(const GemmArgs& g, int m, int nb
             s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
             u1[jh] = s1; u2[jh] = s2;
         }
-        if (g4 == 0 && ok && g.ln_part) *reinterpret_cast<f32x2*>(g.ln_part + ((size_t)m * (g.N >> 5) + (nb32 >> 5)) * 2) = f32x2{u1[0] + u1[1], u2[0] + u2[1]};
+        // (write-through: with GemmArgs::ln_mr_out another workgroup of THIS launch, possibly on another XCD's L2, reads the partials - see the fused finalize)
+        if (g4 == 0 && ok && g.ln_part)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(g.ln_part + ((size_t)m * (g.N >> 5) + (nb32 >> 5)) * 2),
+                               __builtin_bit_cast(unsigned long long, f32x2{u1[0] + u1[1], u2[0] + u2[1]}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     epilogue4<T>(g, m, nb32 + 4 * g4, a0[0], a0[1], a0[2], a0[3]);
@@ -597,6 +600,46 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
 #pragma unroll
             for (int j = 0; j < TN; j++) epilogue_pair16<T>(g, m, n0 + (wn * TN + j) * 32, g4, acc16[i][2 * j], acc16[i][2 * j + 1]);
         }
+        if (g.ln_mr_out) {
+            // fused LN finalize (GemmArgs::ln_mr_out): the last workgroup of this row block to get here reads the block's partials (all column tiles')
+            // and writes (mean, rstd) - 8 lanes per row, quads j, j + 8, ..., then the 1-2-4 butterfly: exactly ln_finalize_kernel (elementwise.hip)
+            // (no __threadfence(): a device-scope fence is an L2 writeback + invalidate per wave here.  The partials are system-scope write-through stores,
+            //  acknowledged at the barrier's vmcnt(0); the counter and the reads below are system-scope atomics as well.)
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(smem);
+            if (tid == 0) {
+                int* c = g.ln_cnt + bm;
+                const int last = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == nbn - 1;
+                if (last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                *flag = last;
+            }
+            __syncthreads();
+            if (*flag) {
+                const int NP = g.N >> 5;
+                const float invD = 1.f / (float)g.N;
+                const int j8 = tid & 7;
+                for (int r = tid >> 3; r < BM; r += NT / 8) {
+                    const long row = (long)m0 + r;
+                    float s1 = 0.f, s2 = 0.f;
+                    if (row < g.M) {
+                        const unsigned long long* p = reinterpret_cast<const unsigned long long*>(g.ln_part + row * (long)NP * 2);
+                        for (int qd = j8; qd < NP / 2; qd += 8) {
+                            const f32x2 t0 = __builtin_bit_cast(f32x2, __hip_atomic_load(p + 2 * qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                            const f32x2 t1 = __builtin_bit_cast(f32x2, __hip_atomic_load(p + 2 * qd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                            s1 += t0[0]; s2 += t0[1];
+                            s1 += t1[0]; s2 += t1[1];
+                        }
+                    }
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+                    if (row < g.M && j8 == 0) {
+                        const float mean = s1 * invD;
+                        const float var = fmaxf(fmaf(-mean, mean, s2 * invD), 0.f);
+                        *reinterpret_cast<f32x2*>(g.ln_mr_out + 2 * row) = f32x2{mean, rsqrtf(var + 1e-6f)};
+                    }
+                }
+            }
+        }
         return;
     }
 #pragma unroll
@@ -680,6 +723,15 @@ bool gemm_runs_pp(const GemmArgs& g) {
     // crossover (M = 3601 per image, N = 1024): the 64 x 128 kernel takes 47 / 18 us per image (fc2 / proj), a 256 x 256 tile 74 / 28 us however few of
     // them there are - from ~94 tiles (two images: 116) the throughput kernel wins (batch 2: 169.3 -> 173.4 img/s)
     return tiles >= moge_tune_get("PP_MIN_TILES", 96);
+}
+
+// LN-fold producers (EPI_RESID + ln_part) that go to gemm_glds_kernel can finalise the statistics themselves (GemmArgs::ln_mr_out): true when launch_gemm<f16>
+// would take that kernel for g - the caller then sets ln_mr_out / ln_cnt and skips launch_ln_finalize.
+bool gemm_fuses_ln_finalize(const GemmArgs& g) {
+    if (!moge_tune_get("LN_FINALIZE_FUSED", 1)) return false;
+    if (g.epi != EPI_RESID || !g.ln_part || !g.x16 || (g.N & 63) != 0) return false;
+    if (gemm_runs_pp(g)) return false;
+    return g.N > 64 && !g.relu_in && (g.K % (8 * TT<f16>::CH)) == 0 && !moge_tune_get("DISABLE_GLDS", 0);
 }
 
 template <typename T>

@@ -5,7 +5,9 @@
 template <typename T> int launch_attention(const void* q, const void* k, const void* vT, void* out, int B, int nh, int Ntok, int Npad, hipStream_t st);
 
 // fp16 throughput path (attention_pp.hip): q, k, v all (B, nh, Ntok, 64)
-int launch_attention_pp(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st);
+int launch_attention_pp(const void* q, const void* k, const void* v, void* out, int B, int nh, int Ntok, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0);
+size_t attention_pp_ws_bytes(int B, int nh, int Ntok);            // stream-K form (sub-round grids): workspace wanted, 0 = not taken for this shape
+size_t attention_pp_ws_counter_bytes(int B, int nh, int Ntok);    // ... of which this many leading bytes must be zero before the first launch (the kernel leaves them zero)
 
 template <typename TIn, typename TOut>
 int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out, int round16, int aa, const float* mean,

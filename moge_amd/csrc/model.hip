@@ -80,6 +80,7 @@ struct moge_handle {
     int onnx_mode = 0;          // onnx_compatible_mode (v2.py:67-74): plain bilinear 14x resize, size-based pos-embed resampling
     std::vector<PosEntry> pos_cache;
     int* d_status = nullptr;
+    int* h_status = nullptr;       // pinned host copy of d_status: moge_sync reads it back on the stream, in front of its one host wait
     // staging for uint8 HWC input (img_dtype 2): converted to the model dtype, CHW, before the forward
     void* u8_stage = nullptr;
     size_t u8_stage_bytes = 0;
@@ -689,6 +690,8 @@ struct Plan {
     int head_sets = 1;        // scratch triples: one per decoder head when the heads run on their own streams (small batches), else 1
     int slot = 0;             // index of this (sub-)batch among the batch-split parts (selects the head streams)
     size_t ln_part, ln_mr;    // LN fold: (sum, sum of squares) per row and 32-column group; (mean, rstd) per row
+    size_t ln_cnt = 0, ln_cnt_bytes = 0;        // fused LN finalize of the latency-regime GEMMs: one counter per 64 rows (zero before the first launch, left zero)
+    size_t attn_ws = 0, attn_ws_bytes = 0;      // stream-K attention (sub-round grids, fp16): counters + segment slots (attention_pp.hip); 0 = plain grid
     size_t maskprob, focal, shift, intr, pts_tmp, nrm_tmp, post_end;
     size_t gn = 0;            // GroupNorm partial sums (normalised residual blocks, ABI v3)
     int B, H, W, rows, cols, Np, Ntok, Npad;
@@ -726,6 +729,10 @@ static Plan make_plan(const moge_config& c, int prec, int B, int H, int W, int r
     p.vT = take(p, (size_t)B * D * p.Npad * s);
     p.attn = take(p, BN * D * s);
     p.hidden = take(p, BN * 4 * D * s);
+    if (prec == MOGE_FP16) {      // (adjacent: one memset zeroes the LN counters and the attention counters at the head of attn_ws)
+        p.ln_cnt_bytes = (BN / 64 + 2) * 4; p.ln_cnt = take(p, p.ln_cnt_bytes);
+        p.attn_ws_bytes = attention_pp_ws_bytes(B, c.num_heads, p.Ntok); p.attn_ws = take(p, p.attn_ws_bytes);
+    }
     p.tapcat = take(p, BP * c.n_taps * D * s);
     p.cls = take(p, (size_t)B * D * 4);
     p.mlp1 = take(p, (size_t)B * (c.scale_hidden > 0 ? c.scale_hidden : 1) * 4);
@@ -1052,6 +1059,11 @@ static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, in
     // fp16 throughput path: V row-major + attention_pp (LDS-DMA, transposed LDS reads); fp32 parity path: V^T + attention.hip
     const bool attn_pp = std::is_same<T, f16>::value && moge_tune_get("ATTN_PP", 1) != 0;
     if (!attn_pp) HIPCHK(hipMemsetAsync(vT, 0, (size_t)B * D * Npad * sizeof(T), st));      // zero the key padding of V^T
+    // stream-K attention (one image: 464 workgroups on 768 slots): its per-query-block counters start at zero; the kernel leaves them zero
+    void* attn_ws = attn_pp && pl.attn_ws_bytes ? (void*)(ws + pl.attn_ws) : nullptr;
+    int* ln_cnt = pl.ln_cnt_bytes ? (int*)(ws + pl.ln_cnt) : nullptr;       // fused LN finalize (latency-regime GEMMs): row-block counters
+    if (ln_cnt) HIPCHK(hipMemsetAsync(ln_cnt, 0, attn_ws ? (pl.attn_ws - pl.ln_cnt) + attention_pp_ws_counter_bytes(B, nh, Ntok) : pl.ln_cnt_bytes, st));      // (adjacent regions: one memset)
+    else if (attn_ws) HIPCHK(hipMemsetAsync(attn_ws, 0, attention_pp_ws_counter_bytes(B, nh, Ntok), st));
 
     // ---- ViT blocks (block.py:110-112) -----------------------------------------------------------------------------
     // LN fold (fp16 path): norm1 / norm2 never run as kernels.  LN(x) W^T + b = rstd (x W'^T - mean c) + b' with W' = g (.) W: the qkv and
@@ -1065,6 +1077,7 @@ static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, in
     float* ln_part = (float*)(ws + pl.ln_part);
     float* ln_mr = (float*)(ws + pl.ln_mr);
     int tap_k = 0;
+    bool ln_done = false;          // the producer GEMM in front has written (mean, rstd) itself: no ln_finalize launch
     for (int i = 0; i < L; i++) {
         const std::string p = bb + S("blocks.%d.", i);
         if (!ln_fold) {
@@ -1073,7 +1086,7 @@ static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, in
         } else if (i == 0) {
             ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * D * (4 + sizeof(T)));
             LCHK(launch_ln_raw<f16>(x, xn, ln_mr, BN, D, st));          // tokens0 come from the patch-embed epilogue: copy + statistics
-        } else {
+        } else if (!ln_done) {
             ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * (D / 32) * 8);
             LCHK(launch_ln_finalize(ln_part, ln_mr, BN, D / 32, D, st));   // partials of block i-1's fc2 epilogue
         }
@@ -1089,7 +1102,7 @@ static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, in
         }
         {
             ProfScope ps(h, st, MOGE_KC_ATTN, 4.0 * B * nh * (double)Ntok * Ntok * 64, (double)BN * D * 4 * sizeof(T));
-            if (attn_pp) LCHK(launch_attention_pp(qb, kb, vT, attn, B, nh, Ntok, st));
+            if (attn_pp) LCHK(launch_attention_pp(qb, kb, vT, attn, B, nh, Ntok, st, attn_ws, pl.attn_ws_bytes));
             else LCHK(launch_attention<T>(qb, kb, vT, attn, B, nh, Ntok, Npad, st));
         }
         {
@@ -1099,12 +1112,14 @@ static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, in
             g.epi = EPI_RESID; g.bias = M(h, p + "attn.proj.bias"); g.xres = x; g.ldc = D; g.gamma = M(h, p + "ls1.gamma");
             if (ln_fold) { g.x16 = xn; g.ln_part = ln_part; }
             if (half_resid) g.xres = nullptr;
+            ln_done = ln_fold && ln_cnt && gemm_fuses_ln_finalize(g);     // latency regime: the GEMM's last column tile of a row block writes (mean, rstd)
+            if (ln_done) { g.ln_mr_out = ln_mr; g.ln_cnt = ln_cnt; }
             CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
         }
         if (!ln_fold) {
             ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * D * (4 + sizeof(T)));
             LCHK(launch_layernorm<T>(x, M(h, p + "norm2.weight"), M(h, p + "norm2.bias"), xn, nullptr, BN, D, D, 0, 0, Ntok, st));
-        } else {
+        } else if (!ln_done) {
             ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * (D / 32) * 8);
             LCHK(launch_ln_finalize(ln_part, ln_mr, BN, D / 32, D, st));
         }
@@ -1123,6 +1138,8 @@ static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, in
             g.epi = EPI_RESID; g.bias = M(h, p + "mlp.fc2.bias"); g.xres = x; g.ldc = D; g.gamma = M(h, p + "ls2.gamma");
             if (ln_fold && i + 1 < L) { g.x16 = xn; g.ln_part = ln_part; }
             if (half_resid) { g.xres = nullptr; g.x16 = xn; }          // (last block: no statistics wanted, the stream is still updated)
+            ln_done = ln_fold && ln_cnt && gemm_fuses_ln_finalize(g);     // (block i + 1's qkv reads ln_mr)
+            if (ln_done) { g.ln_mr_out = ln_mr; g.ln_cnt = ln_cnt; }
             CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st));
         }
         for (int k = 0; k < c.n_taps; k++)
@@ -1166,14 +1183,7 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     // roundings; the fp32 parity path keeps the reference's layer-by-layer order.
     const bool compose = std::is_same<T, f16>::value && moge_tune_get("COMPOSE", 1) != 0;
     CHK(encode<T>(h, image, img_dtype, pl.H, pl.W, pl, st, !compose));
-    // ---- scale head (modules.py:184-192, v2.py:167,182) ---------------------------------------------------------
-    if ((c.heads & MOGE_HEAD_SCALE) && o_metric) {
-        float* m1 = (float*)(ws + pl.mlp1); float* m2 = (float*)(ws + pl.mlp2);
-        ProfScope ps(h, st, MOGE_KC_POST, 0, 0);
-        LCHK(launch_mlp_layer(cls, M(h, "scale_head.0.weight"), M(h, "scale_head.0.bias"), m1, B, D, c.scale_hidden, 1, st));
-        LCHK(launch_mlp_layer(m1, M(h, "scale_head.2.weight"), M(h, "scale_head.2.bias"), m2, B, c.scale_hidden, c.scale_hidden, 1, st));
-        LCHK(launch_mlp_layer(m2, M(h, "scale_head.4.weight"), M(h, "scale_head.4.bias"), o_metric, B, c.scale_hidden, 1, 2, st));
-    }
+    // (the scale head runs behind the heads, see below)
 
     // fp16 path, level 4 (no residual blocks there, 32 channels): out_k(x4_k + in4_k(n4)) = Wout_k x4_k + (Wout_k Win4_k) n4 + b2_k is evaluated
     // INSIDE the two 64 -> 4 x 32 resampler convs (conv_pp.hip, fused output conv); head_final only resizes and remaps 4 + 4 floats per tap
@@ -1355,6 +1365,16 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
         }
     }
     st = st_main;
+    // ---- scale head (modules.py:184-192, v2.py:167,182) ---------------------------------------------------------
+    // Three tiny launches on the caller's stream BEHIND its head: with the other heads on their own streams (small batches) the caller's stream finishes its
+    // head first and would idle until the join - in front of the neck (rounds 1-5) the same 15 us sat on the batch-1 critical path.
+    if ((c.heads & MOGE_HEAD_SCALE) && o_metric) {
+        float* m1 = (float*)(ws + pl.mlp1); float* m2 = (float*)(ws + pl.mlp2);
+        ProfScope ps(h, st, MOGE_KC_POST, 0, 0);
+        LCHK(launch_mlp_layer(cls, M(h, "scale_head.0.weight"), M(h, "scale_head.0.bias"), m1, B, D, c.scale_hidden, 1, st));
+        LCHK(launch_mlp_layer(m1, M(h, "scale_head.2.weight"), M(h, "scale_head.2.bias"), m2, B, c.scale_hidden, c.scale_hidden, 1, st));
+        LCHK(launch_mlp_layer(m2, M(h, "scale_head.4.weight"), M(h, "scale_head.4.bias"), o_metric, B, c.scale_hidden, 1, 2, st));
+    }
     for (int i = 0; i < 2; i++)
         if (forked & (1 << i)) {
             HIPCHK(hipEventRecord(h->ev_head[pl.slot][i], h->head_st[pl.slot][i]));
@@ -1506,6 +1526,10 @@ static PlanV1 make_plan_v1(moge_handle* h, int prec, int B, int H, int W, int rh
     p.vT = take(p, (size_t)B * D * p.Npad * s);
     p.attn = take(p, BN * D * s);
     p.hidden = take(p, BN * 4 * D * s);
+    if (prec == MOGE_FP16) {      // (adjacent: one memset zeroes the LN counters and the attention counters at the head of attn_ws)
+        p.ln_cnt_bytes = (BN / 64 + 2) * 4; p.ln_cnt = take(p, p.ln_cnt_bytes);
+        p.attn_ws_bytes = attention_pp_ws_bytes(B, c.num_heads, p.Ntok); p.attn_ws = take(p, p.attn_ws_bytes);
+    }
     p.tapcat = take(p, BP * c.n_taps * D * s);
     p.cls = take(p, (size_t)B * D * 4);
     p.mlp1 = p.mlp2 = 0;
@@ -1706,6 +1730,7 @@ int moge_create(const moge_config* cfg, int device, moge_handle** out) {
     hipMemset(h->d_status, 0, sizeof(int));
     e = hipMalloc(&h->bcast_rec, 5 * sizeof(long long));                                           // status record of moge_broadcast_weights
     if (e != hipSuccess) { hipFree(h->d_status); delete h; return fail(MOGE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    if (hipHostMalloc((void**)&h->h_status, sizeof(int), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->h_status = nullptr; }      // (optional: moge_sync falls back to a blocking copy)
     *out = h;
     return 0;
 }
@@ -1763,6 +1788,7 @@ int moge_create_v1(const moge_v1_config* cfg, int device, moge_handle** out) {
     hipMemset(h->d_status, 0, sizeof(int));
     e = hipMalloc(&h->bcast_rec, 5 * sizeof(long long));                                           // status record of moge_broadcast_weights
     if (e != hipSuccess) { hipFree(h->d_status); delete h; return fail(MOGE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    if (hipHostMalloc((void**)&h->h_status, sizeof(int), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->h_status = nullptr; }      // (optional: moge_sync falls back to a blocking copy)
     *out = h;
     return 0;
 }
@@ -1778,6 +1804,7 @@ void moge_destroy(moge_handle* h) {
     if (h->u8_stage) hipFree(h->u8_stage);
     for (auto& e : h->pos_cache) hipFree(e.ptr);
     if (h->d_status) hipFree(h->d_status);
+    if (h->h_status) hipHostFree(h->h_status);
     if (h->bcast_rec) hipFree(h->bcast_rec);
     for (int i = 0; i < moge_handle::MAX_SPLIT; i++) { if (h->split_st[i]) hipStreamDestroy(h->split_st[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -2173,9 +2200,17 @@ int moge_cast_f16(const float* src, void* dst_f16, int64_t n, void* stream) {
 
 int moge_sync(moge_handle* h, void* stream) {
     if (!h) return fail(MOGE_ERR_INVALID, "null handle");
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    // ONE host wait: the status word is copied to pinned host memory on the stream, behind the work it reports on.  (Rounds 1-5 waited for the stream and then
+    // ran a blocking 4-byte copy: two host round trips of ~90 us each per call - 1.4 % of a single-image infer().)
     int stv = 0;
-    HIPCHK(hipMemcpy(&stv, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (h->h_status) {
+        HIPCHK(hipMemcpyAsync(h->h_status, h->d_status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        stv = *(volatile int*)h->h_status;
+    } else {
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        HIPCHK(hipMemcpy(&stv, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    }
     if (stv != 0) {
         HIPCHK(hipMemset(h->d_status, 0, sizeof(int)));
         return fail(stv, "Residuals are not finite in the initial point.");

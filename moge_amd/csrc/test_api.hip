@@ -129,7 +129,11 @@ static int t_attention(const float* q, const float* k, const float* v, float* o,
         DevBuf vr;                                   // row-major V for the fp16 throughput kernel
         TCHK(vr.alloc(n * sizeof(T)));
         TL(to_t<T>(v, vr.p, (long)n, st));
-        TL(launch_attention_pp(qb.p, kb.p, vr.p, ob.p, B, nh, N, st));
+        DevBuf aws;                                  // stream-K form (sub-round grids; ATTN_SK = 2 forces it): counters zeroed once
+        const size_t awb = attention_pp_ws_bytes(B, nh, N);
+        if (awb) { TCHK(aws.alloc(awb)); TCHK(hipMemsetAsync(aws.p, 0, attention_pp_ws_counter_bytes(B, nh, N), st)); }
+        TL(launch_attention_pp(qb.p, kb.p, vr.p, ob.p, B, nh, N, st, awb ? aws.p : nullptr, awb));
+        if (awb && moge_tune_get("ATTN_SK_TWICE", 0)) TL(launch_attention_pp(qb.p, kb.p, vr.p, ob.p, B, nh, N, st, aws.p, awb));      // tests: the counters are left zero
         TL(from_t<T>(ob.p, o, (long)n, st));
         TCHK(hipStreamSynchronize(st));
         return 0;

@@ -120,6 +120,45 @@ def test_attention_ping_pong_kernel_is_bit_identical(H, B, nh, N, prio):
     assert torch.equal(outs[1], outs[4])
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "moge_amd", "lib", "obj", ".experiments")),
+                    reason="attn_pp16sk_kernel (tools/experiments/) is compiled by `python -m moge_amd.build --experiments` only")
+@pytest.mark.parametrize("qb", [2, 4])
+@pytest.mark.parametrize("B,nh,N,wgs", [(1, 16, 3601, 0),          # the batch-1 shape of the bench: 8 XCD ranges x 96 workgroups, 34.4 tiles each
+                                        (1, 8, 1370, 0), (1, 2, 3601, 0), (1, 2, 3601, 5), (2, 3, 130, 1), (2, 3, 130, 4), (2, 3, 130, 17),
+                                        (1, 2, 300, 3), (1, 2, 300, 7), (1, 8, 700, 2), (1, 1, 64, 1), (1, 1, 65, 2), (3, 1, 1, 1), (1, 2, 513, 9)])
+def test_attention_stream_k(H, B, nh, N, wgs, qb):
+    """attn_pp16sk_kernel (round 6 experiment, measured 5-8 us slower at one image and therefore not in the product library): attn_pp16mq's body over equal contiguous ranges of (query block, key tile)
+    units; a query block cut into segments is combined by the last-arriving workgroup in segment order.  Forced (ATTN_SK = 2) with partitions that give
+    every case - one workgroup walking several whole query blocks (wgs 1), segments of 1-2 tiles (wgs 17 at two tiles per block), three segments per
+    block, a segment that is only the masked last tile, ranges that start / end on block boundaries, B * nh a multiple of 8 (8 ranges) or not (1) - with late
+    dominant keys that trip the overflow guard inside some segments.  Checked against SDPA at the fp16 tolerance, against the unsplit kernel within a few fp16
+    ulps of the output scale (same fp32 terms, different order), for run-to-run bit-identity (the combine order is fixed) and with a second launch on the
+    same workspace (the counters are left zero)."""
+    from moge_amd import _lib as L
+    g = torch.Generator().manual_seed(N + 31 * wgs)
+    q, k, v = (torch.randn(B, nh, N, 64, generator=g) for _ in range(3))
+    q = q * 1.5
+    v[:, :, N // 2] += 5.0
+    if N > 80:
+        k[:, :, N // 2 + 3] = q[:, :, 5] * 6.0
+        k[:, 0, N - 2] = q[:, 0, min(70, N - 1)] * 5.0
+    ref = F.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda()).permute(0, 2, 1, 3).reshape(B, N, nh * 64)
+    L.tune("ATTN_SK", 0)
+    try:
+        plain = H.attention(1, q, k, v)
+        L.tune("ATTN_SK", 2); L.tune("ATTN_SK_QB", qb); L.tune("ATTN_SK_WGS", wgs); L.tune("ATTN_SK_MIN_TILES", 1 if wgs == 0 and N < 2000 else 12)
+        a = H.attention(1, q, k, v)
+        b = H.attention(1, q, k, v)
+        L.tune("ATTN_SK_TWICE", 1)
+        c = H.attention(1, q, k, v)
+    finally:
+        for key, dflt in (("ATTN_SK", 0), ("ATTN_SK_QB", 2), ("ATTN_SK_WGS", 0), ("ATTN_SK_MIN_TILES", 12), ("ATTN_SK_TWICE", 0)):
+            L.tune(key, dflt)
+    assert relmax(a, ref) < 1e-2
+    assert relmax(a, plain) < 2e-3
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_attention_online_softmax_rescale(H):
     """rule 26: force the running-max rescale branch - one key in a LATE tile dominates one query."""
     g = torch.Generator().manual_seed(7)

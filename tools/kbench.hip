@@ -167,7 +167,8 @@ static int bench_gemm(const char* filter, int iters) {
         {"b1.fc2", Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"vitb1.proj", Ntok, 768, 768, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
         {"vitb1.fc2", Ntok, 768, 3072, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
-        {"b4.proj", 4 * Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
+        {"b1.fc2s2", 2 * Ntok, 1024, 2048, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},      // fc2 of one image split in two along K, emulated: same FLOPs and workgroup count
+        {"b4.proj", 4 * Ntok, 1024, 1024, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},          // (= fc2 of one image split in four along K, emulated)
         {"b4.fc2", 4 * Ntok, 1024, 4096, EPI_RESID, ACT_NONE, 0, 0, 0, 0, 0, 0, 0},
     };
     // kern: PP_KERN (0 = gemm_pp128m16_kernel, 2 = gemm_pp128p_kernel (persistent), 1 = gemm_pp4w16_kernel (--experiments));  exp: PP_EXP (library built with --experiments only: 1/2/3 = gemm_pp128
@@ -183,7 +184,7 @@ static int bench_gemm(const char* filter, int iters) {
                                       {"x:pp4w-32", 1, 2, 0, 0, 4}, {"x:pp64", 1, 2, 0, 0, 5}, {"x:pp64-2wg", 1, 2, 0, 0, 6}};
     if (getenv("KB_GC")) variants = {{"pp128p", 1, 2, 0, 2, 0}, {"pp128p gc2", 1, 2, 2, 2, 0}, {"pp128p gc8", 1, 2, 8, 2, 0}, {"pp128p gc16", 1, 2, 16, 2, 0}};
     if (getenv("KB_LAT")) variants = {{"64x128 ns2", 0, 2, 0, 0, 0, 2, 512}, {"64x128 ns3", 0, 2, 0, 0, 0, 3, 512}, {"64x128 ns4", 0, 2, 0, 0, 0, 4, 512},      // latency-regime kernels
-                                      {"128x128 ns2", 0, 2, 0, 0, 0, 2, 0}, {"128x128 ns3", 0, 4, 0, 0, 0, 2, 0}, {"128x128 ns4", 0, 5, 0, 0, 0, 2, 0}, {"pp128p", 1, 2, 0, 2, 0}};
+                                      {"128x128 ns2", 0, 2, 0, 0, 0, 2, 0}, {"128x128 ns3", 0, 4, 0, 0, 0, 2, 0}, {"128x128 ns4", 0, 5, 0, 0, 0, 2, 0}, {"256x128 8w", 0, 3, 0, 0, 0, 2, 0}, {"pp128p", 1, 2, 0, 2, 0}};
     if (getenv("KB_PP")) variants = {{"pp128-m16", 1, 2, 0, 0, 0}, {"pp128p", 1, 2, 0, 2, 0}};
     if (getenv("KB_M3")) variants = {{"pp128p 4+4", 1, 2, 0, 2, 0}, {"x:2+6", 1, 2, 0, 5, 0}, {"x:3+5", 1, 2, 0, 6, 0}, {"x:dma1st", 1, 2, 0, 7, 0}, {"x:6+2", 1, 2, 0, 8, 0}};      // DMA schedules of the persistent GEMM (--experiments builds)
     if (getenv("KB_STAG")) variants = {{"pp128p", 1, 2, 0, 2, 0}, {"stagger 2", 1, 2, 0, 2, 0, 3, 512, 2}, {"stagger 3", 1, 2, 0, 2, 0, 3, 512, 3}, {"stagger 4", 1, 2, 0, 2, 0, 3, 512, 4},
@@ -412,7 +413,7 @@ static int bench_attn(const char* filter, int iters) {
         ref_attn<<<ns, 256, 0, st>>>(q, k, v, dbh, dq, c.Ntok, ref);
         CK(hipStreamSynchronize(st));
         // exp: ATTN_EXP (32x32x16 kernels), var: ATTN_VAR bits of attn_pp16_kernel - both need a library built with --experiments
-        struct Var { const char* name; int kind, exp, var; int kern = 0; };
+        struct Var { const char* name; int kind, exp, var; int kern = 0; int sk = 0; };      // sk: 2 / 4 = attn_pp16sk_kernel<QB> (stream-K partition, round 6) forced
         // kern 4 = attn_pp16x_kernel (ping-pong wave groups) [+ attn_pp16mq on the queries beyond the last full 512-block]; 5 = the same with s_setprio 1 in the M phase
         std::vector<Var> vars = {{"pp16", 1, 0, 0, 0}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}};
         // kern 6 / 7 = attn_pp16s_kernel (software-pipelined; one / two workgroups per CU) [+ attn_pp16mq<4> on the queries beyond the last full 256-block]
@@ -420,6 +421,8 @@ static int bench_attn(const char* filter, int iters) {
 #ifdef MOGE_EXPERIMENTS
         if (getenv("KB_X")) vars = {{"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"x+prio", 1, 0, 0, 5}};
 #endif
+        if (getenv("KB_SK")) vars = {{"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"sk<2>", 1, 0, 0, 3, 2}, {"sk<4>", 1, 0, 0, 3, 4}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"sk<2>", 1, 0, 0, 3, 2}, {"sk<4>", 1, 0, 0, 3, 4}};
+        void* sk_ws = nullptr; size_t sk_ws_bytes = 0;
         f16* out_q2 = nullptr;                       // mq<2> result: mq<4> must reproduce it bit for bit (per-block guard decisions; spiked keys above force them)
         CK(hipMalloc(&out_q2, n * 2));
         if (getenv("KB_EXP")) vars = {{"old(vT)", 0, 0, 0}, {"x:pp32 nw4", 1, 1, 0}, {"pp16", 1, 0, 0}, {"x:noexp", 1, 0, 1}, {"x:noguard", 1, 0, 2}, {"x:ks-outer", 1, 0, 4},
@@ -431,7 +434,14 @@ static int bench_attn(const char* filter, int iters) {
             moge_tune_set("ATTN_VAR", va.var);
             moge_tune_set("ATTN_KERN", va.kern == 5 ? 4 : va.kern);
             moge_tune_set("ATTN_X_PRIO", va.kern == 5 ? 1 : 0);
-            auto run = [&]() { return va.kind == 0 ? launch_attention<f16>(q, k, vT, out, c.B, c.nh, c.Ntok, Npad, st) : launch_attention_pp(q, k, v, out, c.B, c.nh, c.Ntok, st); };
+            moge_tune_set("ATTN_SK", va.sk ? 2 : 0); moge_tune_set("ATTN_SK_QB", va.sk ? va.sk : 2);
+            if (getenv("KB_SK_WGS")) moge_tune_set("ATTN_SK_WGS", atoi(getenv("KB_SK_WGS")));
+            if (va.sk) {
+                const size_t need = attention_pp_ws_bytes(c.B, c.nh, c.Ntok);
+                if (need > sk_ws_bytes) { if (sk_ws) CK(hipFree(sk_ws)); CK(hipMalloc(&sk_ws, need)); sk_ws_bytes = need; }
+                CK(hipMemsetAsync(sk_ws, 0, attention_pp_ws_counter_bytes(c.B, c.nh, c.Ntok), st));
+            }
+            auto run = [&]() { return va.kind == 0 ? launch_attention<f16>(q, k, vT, out, c.B, c.nh, c.Ntok, Npad, st) : launch_attention_pp(q, k, v, out, c.B, c.nh, c.Ntok, st, va.sk ? sk_ws : nullptr, va.sk ? sk_ws_bytes : 0); };
             CK(hipMemsetAsync(out, 0, n * 2, st));
             int rc = run();
             if (rc) { printf("%s %s launch rc=%d\n", c.name, va.name, rc); fails++; continue; }
@@ -449,7 +459,7 @@ static int bench_attn(const char* filter, int iters) {
             const double tf = 4.0 * BH * (double)c.Ntok * c.Ntok * 64 / (ms * 1e-3) / 1e12;
             int hdiff = -1;
             if (va.kern == 1) CK(hipMemcpyAsync(out_q2, out, n * 2, hipMemcpyDeviceToDevice, st));
-            if (va.kern >= 2) {
+            if (va.kern >= 2 && !va.sk) {
                 CK(hipMemsetAsync(dbad, 0, 4, st));
                 cmp_bits<<<2048, 256, 0, st>>>(out, out_q2, n, dbad);
                 CK(hipMemcpyAsync(&hdiff, dbad, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
@@ -462,6 +472,7 @@ static int bench_attn(const char* filter, int iters) {
             if (hbad) fails++;
         }
         CK(hipFree(out_q2));
+        if (sk_ws) CK(hipFree(sk_ws));
         CK(hipFree(q)); CK(hipFree(k)); CK(hipFree(v)); CK(hipFree(vT)); CK(hipFree(out)); CK(hipFree(dbh)); CK(hipFree(dq)); CK(hipFree(ref)); CK(hipFree(dmax)); CK(hipFree(dbad));
     }
     return fails;
