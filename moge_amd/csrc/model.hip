@@ -2205,7 +2205,7 @@ int moge_sync(moge_handle* h, void* stream) {
     int stv = 0;
     if (h->h_status) {
         HIPCHK(hipMemcpyAsync(h->h_status, h->d_status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
-        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));      // (polling the pinned word instead of this blocking wait measured level: profiles/r06p_ab_SYNC_SPIN_US_b1.log)
         stv = *(volatile int*)h->h_status;
     } else {
         HIPCHK(hipStreamSynchronize((hipStream_t)stream));

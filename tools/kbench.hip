@@ -271,6 +271,21 @@ static int bench_gemm(const char* filter, int iters) {
                            100.0 * (double)(hts[w * 8 + 4] - hts[w * 8]) / (double)(hts[w * 8 + 7] - hts[w * 8 + 6]));
                 CK(hipFree(dts));
             }
+            if (getenv("KB_TS") && v.pp && (v.exp == 5 || v.exp == 6)) {      // 64-byte-row kernels: every workgroup's phase stamps -> CSV (tools/pp64_timeline.py pairs the workgroups of a CU)
+                const size_t nwg = ((M + 255) / 256) * (N / (v.exp == 6 ? 128 : 256));
+                unsigned long long* dts; CK(hipMalloc(&dts, nwg * 64)); CK(hipMemsetAsync(dts, 0, nwg * 64, st));
+                GemmArgs g2 = g; g2.dbg_ts = dts;
+                launch_gemm<f16>(g2, AMODE_LINEAR, st);
+                std::vector<unsigned long long> hts(nwg * 8);
+                CK(hipMemcpyAsync(hts.data(), dts, nwg * 64, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+                char fn[256]; snprintf(fn, sizeof fn, "%s/pp64_timeline_%s_exp%d.csv", getenv("KB_TS_DIR") ? getenv("KB_TS_DIR") : ".", s.name, v.exp);
+                if (FILE* f = fopen(fn, "w")) {
+                    fprintf(f, "wg,t_start,t_main_begin,t_main_end,t_end,hw_id,xcc_id\n");
+                    for (size_t w = 0; w < nwg; w++) fprintf(f, "%zu,%llu,%llu,%llu,%llu,%llu,%llu\n", w, hts[w * 8], hts[w * 8 + 1], hts[w * 8 + 2], hts[w * 8 + 3], hts[w * 8 + 4], hts[w * 8 + 5]);
+                    fclose(f); printf("   ts: %zu workgroups -> %s\n", nwg, fn);
+                }
+                CK(hipFree(dts));
+            }
             if (getenv("KB_TS") && v.pp && v.kern >= 2) {      // persistent kernel (library built with --experiments): per-tile stamps of one workgroup
                 unsigned long long* dts; CK(hipMalloc(&dts, 96 * 8)); CK(hipMemsetAsync(dts, 0, 96 * 8, st));
                 GemmArgs g2 = g; g2.dbg_ts = dts;
