@@ -91,8 +91,11 @@ struct moge_handle {
     hipEvent_t ev_fork = nullptr, ev_join[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
     // head streams (small batches): after the neck the decoder heads are independent and their launches do not fill the chip; heads 1, 2
     // of (sub-)batch `slot` run on head_st[slot][0 / 1] with their own scratch buffers, head 0 stays on the (sub-)batch's stream
-    hipStream_t head_st[MAX_SPLIT][2] = {};
-    hipEvent_t ev_neck[MAX_SPLIT] = {}, ev_head[MAX_SPLIT][2] = {};
+    hipStream_t head_st[MAX_SPLIT][3] = {};
+    hipEvent_t ev_neck[MAX_SPLIT] = {}, ev_head[MAX_SPLIT][3] = {};
+    // pipelined heads (round 6, HEAD_PIPE): EVERY head on its own stream, started level by level behind the neck level it reads (ev_lvl[slot][l] is recorded on the
+    // (sub-)batch's stream when neck level l is complete) - at one image the neck's and the heads' launches are half-chip grids that run side by side
+    hipEvent_t ev_lvl[MAX_SPLIT][MOGE_LEVELS] = {};
     float img_mean[3] = {0.485f, 0.456f, 0.406f}, img_std[3] = {0.229f, 0.224f, 0.225f};   // refreshed from the checkpoint buffers
     // profiler
     bool prof_on = false;
@@ -686,7 +689,7 @@ static int pack_weights(moge_handle* h, hipStream_t st) {
 struct Plan {
     size_t total = 0;
     size_t base = 0;          // byte offset of this plan inside the workspace arena (batch-split mode places two plans side by side)
-    size_t patches, x, xn, q, k, vT, attn, hidden, tapcat, cls, mlp1, mlp2, metric, feat, neck[MOGE_LEVELS], scratch[9];
+    size_t patches, x, xn, q, k, vT, attn, hidden, tapcat, cls, mlp1, mlp2, metric, feat, neck[MOGE_LEVELS], scratch[12];
     int head_sets = 1;        // scratch triples: one per decoder head when the heads run on their own streams (small batches), else 1
     int slot = 0;             // index of this (sub-)batch among the batch-split parts (selects the head streams)
     size_t ln_part, ln_mr;    // LN fold: (sum, sum of squares) per row and 32-column group; (mean, rstd) per row
@@ -753,7 +756,8 @@ static Plan make_plan(const moge_config& c, int prec, int B, int H, int W, int r
     for (int k = 0; k < 3; k++) nheads += (c.heads & HEAD_BITS[k]) ? 1 : 0;
     // (normalised residual blocks share ONE GroupNorm scratch per plan: heads then run one after the other)
     p.head_sets = (nheads > 1 && moge_tune_get("HEAD_STREAMS", 1) != 0 && B <= moge_tune_get("HEAD_STREAMS_MAX_B", 1) && !stack_has_norm(c, false)) ? nheads : 1;      // (only the shared norm-statistics scratch `gn` serialises the heads: activation-only blocks keep their streams)
-    for (int i = 0; i < 3 * p.head_sets; i++) p.scratch[i] = take(p, mx * s);
+    // (head streams: one triple more than heads - in the pipelined form triple 0 stays with the neck, which is still running when the first head starts)
+    for (int i = 0; i < 3 * (p.head_sets > 1 ? p.head_sets + 1 : 1); i++) p.scratch[i] = take(p, mx * s);
     if (stack_has_norm(c, true) || stack_has_norm(c, false)) {
         size_t gmax = 0;
         for (int l = 0; l < MOGE_LEVELS; l++)
@@ -1145,6 +1149,8 @@ static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, in
         for (int k = 0; k < c.n_taps; k++)
             if (c.taps[k] == i) {
                 // shared final LayerNorm on the tap, cls/patch split (vision_transformer.py:321-324); cls of the LAST tap only
+                // (on a side stream beside the next block's qkv GEMM and attention, which only read the residual stream: measured level at one image,
+                //  profiles/r06t_ab_TAP_STREAM_b1.log - the two cross-stream events cost what the 13 us per tap save)
                 ProfScope ps(h, st, MOGE_KC_NORM, 0, (double)BN * D * ((half_resid ? 2 : 4) + sizeof(T)));
                 if (half_resid)
                     LCHK(launch_layernorm_x16(xn, M(h, bb + "norm.weight"), M(h, bb + "norm.bias"), tapcat, k == c.n_taps - 1 ? cls : nullptr, BN, D,
@@ -1192,6 +1198,17 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     const bool l4dot = std::is_same<T, f16>::value && c.head_res_blocks[MOGE_LEVELS - 1] == 0 && c.neck_res_blocks[MOGE_LEVELS - 1] == 0 && c.dims[4] == 32 &&
                        c.dims[3] == 64 && rs_is_phase(c.neck_resamplers[3]) && rs_is_phase(c.head_resamplers[3]) &&
                        moge_tune_get("FUSE_L4", 1) != 0 && moge_tune_get("L4DOT", 1) != 0 && moge_tune_get("CONV_PP", 1) != 0;
+    // small batches: the heads on their own streams and scratch triples (same kernels: bit-identical); not under the profiler, whose events bracket
+    // launches on ONE stream.  HEAD_PIPE (default, round 6): every head on a side stream, level l of a head released by the event of neck level l;
+    // HEAD_PIPE 0 (rounds 3-5): the first head on the caller's stream, the others forked behind the whole neck
+    const bool par_heads = pl.head_sets > 1 && !h->prof_on;
+    const bool pipe = par_heads && moge_tune_get("HEAD_PIPE", 1) != 0;
+    auto neck_level_done = [&](int l) -> int {
+        if (!pipe) return 0;
+        if (!h->ev_lvl[pl.slot][l]) HIPCHK(hipEventCreateWithFlags(&h->ev_lvl[pl.slot][l], hipEventDisableTiming));
+        HIPCHK(hipEventRecord(h->ev_lvl[pl.slot][l], st));
+        return 0;
+    };
     // ---- neck (modules.py:242-254; level-0 uv concat folded into a rank-2 epilogue term, v2.py:154-160) -----------
     T* N[MOGE_LEVELS];
     for (int l = 0; l < MOGE_LEVELS; l++) N[l] = (T*)(ws + pl.neck[l]);
@@ -1208,6 +1225,7 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
         } else
         CHK(conv1x1<T>(h, feat, P<T>(h, "neck.in0.w"), M(h, "neck.input_blocks.0.bias"), N[0], BP, c0, c0, nullptr, &uv, cols, rows, st));
         CHK(res_blocks<T>(h, "neck", 0, c.neck_res_blocks[0], N[0], Sc[0], B, rows, cols, c0, st, false, nullptr, Sc[1], gn));
+        CHK(neck_level_done(0));
         for (int l = 1; l < MOGE_LEVELS; l++) {
             const int Hh = rows << l, Ww = cols << l, ci = c.dims[l - 1], co = c.dims[l];
             const int rsl = c.neck_resamplers[l - 1];
@@ -1237,14 +1255,12 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
                 CHK(conv_up2_phase<T>(h, N[l - 1], P<T>(h, S("neck.rs%d.w3p", l - 1)), A(h, S("neck.rs%d.bias4", l - 1)), N[l], B, Hh / 2, Ww / 2, ci, co, &uvl, st));
             }
             CHK(res_blocks<T>(h, "neck", l, c.neck_res_blocks[l], N[l], Sc[1], B, Hh, Ww, co, st, false, nullptr, Sc[2], gn));
+            CHK(neck_level_done(l));
         }
     }
     // ---- heads -------------------------------------------------------------------------------------------------------
     float* outs[3] = {o_points, o_normal, o_maskprob};
     const bool fuse_l4 = std::is_same<T, f16>::value && c.head_res_blocks[MOGE_LEVELS - 1] == 0 && moge_tune_get("FUSE_L4", 1) != 0;
-    // small batches: every head after the first on its own stream and scratch triple (same kernels: bit-identical); not under the profiler,
-    // whose events bracket launches on ONE stream
-    const bool par_heads = pl.head_sets > 1 && !h->prof_on;
     hipStream_t st_main = st;
     int forked = 0;
     // Whatever way this function is left (a failed launch in the middle of a head included), the caller's stream must be ordered behind every
@@ -1253,14 +1269,14 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
     struct HeadJoin {
         moge_handle* h; int slot; hipStream_t main; int* forked;
         ~HeadJoin() {
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < 3; i++)
                 if (*forked & (1 << i)) {
                     if (hipEventRecord(h->ev_head[slot][i], h->head_st[slot][i]) == hipSuccess) hipStreamWaitEvent(main, h->ev_head[slot][i], 0);
                 }
             *forked = 0;
         }
     } head_join{h, pl.slot, st_main, &forked};
-    if (par_heads) {
+    if (par_heads && !pipe) {
         if (!h->ev_neck[pl.slot]) HIPCHK(hipEventCreateWithFlags(&h->ev_neck[pl.slot], hipEventDisableTiming));
         HIPCHK(hipEventRecord(h->ev_neck[pl.slot], st_main));
     }
@@ -1269,16 +1285,17 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
         const std::string name = HEAD_NAMES[k];
         int head_idx = 0;                  // this head's group in the neck's fused-output-conv table: its position among the model's heads
         for (int k2 = 0; k2 < k; k2++) head_idx += (c.heads & HEAD_BITS[k2]) ? 1 : 0;
-        if (par_heads && head_idx > 0) {
-            hipStream_t& hs = h->head_st[pl.slot][head_idx - 1];
+        if (par_heads && (pipe || head_idx > 0)) {
+            const int sidx = pipe ? head_idx : head_idx - 1;           // side stream / join event of this head
+            hipStream_t& hs = h->head_st[pl.slot][sidx];
             if (!hs) {
                 HIPCHK(hipStreamCreateWithFlags(&hs, hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&h->ev_head[pl.slot][head_idx - 1], hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&h->ev_head[pl.slot][sidx], hipEventDisableTiming));
             }
-            HIPCHK(hipStreamWaitEvent(hs, h->ev_neck[pl.slot], 0));
+            HIPCHK(hipStreamWaitEvent(hs, pipe ? h->ev_lvl[pl.slot][0] : h->ev_neck[pl.slot], 0));
             st = hs;
-            for (int i = 0; i < 3; i++) Sc[i] = (T*)(ws + pl.scratch[3 * head_idx + i]);
-            forked |= 1 << (head_idx - 1);
+            for (int i = 0; i < 3; i++) Sc[i] = (T*)(ws + pl.scratch[3 * (pipe ? head_idx + 1 : head_idx) + i]);
+            forked |= 1 << sidx;
         } else {
             st = st_main;
             for (int i = 0; i < 3; i++) Sc[i] = (T*)(ws + pl.scratch[i]);
@@ -1292,6 +1309,7 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
         for (int l = 1; l < MOGE_LEVELS; l++) {
             const int Hh = rows << l, Ww = cols << l, ci = c.dims[l - 1], co = c.dims[l];
             const int a = (cur + 1) % 3, b2 = (cur + 2) % 3;
+            if (pipe) HIPCHK(hipStreamWaitEvent(st, h->ev_lvl[pl.slot][l], 0));       // this level reads neck level l (side input / level-4 dot products)
             const int rsl = c.head_resamplers[l - 1];
             int nxt;
             bool in_fused = false;
@@ -1365,6 +1383,7 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
         }
     }
     st = st_main;
+    for (int i = 0; i < 3; i++) Sc[i] = (T*)(ws + pl.scratch[i]);
     // ---- scale head (modules.py:184-192, v2.py:167,182) ---------------------------------------------------------
     // Three tiny launches on the caller's stream BEHIND its head: with the other heads on their own streams (small batches) the caller's stream finishes its
     // head first and would idle until the join - in front of the neck (rounds 1-5) the same 15 us sat on the batch-1 critical path.
@@ -1375,7 +1394,7 @@ static int forward_impl(moge_handle* h, const void* image, int img_dtype, const 
         LCHK(launch_mlp_layer(m1, M(h, "scale_head.2.weight"), M(h, "scale_head.2.bias"), m2, B, c.scale_hidden, c.scale_hidden, 1, st));
         LCHK(launch_mlp_layer(m2, M(h, "scale_head.4.weight"), M(h, "scale_head.4.bias"), o_metric, B, c.scale_hidden, 1, 2, st));
     }
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 3; i++)
         if (forked & (1 << i)) {
             HIPCHK(hipEventRecord(h->ev_head[pl.slot][i], h->head_st[pl.slot][i]));
             HIPCHK(hipStreamWaitEvent(st_main, h->ev_head[pl.slot][i], 0));
@@ -1810,7 +1829,8 @@ void moge_destroy(moge_handle* h) {
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     for (int i = 0; i < moge_handle::MAX_SPLIT; i++) {
         if (h->ev_neck[i]) hipEventDestroy(h->ev_neck[i]);
-        for (int k = 0; k < 2; k++) { if (h->head_st[i][k]) hipStreamDestroy(h->head_st[i][k]); if (h->ev_head[i][k]) hipEventDestroy(h->ev_head[i][k]); }
+        for (int k = 0; k < 3; k++) { if (h->head_st[i][k]) hipStreamDestroy(h->head_st[i][k]); if (h->ev_head[i][k]) hipEventDestroy(h->ev_head[i][k]); }
+        for (int l = 0; l < MOGE_LEVELS; l++) if (h->ev_lvl[i][l]) hipEventDestroy(h->ev_lvl[i][l]);
     }
     for (auto& r : h->prof_pending) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (auto e : h->ev_pool) hipEventDestroy(e);

@@ -351,24 +351,27 @@ def test_head_streams_are_bit_identical(MoGeModel, tmp_path_factory):
                 L.tune("HEAD_STREAMS", 0)
                 ref = model.infer(x, num_tokens=108)
                 L.tune("HEAD_STREAMS", 1)
-                for _ in range(2):                      # twice: the second call reuses streams, events and scratch of the first
-                    out = model.infer(x, num_tokens=108)
-                    for k in ref:
-                        _same(out[k], ref[k], f"{k}: head streams != one stream (B={B}, half={half})")
+                for pipe in (0, 1, 1):                  # HEAD_PIPE 1 (default): every head on a side stream, released level by level behind the neck; 0: forked behind the whole neck.
+                    L.tune("HEAD_PIPE", pipe)           # (twice: the second call reuses streams, events and scratch of the first)
+                    for _ in range(2):
+                        out = model.infer(x, num_tokens=108)
+                        for k in ref:
+                            _same(out[k], ref[k], f"{k}: head streams != one stream (B={B}, half={half}, HEAD_PIPE={pipe})")
         # a subset of the outputs (forward with only normal + mask requested: head 0 is skipped, the first REQUESTED head is not head index 0)
         model.float()
         x = torch.rand(2, 3, 84, 112, generator=torch.Generator().manual_seed(5)).cuda()
         full = model.forward(x, 108)
-        for hs in (0, 1):
-            L.tune("HEAD_STREAMS", hs)
+        for hs, pipe in ((0, 1), (1, 0), (1, 1)):
+            L.tune("HEAD_STREAMS", hs); L.tune("HEAD_PIPE", pipe)
             o = L.Outputs()
             nrm = torch.empty_like(full["normal"]); mp = torch.empty_like(full["mask"])
             o.normal, o.mask_prob = nrm.data_ptr(), mp.data_ptr()
             L.check(L.lib.moge_forward(model._handle, x.data_ptr(), 0, 2, 84, 112, 9, 12, C.byref(o), L.stream_ptr()))
             torch.cuda.synchronize()
-            assert torch.equal(nrm, full["normal"]) and torch.equal(mp, full["mask"]), f"subset of outputs, HEAD_STREAMS={hs}"
+            assert torch.equal(nrm, full["normal"]) and torch.equal(mp, full["mask"]), f"subset of outputs, HEAD_STREAMS={hs}, HEAD_PIPE={pipe}"
     finally:
         L.tune("HEAD_STREAMS", 1)
+        L.tune("HEAD_PIPE", 1)
         L.tune("HEAD_STREAMS_MAX_B", 1)
         model.float()
 
