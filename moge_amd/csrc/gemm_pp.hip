@@ -1182,10 +1182,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
             // counters untouched; some results are first USED later, and its own wait there would be vmcnt(0) behind the DMA), then
             // request the next tile's first pieces - UNCONDITIONALLY (after the last tile: this tile's own pieces again, never read): a branch
             // here would merge into a conservative wait as well
+            PP_STAMP(6);
             setup(more ? li : li - wgs_x);
             if constexpr (EpkBase<EPK>::K != EPK_RESID && EpkBase<EPK>::K != EPK_RESID16) __builtin_amdgcn_s_waitcnt(0x0F70);      // (RESID: the last row loads were waited for by the add in front)
             prefetch();
             asm volatile("" ::: "memory");
+            PP_STAMP(7);
         };
         if (abl & 4) {                                       // no epilogue: the accumulators stay alive, the next tile's prefetch is still requested
 #pragma unroll

@@ -294,8 +294,8 @@ static int bench_gemm(const char* filter, int iters) {
                 for (int w = 0; w < 2; w++)
                     for (int t = 0; t < 6 && hts[w * 48 + t * 8 + 4]; t++) {
                         const unsigned long long* q = hts + w * 48 + t * 8;
-                        printf("   ts wave %d tile %d: head %5.2f  mainloop %6.2f  epi-loads %5.2f  epilogue %5.2f  store-drain %5.2f   (tile start +%.2f)  [x100 clocks]\n", w * 4, t,
-                               (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01, (q[5] - q[4]) * 0.01, (q[0] - hts[w * 48]) * 0.01);      // "us" = 100 shader clocks
+                        printf("   ts wave %d tile %d: head %5.2f  mainloop %6.2f  epi-loads %5.2f  epilogue %5.2f (before the prefetch %5.2f, prefetch %5.2f, behind it %5.2f)  store-drain %5.2f   (tile start +%.2f)  [x100 clocks]\n", w * 4, t,
+                               (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01, (q[6] - q[3]) * 0.01, (q[7] - q[6]) * 0.01, (q[4] - q[7]) * 0.01, (q[5] - q[4]) * 0.01, (q[0] - hts[w * 48]) * 0.01);      // "us" = 100 shader clocks
                     }
                 CK(hipFree(dts));
             }
