@@ -792,6 +792,7 @@ __device__ __forceinline__ void pp_epi_run(const GemmArgs& g, f32x4 (&acc)[8][4]
 // 64-127 of the wave ("hi") are read from LDS INSIDE the segment, into the registers of the "lo" fragments as those die, so the register
 // count does not change.  The DMA schedule is then tied to the global intervals (both groups issue at the start of an even interval - group 0
 // is in its read segment, group 1 in its MFMA segment - and wait at the interval ends), see the loop.
+constexpr int PP_WX_DEFAULT = 0;      // (measured slower in the production step: see launch_pp_any)
 template <int EPK, int SROWS, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
     constexpr bool MRG = MODE == 1;
@@ -799,7 +800,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
     // MODE 3 (round 4): BOTH halves of A(t+2) are requested in the FIRST read segment of K-tile t (4 pieces per wave), W(t+2) alone in the second
     // (4 pieces) - instead of 2 + 6: the second read segment (8 fragment reads + 6 DMA issues) was the one that overran the partner's 32 MFMAs.
     // Queue per K-tile: [L_a(t): A(t+2)] [L_b(t): W(t+2)], wait at the end of L_b(t): vmcnt(8) = everything up to W(t+1) has landed.
-    constexpr bool ALO_A = MODE == 3 || MODE == 5;
+    constexpr bool ALO_A = MODE == 3 || MODE == 5 || MODE == 7;
+    // MODE 7 (round 6) = MODE 3 with the W stream CONTINUOUS across the tile boundary: the last two K-tiles of a tile, whose second read segments have no W(t + 2) of
+    // their own to request, request the NEXT tile's W(0) and W(1) there (into the W slots that are dead by then, exactly the steady-state rule) - 8 of the 12 DMA
+    // pieces per wave leave the epilogue's prefetch, where 256 workgroups issue them together with the store burst (230-700 clocks per piece against 13-20 in the
+    // main loop: EXPERIMENTS R6.3c).  Needs an even number of K-tiles (slot parity); the next tile's descriptor is set up at the head of K-tile nkt - 2.
+    constexpr bool WX = MODE == 7;
     // MODE 6: "6 + 2" - as MODE 3, and the second half of W(t+1) is requested at the head of L_a(t) instead of in L_b(t-1):
     // [L_a(t): W(t+1) rows 128-255, A(t+2)] [L_b(t): W(t+2) rows 0-127]; wait at the end of L_b(t): vmcnt(6)
     constexpr bool W_SPLIT = MODE == 6;
@@ -894,6 +900,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
         issue_w(0);
         issue_w(1);
     };
+    auto prefetch_a = [&]() { issue_a(0, 0, 0); issue_a(0, 0, 1); };      // MODE 7: W(0), W(1) of the next tile were requested by the last two K-tiles
 
     const int sx = (l15 >> 1) & 7;
     const int a_off = (wm * 128 + l15) * 128 + ((g4 ^ sx) << 4);
@@ -927,6 +934,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
     bool first = true;
     for (;;) {
         const int m0 = m0n, n0 = n0n;
+        const int li_next = li + wgs_x;
+        const bool more = li_next < cnt;
         PP_STAMP(0);
         // (no zero fill in the product form: the first K-tile is peeled and its first 64 MFMAs take the constant 0 as their C operand - 128 v_mov per
         //  wave and tile less, with the matrix pipe idle while they would run)
@@ -1068,6 +1077,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
             const char* sl = smem + sa * 32768;
             const char* slw = smem + 98304 + (t & 1) * 32768;
             const int sa2 = sa == 0 ? 2 : sa - 1;
+            if constexpr (WX) {
+                // this tile's last DMA request was W(nkt - 1), in K-tile nkt - 3: its descriptor is dead, the next tile's replaces it (after the last tile: this tile again, never read)
+                if (t == nkt - 2) setup(more ? li_next : li);
+            }
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 if constexpr (DMA_FIRST) {
@@ -1109,6 +1122,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
                         if (t + 3 < nkt) { issue_w(t + 2); issue_a1(t + 3, sa, 1); asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); }
                         else if (t + 2 < nkt) { issue_w(t + 2); asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
                         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    } else
+                    if constexpr (WX) {
+                        // queue at the end of this segment: [A(t+2)] W(t+2) while t + 2 < nkt; then W_next(0) (K-tile nkt - 2) and W_next(0) W_next(1) (K-tile nkt - 1):
+                        // everything of THIS tile has landed, the next tile's pieces stay in flight
+                        if (t + 2 < nkt) { issue_w(t + 2); asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
+                        else if (t + 2 == nkt) { issue_w(0); asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
+                        else { issue_w(1); asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
                     } else
                     if constexpr (ALO_A) {
                         if (t + 2 < nkt) { if constexpr (!DMA_FIRST) issue_w(t + 2); asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
@@ -1174,8 +1194,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        li += wgs_x;
-        const bool more = li < cnt;
+        li = li_next;
         PP_STAMP(3);
         auto mid = [&]() {
             // every load of the epilogue has been issued long ago: tell the compiler they are complete (a real S_WAITCNT it accounts for: vmcnt(0), other
@@ -1183,9 +1202,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128p_kernel(const GemmArgs g) {
             // request the next tile's first pieces - UNCONDITIONALLY (after the last tile: this tile's own pieces again, never read): a branch
             // here would merge into a conservative wait as well
             PP_STAMP(6);
-            setup(more ? li : li - wgs_x);
+            if constexpr (!WX) setup(more ? li : li - wgs_x);
             if constexpr (EpkBase<EPK>::K != EPK_RESID && EpkBase<EPK>::K != EPK_RESID16) __builtin_amdgcn_s_waitcnt(0x0F70);      // (RESID: the last row loads were waited for by the add in front)
-            prefetch();
+            if constexpr (WX) prefetch_a(); else prefetch();
             asm volatile("" ::: "memory");
             PP_STAMP(7);
         };
@@ -1336,6 +1355,11 @@ static int launch_pp_any(const GemmArgs& g, hipStream_t st) {
     if (kern < 0) kern = 2;
     // The product's persistent kernel is MODE 3 (round 4): the DMA pieces of a K-tile split 4 + 4 over the wave's two read segments (A(t+2) whole
     // in the first, W(t+2) in the second).  Same MFMAs in the same order as every other schedule: bit-identical results.
+#ifdef MOGE_EXPERIMENTS
+    // MODE 7 (round 6, PP_WX; --experiments builds): the W stream continuous across the tile boundary; needs an even number of K-tiles >= 4.  Bit-identical; kbench,
+    // sustained 1500-launch samples: qkv / fc1 / proj +1.2-1.4 %, fc2 level - and 247.1 -> 246.8 img/s in the production two-stream step (EXPERIMENTS R6.3d)
+    if (kern == 2 && pp_persistent_ok(g) && moge_tune_get("PP_WX", PP_WX_DEFAULT) != 0 && ((g.K >> 6) & 1) == 0 && g.K >= 256) return launch_pp128p<EPK, 64, 7>(g, st);
+#endif
     if (kern == 2 && pp_persistent_ok(g)) return launch_pp128p<EPK, 64, 3>(g, st);
 #ifdef MOGE_EXPERIMENTS
     // the other DMA schedules and loop shapes that were measured (tools/kbench A-B builds only; profiles/r04n ... r04r, r03r, r03u):

@@ -173,11 +173,11 @@ static int bench_gemm(const char* filter, int iters) {
     };
     // kern: PP_KERN (0 = gemm_pp128m16_kernel, 2 = gemm_pp128p_kernel (persistent), 1 = gemm_pp4w16_kernel (--experiments));  exp: PP_EXP (library built with --experiments only: 1/2/3 = gemm_pp128
     // 32x32x16 form with A3 = 1/2/0, 4 = gemm_pp4w 32x32x16, 5 = 64-byte-row 256x256, 6 = 64-byte-row 256x128 two workgroups per CU)
-    struct Variant { const char* name; int pp, glds, dbg, kern, exp; int small_ns = 3, small_blocks = 512, stagger = 0; };
+    struct Variant { const char* name; int pp, glds, dbg, kern, exp; int small_ns = 3, small_blocks = 512, stagger = 0, wx = 0; };      // wx: PP_WX (MODE 7: W stream continuous across the tile boundary)
     auto apply = [](const Variant& v) {
         moge_tune_set("GEMM_PP", v.pp); moge_tune_set("PP_MIN_TILES", 0); moge_tune_set("GLDS_VARIANT", v.glds); moge_tune_set("PP_DBG", v.dbg);
         moge_tune_set("PP_KERN", v.kern); moge_tune_set("PP_EXP", v.exp);
-        moge_tune_set("GLDS_SMALL_NS", v.small_ns); moge_tune_set("GLDS_SMALL_BLOCKS", v.small_blocks); moge_tune_set("PP_STAGGER", v.stagger);
+        moge_tune_set("GLDS_SMALL_NS", v.small_ns); moge_tune_set("GLDS_SMALL_BLOCKS", v.small_blocks); moge_tune_set("PP_STAGGER", v.stagger); moge_tune_set("PP_WX", v.wx);
     };
     std::vector<Variant> variants = {{"glds2-m16", 0, 2, 0, 0, 0}, {"pp128-m16", 1, 2, 0, 0, 0}, {"pp128p", 1, 2, 0, 2, 0}};
     if (getenv("KB_EXP")) variants = {{"pp128-m16", 1, 2, 0, 0, 0}, {"pp4w-16", 1, 2, 0, 1, 0}, {"x:pp128-a3", 1, 2, 0, 0, 1}, {"x:pp128-a3c", 1, 2, 0, 0, 2}, {"x:pp128-2buf", 1, 2, 0, 0, 3},
@@ -190,6 +190,7 @@ static int bench_gemm(const char* filter, int iters) {
     if (getenv("KB_STAG")) variants = {{"pp128p", 1, 2, 0, 2, 0}, {"stagger 2", 1, 2, 0, 2, 0, 3, 512, 2}, {"stagger 3", 1, 2, 0, 2, 0, 3, 512, 3}, {"stagger 4", 1, 2, 0, 2, 0, 3, 512, 4},
                                        {"stagger 8", 1, 2, 0, 2, 0, 3, 512, 8}, {"stagger 16", 1, 2, 0, 2, 0, 3, 512, 16}, {"stagger 32", 1, 2, 0, 2, 0, 3, 512, 32}};      // start-phase groups of the persistent GEMM (round 5)
     if (getenv("KB_P")) variants = {{"pp128p", 1, 2, 0, 2, 0}};      // the product kernel alone (A-B of two library builds: tools/gpu_call.sh kb_ab)
+    if (getenv("KB_WX")) variants = {{"pp128p wx0", 1, 2, 0, 2, 0, 3, 512, 0, 0}, {"pp128p wx1", 1, 2, 0, 2, 0, 3, 512, 0, 1}};      // round 6: MODE 3 against MODE 7
     if (getenv("KB_PPX")) variants = {{"pp128p", 1, 2, 0, 2, 0}, {"x:pp128p-mrg", 1, 2, 0, 3, 0}, {"x:pp128p-wm", 1, 2, 0, 4, 0}};      // --experiments builds
     if (getenv("KB_DBG")) for (Variant& v : variants) v.dbg = atoi(getenv("KB_DBG"));      // tile columns per group of the persistent walk (PP_DBG), every variant
     int fails = 0;
