@@ -403,8 +403,10 @@ int launch_mlp_layer(const float* in, const float* W, const float* bias, float* 
 // recovery
 // ------------------------------------------------------------------------------------------------------------
 // REC_THREADS threads x REC_PTS sample points = the 64 x 64 grid.  Batch-1 latency: the solver is a chain of ~35 block reductions over fp64 divisions; more
-// waves shorten every link (4 waves: 168 us; 16 waves: 82-91 us with 300 B per lane of scratch under its 128-register budget; 8 waves, REC_THREADS = 512, no
-// scratch: 89-90 us - level, the 16-wave form is the one the golden suite ran with)
+// waves shorten every link (round 3: 4 waves 168 us; 16 waves 82-91 us with 300 B per lane of scratch under its 128-register budget; 8 waves, no scratch: 89-90 us -
+// level then).  Round 6, with the residuals / Jacobian column of the finite-difference pass kept per lane for the Householder pass: 16 waves 67.7 us (those arrays
+// live in scratch under 128 registers), **8 waves 30.8 us** (256 registers, no scratch), 4 waves 41.1 us (profiles/r06ae_recover_threads.log) - the default is 512
+// threads from round 6 on; the summation tree of the block reductions differs from the 16-wave form's in the last fp64 bits only (same gates, same fixtures).
 
 template <int NV, int REC_THREADS>
 __device__ __forceinline__ void block_sum(double* v, double* sh) {
@@ -720,7 +722,10 @@ int launch_recover(const float* points, const float* mask_prob, const uint8_t* m
     const float ustep = W > 1 ? (u1 - u0) / (float)(W - 1) : 0.f, vstep = H > 1 ? (v1 - v0) / (float)(H - 1) : 0.f;
     const float fov_c = (float)(a / sqrt(1 + a * a));
     const float diag = (float)sqrt(1 + a * a);
-    if (moge_tune_get("REC_THREADS", 1024) == 512)
+    if (moge_tune_get("REC_THREADS", 512) == 256)
+        hipLaunchKernelGGL(recover_kernel<256>, dim3(B), dim3(256), 0, st, points, mask_prob, mask_u8, fov_deg, focal_in, H, W, u0, u1, ustep, v0, v1,
+                           vstep, fov_c, diag, (float)a, diag, mask_thr, focal, shift, intrinsics, status);
+    else if (moge_tune_get("REC_THREADS", 512) == 512)
         hipLaunchKernelGGL(recover_kernel<512>, dim3(B), dim3(512), 0, st, points, mask_prob, mask_u8, fov_deg, focal_in, H, W, u0, u1, ustep, v0, v1,
                            vstep, fov_c, diag, (float)a, diag, mask_thr, focal, shift, intrinsics, status);
     else
