@@ -230,13 +230,15 @@ int launch_cls_row(float* x, const float* cls, const float* pos, int B, int Ntok
 //   tap  : (get_intermediate_layers, vision_transformer.py:321-324) token 0 -> cls_out[b*D + col] (fp32, optional),
 //          token t>0 -> out[(b*Np + t-1)*ldo + coloff + col]  (the K-concatenated output-projection operand)
 // --------------------------------------------------------------------------------------------
-template <typename T, typename TX = float>      // TX: element type of the residual stream (float; f16 for `.half()` models, whose stream is fp16)
+// LN_RPW: consecutive rows per wave - 4 for large row counts (weights / bias loaded once per 4 rows), 1 when there are few rows (one image: 3601 rows = 226 workgroups of
+// 16 rows left most of the chip idle and every wave walked four dependent load -> reduce -> store round trips; 901 workgroups of 4 rows: 13.2 -> see EXPERIMENTS R6.10)
+constexpr long LN_FEW_ROWS = 16384;      // up to ~4 images of 3601 tokens: one row per wave
+template <typename T, typename TX = float, int LN_RPW = 4>      // TX: element type of the residual stream (float; f16 for `.half()` models, whose stream is fp16)
 __global__ __launch_bounds__(256) void layernorm_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                         T* __restrict__ out, float* __restrict__ cls_out, long rowsN, int D, int ldo,
                                                         int coloff, int tap_mode, int Ntok) {
     // One wave per row, LN_RPW consecutive rows per wave: a lane owns columns i*256 + 4*lane .. +3 (16-byte loads: a wave
     // instruction moves 1 KiB of the fp32 row, 8-byte stores of the storage type), weight / bias stay in registers.
-    constexpr int LN_RPW = 4;
     const int lane = threadIdx.x & 63;
     const long row0 = (blockIdx.x * 4L + (threadIdx.x >> 6)) * LN_RPW;
     if (row0 >= rowsN) return;
@@ -424,6 +426,10 @@ int launch_layernorm(const float* x, const float* w, const float* b, void* out, 
         return (int)hipGetLastError();
     }
 #endif
+    if (rowsN <= LN_FEW_ROWS) {
+        hipLaunchKernelGGL((layernorm_kernel<T, float, 1>), dim3((unsigned)((rowsN + 3) / 4)), dim3(256), 0, st, x, w, b, (T*)out, cls_out, rowsN, D, ldo, coloff, tap_mode, Ntok);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(layernorm_kernel<T>, dim3((unsigned)((rowsN + 15) / 16)), dim3(256), 0, st, x, w, b, (T*)out, cls_out, rowsN, D, ldo, coloff,
                        tap_mode, Ntok);
     return (int)hipGetLastError();
@@ -435,6 +441,10 @@ template int launch_layernorm<float>(const float*, const float*, const float*, v
 int launch_layernorm_x16(const void* x16, const float* w, const float* b, void* out, float* cls_out, long rowsN, int D, int ldo, int coloff,
                          int tap_mode, int Ntok, hipStream_t st) {
     if (D % 4 != 0 || D > 1024 || (ldo & 3) || (coloff & 3)) return -1;
+    if (rowsN <= LN_FEW_ROWS) {
+        hipLaunchKernelGGL((layernorm_kernel<f16, f16, 1>), dim3((unsigned)((rowsN + 3) / 4)), dim3(256), 0, st, (const f16*)x16, w, b, (f16*)out, cls_out, rowsN, D, ldo, coloff, tap_mode, Ntok);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL((layernorm_kernel<f16, f16>), dim3((unsigned)((rowsN + 15) / 16)), dim3(256), 0, st, (const f16*)x16, w, b, (f16*)out, cls_out, rowsN, D, ldo,
                        coloff, tap_mode, Ntok);
     return (int)hipGetLastError();
