@@ -720,12 +720,16 @@ static int launch_conv_epi(const GemmArgs& g, hipStream_t st) {
 template <int NJ>      // Cout / 16
 __global__ __launch_bounds__(256) void ct3_border_kernel(const f16* __restrict__ in, const f16* __restrict__ dw, f16* __restrict__ out, int B, int H, int W, int Cin) {
     constexpr int Cout = NJ * 16;
+    // 16 border pixels per WORKGROUP: its four waves split the K-steps (slot, 32-channel chunk) round-robin and wave 0 adds the partial sums in wave order (fixed:
+    // deterministic, the same for every batch size).  One image has 4 W + 4 H - 4 = 476 such pixels at the 120^2 level: with 16 pixels per WAVE over the whole K
+    // (first form) a launch was 24 workgroups walking a chain of 16 dependent load -> MFMA steps, 20-29 us on the one-image critical path.
+    __shared__ f32x4 red[3][NJ][64];
     const int cls = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g4 = lane >> 4;
     const int n_c = cls < 4 ? W - 1 : (cls < 8 ? H - 1 : 1);
     const long Mc = (long)B * n_c;
-    const long m0 = (long)blockIdx.x * 64 + wave * 16;
+    const long m0 = (long)blockIdx.x * 16;
     if (m0 >= Mc) return;
     long m = m0 + l15;
     const bool valid = m < Mc;
@@ -749,18 +753,32 @@ __global__ __launch_bounds__(256) void ct3_border_kernel(const f16* __restrict__
     for (int j = 0; j < NJ; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const f16* wbase = dw + ((size_t)cls * Cout + l15) * (2 * Cin) + 8 * g4;
     const int nslot = cls < 8 ? 2 : 1;
-    for (int slot = 0; slot < nslot; slot++) {
+    const int nkc = Cin >> 5, nsteps = nslot * nkc;
+    for (int stp = wave; stp < nsteps; stp += 4) {
+        const int slot = stp >= nkc ? 1 : 0, kc = (stp - slot * nkc) << 5;
         const f16* pp = in + (((size_t)b * H + (slot ? cy1 : cy0)) * W + (slot ? cx1 : cx0)) * Cin + 8 * g4;
         const f16* wp = wbase + slot * Cin;
-        for (int kc = 0; kc < Cin; kc += 32) {
-            const u32x4 pf = *reinterpret_cast<const u32x4*>(pp + kc);
+        const u32x4 pf = *reinterpret_cast<const u32x4*>(pp + kc);
 #pragma unroll
-            for (int j = 0; j < NJ; j++) {
-                const u32x4 wf = *reinterpret_cast<const u32x4*>(wp + (size_t)j * 16 * (2 * Cin) + kc);
-                mma16<f16>(acc[j], wf, pf);
-            }
+        for (int j = 0; j < NJ; j++) {
+            const u32x4 wf = *reinterpret_cast<const u32x4*>(wp + (size_t)j * 16 * (2 * Cin) + kc);
+            mma16<f16>(acc[j], wf, pf);
         }
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) red[wave - 1][j][lane] = acc[j];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; w++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const f32x4 p = red[w][j][lane];
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[j][e] += p[e];
+        }
     if (!valid) return;
     f16* op = out + (((size_t)b * 2 * H + Y) * (2 * W) + X) * Cout + 4 * g4;
 #pragma unroll
@@ -774,7 +792,7 @@ __global__ __launch_bounds__(256) void ct3_border_kernel(const f16* __restrict__
 int launch_ct3_border(const void* in, const void* dw, void* out, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
     if ((Cin & 31) || (Cout != 128 && Cout != 64) || H < 1 || W < 1) return -1;
     const long mmax = (long)B * ((W > H ? W : H) - 1 > 1 ? (W > H ? W : H) - 1 : 1);
-    const dim3 grid((unsigned)((mmax + 63) / 64), 12);
+    const dim3 grid((unsigned)((mmax + 15) / 16), 12);
     if (Cout == 128) hipLaunchKernelGGL(ct3_border_kernel<8>, grid, dim3(256), 0, st, (const f16*)in, (const f16*)dw, (f16*)out, B, H, W, Cin);
     else hipLaunchKernelGGL(ct3_border_kernel<4>, grid, dim3(256), 0, st, (const f16*)in, (const f16*)dw, (f16*)out, B, H, W, Cin);
     return (int)hipGetLastError();
