@@ -378,7 +378,7 @@ __device__ __forceinline__ bool attn_pp16mq_body(const f16* __restrict__ q, cons
                                                  int Ntok, int nh, int bh, int q_base, char* smem, int tb_in = 0, int te_in = 0, AttnAcc<QB>* acc = nullptr) {
     constexpr int NW = 4, NPW = 4;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & (NW - 1);      // (attn_pp16ks_kernel: eight waves = two groups of four, each on its own ring and key range)
     const int l15 = lane & 15, g4 = lane >> 4;
     const int b = bh / nh, head = bh - b * nh;
     const int q0 = q_base + wave * (16 * QB);
@@ -679,6 +679,75 @@ __global__ __launch_bounds__(256, QB > 2 ? 2 : 3) void attn_pp16mq_kernel(const 
     attn_pp16mq_body<QB>(q, k, v, out, Ntok, nh, bh, q_base, smem);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// attn_pp16ks_kernel<QB> (round 6, batch-1 latency; VERDICT r05 item 4 "split-KV attention for sub-round grids"): the key range of a query block split
+// INSIDE the workgroup.  When the 64 * QB-query blocks of a launch are no more than the chip has CUs (one image of N = 3601 tokens, 16 heads: 240
+// blocks of 256 queries), the plain grid leaves every SIMD with one or two waves walking all 57 key tiles - a latency chain.  Here a block is an
+// EIGHT-wave workgroup: waves 0-3 run attn_pp16mq's body over the key tiles [0, ceil(ntiles / 2)) on ring 0, waves 4-7 the same queries over the rest on ring 1
+// (same barriers: the shorter half adds one), so every SIMD holds two waves and the chain is half as long; then the second group leaves its unnormalised state
+// (O, l relative to its running max m) in LDS - the rings are dead by then - and the first group combines in a FIXED order, O = O_0 2^(m_0 - m*) + O_1 2^(m_1 - m*),
+// l likewise, normalises and stores.  No global workspace, no atomics, no second launch (the stream-K form of tools/experiments/ paid 7 us for those);
+// deterministic run to run.  The result differs from the unsplit kernel's in the last fp16 bit (the same fp32 terms summed in another order), so a single
+// image is no longer bit-identical to the same image inside a large batch in the fp16 modes (ATTN_KS = 0 restores that; the fp32 parity mode runs attention.hip
+// and is untouched).  Taken by launch_attn_pp16 for grids of at most one workgroup per CU and at least AP_KS_MIN_TILES key tiles.
+constexpr int AP_KS_MIN_TILES = 8;
+template <int QB>
+__global__ __launch_bounds__(512, 1) void attn_pp16ks_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
+                                                            f16* __restrict__ out, int Ntok, int nh, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 rings of 3 * AP_STAGE; afterwards the exchange buffer (QB * 18 KiB)
+    int bh = blockIdx.y, qblk = blockIdx.x;
+    if (((gridDim.y & 7) == 0) && (xcd_remap & 1)) {                 // a head's query blocks on ONE XCD (see attn_pp16mq_kernel)
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int x = lin & 7, s = lin >> 3;
+        const int hs = s / (int)gridDim.x;
+        bh = x + 8 * hs;
+        qblk = s - hs * (int)gridDim.x;
+    }
+    const int q_base = qblk * (64 * QB);
+    const int tid = threadIdx.x, lane = tid & 63, t4 = tid & 255;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave8 >> 2, wave = wave8 & 3;
+    const int ntiles = (Ntok + 63) >> 6, tmid = (ntiles + 1) >> 1;
+    AttnAcc<QB> a;
+    const bool active = attn_pp16mq_body<QB, true>(q, k, v, out, Ntok, nh, bh, q_base, smem + grp * (3 * AP_STAGE), grp ? tmid : 0, grp ? ntiles : tmid, &a);
+    if (grp && (ntiles & 1)) __builtin_amdgcn_s_barrier();           // one barrier per tile in the body: the second group has one tile fewer when ntiles is odd
+    __syncthreads();                                                 // every wave is done with both rings
+    f32x4* ex_o = reinterpret_cast<f32x4*>(smem);                    // [db * QB + qb][lane of the group] fragment-linear: conflict-free 16-byte accesses
+    f32x2* ex_ml = reinterpret_cast<f32x2*>(smem + (size_t)4 * QB * 256 * 16);
+    if (grp && active) {
+#pragma unroll
+        for (int db = 0; db < 4; db++)
+#pragma unroll
+            for (int qb = 0; qb < QB; qb++) ex_o[(db * QB + qb) * 256 + t4] = a.o[db][qb];
+#pragma unroll
+        for (int qb = 0; qb < QB; qb++) ex_ml[qb * 256 + t4] = f32x2{a.m[qb], a.l[qb]};
+    }
+    __syncthreads();
+    if (grp || !active) return;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int b = bh / nh, head = bh - b * nh;
+    const int q0 = q_base + wave * (16 * QB);
+#pragma unroll
+    for (int qb = 0; qb < QB; qb++) {
+        const f32x2 ml = ex_ml[qb * 256 + t4];
+        const float mstar = fmaxf(a.m[qb], ml[0]);
+        const float w0 = __builtin_amdgcn_exp2f(a.m[qb] - mstar), w1 = __builtin_amdgcn_exp2f(ml[0] - mstar);
+        const float l = fmaf(w1, ml[1], w0 * a.l[qb]);
+        const float inv = 1.f / l;
+        const int qrow = q0 + qb * 16 + l15;
+#pragma unroll
+        for (int db = 0; db < 4; db++) {
+            const f32x4 o1 = ex_o[(db * QB + qb) * 256 + t4];
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = fmaf(w1, o1[r], w0 * a.o[db][qb][r]);
+            if (qrow < Ntok) {
+                f16* op = out + ((size_t)b * Ntok + qrow) * ((size_t)nh * 64) + head * 64;
+                store4(op + 16 * db + 4 * g4, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+            }
+        }
+    }
+}
+
 #ifdef MOGE_EXPERIMENTS
 #include "../../tools/experiments/attention_pp16sk_exp.inc"    // attn_pp16sk_kernel: attn_pp16mq's body over a stream-K partition of (query block, key tile) units (round 6; correct, 5-8 us SLOWER at one image)
 #else
@@ -787,6 +856,25 @@ static int launch_attn_pp16(const void* q, const void* k, const void* v, void* o
             return (int)hipGetLastError();
         }
 #endif
+        // attn_pp16ks_kernel: grids of at most ONE 4-wave workgroup per CU run as 8-wave workgroups with the key range split inside the workgroup
+        // (two waves per SIMD, half the serial tiles; see the kernel).  32-query blocks while they fit the chip (more CUs busy), else 64-query blocks
+        // (N = 3601, 16 heads, one image: 464 > 256 >= 240).  ATTN_KS: 0 off (a single image is then bit-identical to a batch item), 1 by grid size (default), 2 / 4 forced (tests)
+        if (const int ks = moge_tune_get("ATTN_KS", 1); ks > 1 || (ks == 1 && akern == 3)) {
+            constexpr int smem_ks = 6 * AP_STAGE;
+            const int cus = pp_device_cus(), ntiles = (Ntok + 63) >> 6;
+            const long w2 = (long)((Ntok + 127) / 128) * B * nh, w4 = (long)((Ntok + 255) / 256) * B * nh;
+            const bool fits = ks == 1 && ntiles >= AP_KS_MIN_TILES;
+            if ((ks == 2 && ntiles >= 2) || (fits && w2 <= cus)) {
+                if (int rc = set_dyn_lds<attn_pp16ks_kernel<2>>(smem_ks)) return rc;
+                hipLaunchKernelGGL(attn_pp16ks_kernel<2>, dim3((Ntok + 127) / 128, B * nh), dim3(512), smem_ks, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr);
+                return (int)hipGetLastError();
+            }
+            if ((ks == 4 && ntiles >= 2) || (fits && w4 <= cus)) {
+                if (int rc = set_dyn_lds<attn_pp16ks_kernel<4>>(smem_ks)) return rc;
+                hipLaunchKernelGGL(attn_pp16ks_kernel<4>, dim3((Ntok + 255) / 256, B * nh), dim3(512), smem_ks, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr);
+                return (int)hipGetLastError();
+            }
+        }
         if (q4) {
             if (int rc = set_dyn_lds<attn_pp16mq_kernel<4>>(smem)) return rc;
             hipLaunchKernelGGL(attn_pp16mq_kernel<4>, dim3((Ntok + 255) / 256, B * nh), dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr, 0);

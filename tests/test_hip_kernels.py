@@ -159,6 +159,39 @@ def test_attention_stream_k(H, B, nh, N, wgs, qb):
     assert torch.equal(a, b) and torch.equal(a, c)
 
 
+@pytest.mark.parametrize("ks", [1, 2, 4])
+@pytest.mark.parametrize("B,nh,N", [(1, 16, 3601),           # one image of the bench: 240 blocks of 256 queries, 29 + 28 key tiles (the dispatch's own choice with ks = 1)
+                                    (1, 12, 3601), (1, 6, 1370), (1, 16, 1370), (1, 2, 3601), (2, 3, 130), (1, 2, 300), (1, 2, 513), (1, 3, 65), (1, 1, 128),
+                                    (3, 1, 129), (1, 8, 700), (2, 2, 897)])
+def test_attention_key_split_inside_the_workgroup(H, B, nh, N, ks):
+    """attn_pp16ks_kernel<QB> (round 6, batch-1 latency): 8-wave workgroups, waves 0-3 run attn_pp16mq's body over the first half of the key tiles, waves 4-7 over
+    the rest, combined through LDS in a fixed order.  Forced (ATTN_KS = 2 / 4: 32 / 64 queries per wave) on every split - even / odd tile counts (the second group's
+    extra barrier), two tiles (each half one tile, the second one the masked last tile), query-less waves in both groups, 17-query tails - and through the dispatch's
+    own choice (ATTN_KS = 1), with late dominant keys that trip the overflow guard in either half.  Against SDPA at the fp16 tolerance, against the unsplit kernel
+    within a few fp16 ulps of the output scale (the same fp32 terms in another order), and run to run bit for bit (no atomics, fixed combine order)."""
+    from moge_amd import _lib as L
+    g = torch.Generator().manual_seed(N + 7 * ks)
+    q, k, v = (torch.randn(B, nh, N, 64, generator=g) for _ in range(3))
+    q = q * 1.5
+    v[:, :, N // 2] += 5.0
+    if N > 80:
+        k[:, :, N // 4 + 3] = q[:, :, 5] * 6.0              # first half of the keys
+        k[:, 0, N - 2] = q[:, 0, min(70, N - 1)] * 5.0      # second half, the masked last tile
+        k[:, :, (3 * N) // 4] = q[:, :, N - 1] * 6.0        # second half, seen by the last query (a tail wave)
+    ref = F.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda()).permute(0, 2, 1, 3).reshape(B, N, nh * 64)
+    try:
+        L.tune("ATTN_KS", 0)
+        plain = H.attention(1, q, k, v)
+        L.tune("ATTN_KS", ks)
+        a = H.attention(1, q, k, v)
+        b = H.attention(1, q, k, v)
+    finally:
+        L.tune("ATTN_KS", 1)
+    assert relmax(a, ref) < 1e-2
+    assert relmax(a, plain) < 2e-3
+    assert torch.equal(a, b)
+
+
 def test_attention_online_softmax_rescale(H):
     """rule 26: force the running-max rescale branch - one key in a LATE tile dominates one query."""
     g = torch.Generator().manual_seed(7)

@@ -73,12 +73,14 @@ def test_batches_above_32_equal_their_single_image_results(MoGeModel, tmp_path_f
         L.tune("BATCH_SPLIT", 2)
         for k in ("points", "depth"):
             assert batch[k].shape[0] == B
+        L.tune("ATTN_KS", 0)         # the batch-invariant form of the one-image attention (the default splits a single image's key range inside the workgroup: within the band, tests/test_hip_parity.py)
         for i in (0, B // 2 - 1, B // 2, B - 1):
             single = model.infer(x[i])
             for k in single:
                 _same(batch[k][i], single[k], f"{k}: item {i} of the batch of {B} differs from its single-image result")
     finally:
         L.tune("BATCH_SPLIT", 2)
+        L.tune("ATTN_KS", 1)
         model.float()
         torch.cuda.empty_cache()
 

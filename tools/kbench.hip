@@ -429,7 +429,7 @@ static int bench_attn(const char* filter, int iters) {
         ref_attn<<<ns, 256, 0, st>>>(q, k, v, dbh, dq, c.Ntok, ref);
         CK(hipStreamSynchronize(st));
         // exp: ATTN_EXP (32x32x16 kernels), var: ATTN_VAR bits of attn_pp16_kernel - both need a library built with --experiments
-        struct Var { const char* name; int kind, exp, var; int kern = 0; int sk = 0; };      // sk: 2 / 4 = attn_pp16sk_kernel<QB> (stream-K partition, round 6) forced
+        struct Var { const char* name; int kind, exp, var; int kern = 0; int sk = 0; int ks = 0; };      // ks: 2 / 4 = attn_pp16ks_kernel<QB> (key range split inside an 8-wave workgroup, round 6) forced; 1 = by grid size (the product dispatch)      // sk: 2 / 4 = attn_pp16sk_kernel<QB> (stream-K partition, round 6) forced
         // kern 4 = attn_pp16x_kernel (ping-pong wave groups) [+ attn_pp16mq on the queries beyond the last full 512-block]; 5 = the same with s_setprio 1 in the M phase
         std::vector<Var> vars = {{"pp16", 1, 0, 0, 0}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}};
         // kern 6 / 7 = attn_pp16s_kernel (software-pipelined; one / two workgroups per CU) [+ attn_pp16mq<4> on the queries beyond the last full 256-block]
@@ -438,6 +438,8 @@ static int bench_attn(const char* filter, int iters) {
         if (getenv("KB_X")) vars = {{"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"mq<4>", 1, 0, 0, 2}, {"x", 1, 0, 0, 4}, {"x+prio", 1, 0, 0, 5}};
 #endif
         if (getenv("KB_SK")) vars = {{"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"sk<2>", 1, 0, 0, 3, 2}, {"sk<4>", 1, 0, 0, 3, 4}, {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"sk<2>", 1, 0, 0, 3, 2}, {"sk<4>", 1, 0, 0, 3, 4}};
+        if (getenv("KB_KS")) vars = {{"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"ks<2>", 1, 0, 0, 3, 0, 2}, {"ks<4>", 1, 0, 0, 3, 0, 4}, {"dispatch", 1, 0, 0, 3, 0, 1},
+                                     {"mq<2>", 1, 0, 0, 1}, {"mq<4>", 1, 0, 0, 2}, {"ks<2>", 1, 0, 0, 3, 0, 2}, {"ks<4>", 1, 0, 0, 3, 0, 4}, {"dispatch", 1, 0, 0, 3, 0, 1}};
         void* sk_ws = nullptr; size_t sk_ws_bytes = 0;
         f16* out_q2 = nullptr;                       // mq<2> result: mq<4> must reproduce it bit for bit (per-block guard decisions; spiked keys above force them)
         CK(hipMalloc(&out_q2, n * 2));
@@ -451,6 +453,7 @@ static int bench_attn(const char* filter, int iters) {
             moge_tune_set("ATTN_KERN", va.kern == 5 ? 4 : va.kern);
             moge_tune_set("ATTN_X_PRIO", va.kern == 5 ? 1 : 0);
             moge_tune_set("ATTN_SK", va.sk ? 2 : 0); moge_tune_set("ATTN_SK_QB", va.sk ? va.sk : 2);
+            moge_tune_set("ATTN_KS", va.ks);
             if (getenv("KB_SK_WGS")) moge_tune_set("ATTN_SK_WGS", atoi(getenv("KB_SK_WGS")));
             if (va.sk) {
                 const size_t need = attention_pp_ws_bytes(c.B, c.nh, c.Ntok);
@@ -475,7 +478,7 @@ static int bench_attn(const char* filter, int iters) {
             const double tf = 4.0 * BH * (double)c.Ntok * c.Ntok * 64 / (ms * 1e-3) / 1e12;
             int hdiff = -1;
             if (va.kern == 1) CK(hipMemcpyAsync(out_q2, out, n * 2, hipMemcpyDeviceToDevice, st));
-            if (va.kern >= 2 && !va.sk) {
+            if (va.kern >= 2 && !va.sk && !va.ks) {
                 CK(hipMemsetAsync(dbad, 0, 4, st));
                 cmp_bits<<<2048, 256, 0, st>>>(out, out_q2, n, dbad);
                 CK(hipMemcpyAsync(&hdiff, dbad, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
