@@ -372,10 +372,14 @@ __global__ __launch_bounds__(256, 3) void attn_pp16_kernel(const f16* __restrict
 // The body for one workgroup: head `bh`, queries from `q_base` (this workgroup covers 64 * QB of them; wave w owns 16 * QB from q_base + 16 * QB * w).
 // SK (attn_pp16sk_kernel, below): the body runs the key tiles [tb_in, te_in) only and leaves its unnormalised state (O, l relative to the running
 // max m) in *acc instead of storing the output; returns false for a wave without queries.  SK = false: all tiles, output stored (the code of rounds 2-5).
+// seed_k (SK, attn_pp16ks_kernel's second wave group): LDS address of the sequence's FIRST K tile (the first group's ring, complete behind the first barrier).  The range then
+// starts from the running max the unsplit kernel carries out of tile 0 - the same K Q^T MFMAs, the same reduction - and runs its own first tile in the hot loop's form, so its
+// P operands are the unsplit kernel's bit for bit (until a guard trip raises m in one range and not in the other) and the two forms differ by fp32 summation order only.
 template <int QB> struct AttnAcc { f32x4 o[4][QB]; float m[QB], l[QB]; };
 template <int QB, bool SK = false>
 __device__ __forceinline__ bool attn_pp16mq_body(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v, f16* __restrict__ out,
-                                                 int Ntok, int nh, int bh, int q_base, char* smem, int tb_in = 0, int te_in = 0, AttnAcc<QB>* acc = nullptr) {
+                                                 int Ntok, int nh, int bh, int q_base, char* smem, int tb_in = 0, int te_in = 0, AttnAcc<QB>* acc = nullptr,
+                                                 const char* seed_k = nullptr) {
     constexpr int NW = 4, NPW = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & (NW - 1);      // (attn_pp16ks_kernel: eight waves = two groups of four, each on its own ring and key range)
@@ -550,17 +554,43 @@ __device__ __forceinline__ bool attn_pp16mq_body(const f16* __restrict__ q, cons
         for (int tt = tb; tt < te; tt++) tile_head(tt);
         return false;
     }
-    tile_head(tb);
+    bool seeded = false;
+    if constexpr (SK) seeded = seed_k != nullptr && tb < ntiles - 1;      // (a range that is only the masked last tile keeps the exact path, from the seeded max)
+    tile_head(tb, !seeded);
+    if constexpr (SK) if (seed_k) {
 #pragma unroll
-    for (int qb = 0; qb < QB; qb++) exact_block(tb, tb == ntiles - 1, qb);
+        for (int qb = 0; qb < QB; qb++) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++) {
+                const int koff = (32 * (kb >> 1) + 4 * (kb & 1)) * 128;
+                const u32x4 kf0 = *reinterpret_cast<const u32x4*>(seed_k + kaddr[0] + koff), kf1 = *reinterpret_cast<const u32x4*>(seed_k + kaddr[1] + koff);
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+                mma16<f16>(s0, kf0, qf[qb][0]);
+                mma16<f16>(s0, kf1, qf[qb][1]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) mx = fmaxf(mx, s0[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            m_run[qb] = mx;
+#pragma unroll
+            for (int r = 0; r < 4; r++) negs[qb][r] = -mx;
+        }
+    }
     int t = tb + 1;
+    if (seeded) t = tb;                              // the first tile in the hot loop's form, against the seeded max (its barrier is done)
+    else {
+#pragma unroll
+        for (int qb = 0; qb < QB; qb++) exact_block(tb, tb == ntiles - 1, qb);
+    }
     const int hot_end = SK ? (te < ntiles - 1 ? te : ntiles - 1) : ntiles - 1;      // (the sequence's last tile is masked: exact path)
     u32x4 pf[QB][2];                             // [query block][32-key step]: the tile's P^T operands
     f32x4 lt[QB];                                // this tile's row sums (every register / lane of a query holds the same number)
     for (;;) {
         bool hit = false;
         for (; t < hot_end; t++) {                   // ---- hot loop ----
-            tile_head(t, false);
+            if (!(seeded && t == tb)) tile_head(t, false);
             u32x4 kf[4][2];
 #pragma unroll
             for (int kb = 0; kb < 4; kb++) {
@@ -693,7 +723,7 @@ __global__ __launch_bounds__(256, QB > 2 ? 2 : 3) void attn_pp16mq_kernel(const 
 constexpr int AP_KS_MIN_TILES = 8;
 template <int QB>
 __global__ __launch_bounds__(512, 1) void attn_pp16ks_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
-                                                            f16* __restrict__ out, int Ntok, int nh, int xcd_remap) {
+                                                            f16* __restrict__ out, int Ntok, int nh, int xcd_remap, int tmid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 rings of 3 * AP_STAGE; afterwards the exchange buffer (QB * 18 KiB)
     int bh = blockIdx.y, qblk = blockIdx.x;
     if (((gridDim.y & 7) == 0) && (xcd_remap & 1)) {                 // a head's query blocks on ONE XCD (see attn_pp16mq_kernel)
@@ -706,10 +736,11 @@ __global__ __launch_bounds__(512, 1) void attn_pp16ks_kernel(const f16* __restri
     const int q_base = qblk * (64 * QB);
     const int tid = threadIdx.x, lane = tid & 63, t4 = tid & 255;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave8 >> 2, wave = wave8 & 3;
-    const int ntiles = (Ntok + 63) >> 6, tmid = (ntiles + 1) >> 1;
+    const int ntiles = (Ntok + 63) >> 6;                             // tmid (host): the first group's tile count, ceil(ntiles / 2) unless a test moves it (1 <= tmid < ntiles)
     AttnAcc<QB> a;
-    const bool active = attn_pp16mq_body<QB, true>(q, k, v, out, Ntok, nh, bh, q_base, smem + grp * (3 * AP_STAGE), grp ? tmid : 0, grp ? ntiles : tmid, &a);
-    if (grp && (ntiles & 1)) __builtin_amdgcn_s_barrier();           // one barrier per tile in the body: the second group has one tile fewer when ntiles is odd
+    const bool active = attn_pp16mq_body<QB, true>(q, k, v, out, Ntok, nh, bh, q_base, smem + grp * (3 * AP_STAGE), grp ? tmid : 0, grp ? ntiles : tmid, &a, grp ? smem : nullptr);
+    // one barrier per tile in the body: the group with fewer tiles makes up the difference (the second one by one tile when ntiles is odd)
+    for (int i = grp ? ntiles - tmid : tmid, n = max(tmid, ntiles - tmid); i < n; i++) __builtin_amdgcn_s_barrier();
     __syncthreads();                                                 // every wave is done with both rings
     f32x4* ex_o = reinterpret_cast<f32x4*>(smem);                    // [db * QB + qb][lane of the group] fragment-linear: conflict-free 16-byte accesses
     f32x2* ex_ml = reinterpret_cast<f32x2*>(smem + (size_t)4 * QB * 256 * 16);
@@ -864,14 +895,16 @@ static int launch_attn_pp16(const void* q, const void* k, const void* v, void* o
             const int cus = pp_device_cus(), ntiles = (Ntok + 63) >> 6;
             const long w2 = (long)((Ntok + 127) / 128) * B * nh, w4 = (long)((Ntok + 255) / 256) * B * nh;
             const bool fits = ks == 1 && ntiles >= AP_KS_MIN_TILES;
+            int tmid = (ntiles + 1) >> 1;
+            if (const int f = moge_tune_get("ATTN_KS_MID", 0); f > 0 && f < ntiles) tmid = f;       // tests / tools: any split point
             if ((ks == 2 && ntiles >= 2) || (fits && w2 <= cus)) {
                 if (int rc = set_dyn_lds<attn_pp16ks_kernel<2>>(smem_ks)) return rc;
-                hipLaunchKernelGGL(attn_pp16ks_kernel<2>, dim3((Ntok + 127) / 128, B * nh), dim3(512), smem_ks, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr);
+                hipLaunchKernelGGL(attn_pp16ks_kernel<2>, dim3((Ntok + 127) / 128, B * nh), dim3(512), smem_ks, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr, tmid);
                 return (int)hipGetLastError();
             }
             if ((ks == 4 && ntiles >= 2) || (fits && w4 <= cus)) {
                 if (int rc = set_dyn_lds<attn_pp16ks_kernel<4>>(smem_ks)) return rc;
-                hipLaunchKernelGGL(attn_pp16ks_kernel<4>, dim3((Ntok + 255) / 256, B * nh), dim3(512), smem_ks, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr);
+                hipLaunchKernelGGL(attn_pp16ks_kernel<4>, dim3((Ntok + 255) / 256, B * nh), dim3(512), smem_ks, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, Ntok, nh, xr, tmid);
                 return (int)hipGetLastError();
             }
         }

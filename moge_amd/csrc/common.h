@@ -210,8 +210,9 @@ struct GemmArgs {
     // EPI_RESID: x[m*ldc+n] += gamma[n]*(acc+bias[n])   (fp32 residual stream)
     float* xres;
     const float* gamma;
-    // EPI_PATCH: xres[(b*Ntok+1+p)*N + n] = acc + bias[n] + pos[(1+p)*N + n]
+    // EPI_PATCH: xres[(b*Ntok+1+p)*N + n] = acc + bias[n] + pos[(1+p)*N + n]; with cls: the rows of patch 0 also write the image's cls row xres[b*Ntok*N + n] = cls[n] + pos[n]
     const float* pos;
+    const float* cls;
     int Np, Ntok;
     // EPI_QKV: scatter to q,k (B,nh,Ntok,64) and vT (B,nh,64,Npad); q pre-scaled by qscale
     void* q; void* k; void* vT;

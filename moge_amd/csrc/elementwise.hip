@@ -22,21 +22,31 @@ __device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1
 
 template <typename TIn, typename TOut>
 __global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict__ out, int B, int H, int W, int rows, int cols,
-                                  int ldk, int nchw_out, int round16, int aa, float m0, float m1, float m2, float s0, float s1, float s2) {
+                                  int ldk, int nchw_out, int round16, int aa, float m0, float m1, float m2, float s0, float s1, float s2,
+                                  int* __restrict__ zero_i32, int zero_n) {
     // aa == 0: onnx_compatible_mode (modules.py:121 antialias=False): ATen upsample_bilinear2d, align_corners=False - two taps per axis at
     // src = scale * (dst + 0.5) - 0.5 clamped at 0, i1 = min(i0 + 1, in - 1), whatever the scale
     // round16: fp32 input whose values are first rounded to fp16 - the reference's `image.to(dtype=self.dtype)` for a .half() model
     // (v2.py:229) - done here on load instead of as a separate cast pass over the image
     // one thread per output PIXEL: the filter ranges and weight sums depend on (oy, ox) only and serve the three channels
     // (per-channel arithmetic and its order are unchanged: horizontal pass first, then vertical, fp32)
+    // Round 6 (one image: every launch in front of the first block is ~4-5 us of dispatch): the im2col matrix's K padding columns [588, ldk) are zeroed HERE - the
+    // pixel (iy, ix) of a patch zeroes padding column iy * 14 + ix of its row (ldk - 588 <= 196) - instead of by zero_cols_kernel, and so are the forward's
+    // device-side counters (zero_i32[0 .. zero_n): the fused LN finalize's row-block counters) instead of by a hipMemsetAsync (two fill kernels).
     const int OH = rows * 14, OW = cols * 14;
     const long total = (long)B * OH * OW;
     const float scale_y = (float)H / (float)OH, scale_x = (float)W / (float)OW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < zero_n; i += (long)gridDim.x * blockDim.x) zero_i32[i] = 0;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int ox = idx % OW;
         long t = idx / OW;
         const int oy = t % OH;
         const int b = t / OH;
+        if (!nchw_out) {
+            const int py = oy / 14, px = ox / 14;
+            const int j = 588 + (oy - py * 14) * 14 + (ox - px * 14);
+            if (j < ldk) out[((size_t)b * rows * cols + (size_t)py * cols + px) * ldk + j] = (TOut)0.f;
+        }
         if (!aa) {
             float sy = scale_y * ((float)oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
             float sx = scale_x * ((float)ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
@@ -92,18 +102,19 @@ __global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict_
 
 template <typename TIn, typename TOut>
 int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out, int round16, int aa,
-                      const float* mean, const float* std_, hipStream_t st) {
+                      const float* mean, const float* std_, hipStream_t st, int* zero_i32, int zero_n) {
+    if (!nchw_out && (ldk < 588 || ldk - 588 > 196)) return -1;         // (the padding columns are zeroed by the patch's own 196 pixels)
     const long total = (long)B * rows * 14 * cols * 14;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL((preprocess_kernel<TIn, TOut>), dim3(blocks), dim3(256), 0, st, (const TIn*)img, (TOut*)out, B, H, W, rows, cols,
-                       ldk, nchw_out, round16, aa, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2]);
+                       ldk, nchw_out, round16, aa, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], zero_i32, zero_i32 ? zero_n : 0);
     return (int)hipGetLastError();
 }
-template int launch_preprocess<float, f16>(const void*, void*, int, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
-template int launch_preprocess<float, float>(const void*, void*, int, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
-template int launch_preprocess<f16, f16>(const void*, void*, int, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
-template int launch_preprocess<f16, float>(const void*, void*, int, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+template int launch_preprocess<float, f16>(const void*, void*, int, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t, int*, int);
+template int launch_preprocess<float, float>(const void*, void*, int, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t, int*, int);
+template int launch_preprocess<f16, f16>(const void*, void*, int, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t, int*, int);
+template int launch_preprocess<f16, float>(const void*, void*, int, int, int, int, int, int, int, int, int, const float*, const float*, hipStream_t, int*, int);
 
 // Caller-side ingest (scripts/infer.py:98: `torch.tensor(image / 255, dtype=torch.float32).permute(2, 0, 1)`, then v2.py:229 casts to the model
 // dtype): uint8 (B,H,W,3) -> T (B,3,H,W).  numpy divides in float64 and the tensor constructor rounds to float32 once: same here.
@@ -128,27 +139,7 @@ int launch_u8hwc_to_chw(const void* in, void* out, int B, int H, int W, hipStrea
 template int launch_u8hwc_to_chw<f16>(const void*, void*, int, int, int, hipStream_t);
 template int launch_u8hwc_to_chw<float>(const void*, void*, int, int, int, hipStream_t);
 
-// zero the K padding columns [kfrom, ldk) of the im2col matrix (written once per forward)
-template <typename T>
-__global__ void zero_cols_kernel(T* a, long rowsN, int ldk, int kfrom) {
-    const int w = ldk - kfrom;
-    const long total = rowsN * w;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / w;
-        a[r * ldk + kfrom + (i - r * w)] = (T)0.f;
-    }
-}
-template <typename T>
-int launch_zero_cols(void* a, long rowsN, int ldk, int kfrom, hipStream_t st) {
-    if (kfrom >= ldk) return 0;
-    long total = rowsN * (ldk - kfrom);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(zero_cols_kernel<T>, dim3(blocks), dim3(256), 0, st, (T*)a, rowsN, ldk, kfrom);
-    return (int)hipGetLastError();
-}
-template int launch_zero_cols<f16>(void*, long, int, int, hipStream_t);
-template int launch_zero_cols<float>(void*, long, int, int, hipStream_t);
+// (The K padding columns [588, ldk) of the im2col matrix are zeroed by preprocess_kernel itself since round 6.)
 
 // --------------------------------------------------------------------------------------------
 // Position embedding for an (rows x cols) grid: bicubic (A=-0.75, align_corners=False, no antialias) resample of the
@@ -212,16 +203,7 @@ int launch_posembed(const float* pos, float* out, int D, int rows, int cols, int
 }
 
 // x[b, 0, :] = cls_token + pos[0]   (vision_transformer.py:230-231)
-__global__ void cls_row_kernel(float* x, const float* cls, const float* pos, int B, int Ntok, int D) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * D) return;
-    const int b = i / D, d = i - b * D;
-    x[(size_t)b * Ntok * D + d] = cls[d] + pos[d];
-}
-int launch_cls_row(float* x, const float* cls, const float* pos, int B, int Ntok, int D, hipStream_t st) {
-    hipLaunchKernelGGL(cls_row_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, x, cls, pos, B, Ntok, D);
-    return (int)hipGetLastError();
-}
+// (cls row = cls_token + pos_embed[0]: written by the patch-embed GEMM's EPI_PATCH epilogue since round 6, gemm.hip.)
 
 // --------------------------------------------------------------------------------------------
 // LayerNorm (eps 1e-6, vision_transformer.py:95): one wave per row of the fp32 residual stream, two-pass in

@@ -93,6 +93,10 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, float
         const f32x4 pe = *reinterpret_cast<const f32x4*>(g.pos + (size_t)(1 + p) * g.N + n);
         f32x4 o = {v[0] + pe[0], v[1] + pe[1], v[2] + pe[2], v[3] + pe[3]};
         *reinterpret_cast<f32x4*>(g.xres + ((size_t)b * g.Ntok + 1 + p) * g.N + n) = o;
+        if (p == 0 && g.cls) {            // the image's cls row (vision_transformer.py:228-231: cls_token + pos_embed[0]); cls_row_kernel's arithmetic, one launch fewer
+            const f32x4 c = *reinterpret_cast<const f32x4*>(g.cls + n), p0 = *reinterpret_cast<const f32x4*>(g.pos + n);
+            *reinterpret_cast<f32x4*>(g.xres + (size_t)b * g.Ntok * g.N + n) = f32x4{c[0] + p0[0], c[1] + p0[1], c[2] + p0[2], c[3] + p0[3]};
+        }
         break;
     }
     case EPI_QKV: {

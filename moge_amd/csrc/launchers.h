@@ -11,8 +11,7 @@ size_t attention_pp_ws_counter_bytes(int B, int nh, int Ntok);    // ... of whic
 
 template <typename TIn, typename TOut>
 int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out, int round16, int aa, const float* mean,
-                      const float* std_, hipStream_t st);
-template <typename T> int launch_zero_cols(void* a, long rowsN, int ldk, int kfrom, hipStream_t st);
+                      const float* std_, hipStream_t st, int* zero_i32 = nullptr, int zero_n = 0);      // patch layout: also zeroes the K padding columns [588, ldk) and zero_i32[0 .. zero_n)
 // LN fold (fp16 path): fp16 copy + (mean, rstd) of the first block's input; partial sums -> (mean, rstd); weight folding at pack time
 template <typename T> int launch_ln_raw(const float* x, void* out, float* mr, long rowsN, int D, hipStream_t st);
 int launch_ln_finalize(const float* part, float* mr, long rowsN, int NP, int D, hipStream_t st);
@@ -20,7 +19,6 @@ template <typename T> int launch_fold_ln(const float* W, const float* g, const f
 template <typename T> int launch_u8hwc_to_chw(const void* in, void* out, int B, int H, int W, hipStream_t st);      // uint8 (B,H,W,3) -> T (B,3,H,W), /255
 int launch_depth_edge_mask(const float* depth, const unsigned char* mask, unsigned char* out, int B, int H, int W, float rtol, hipStream_t st);
 int launch_posembed(const float* pos, float* out, int D, int rows, int cols, int size_mode, hipStream_t st);
-int launch_cls_row(float* x, const float* cls, const float* pos, int B, int Ntok, int D, hipStream_t st);
 template <typename T>
 int launch_layernorm(const float* x, const float* w, const float* b, void* out, float* cls_out, long rowsN, int D, int ldo, int coloff,
                      int tap_mode, int Ntok, hipStream_t st);

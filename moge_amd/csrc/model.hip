@@ -1045,29 +1045,35 @@ static int encode(moge_handle* h, const void* image, int img_dtype, int imgH, in
     const float* mean = h->img_mean; const float* sd = h->img_std;
     {
         ProfScope ps(h, st, MOGE_KC_PRE, 0, (double)B * 3 * imgH * imgW * (img_dtype == 1 ? 2 : 4) + (double)BP * KPATCH_PAD * sizeof(T));
-        LCHK(launch_zero_cols<T>(patches, BP, KPATCH_PAD, KPATCH, st));
+        // Round 6 (one image): preprocess_kernel also zeroes the K padding columns of `patches` (zero_cols_kernel before) and the forward's device-side
+        // counters (a hipMemsetAsync = two fill kernels before), and the patch-embed epilogue writes the cls rows (cls_row_kernel before): four launches
+        // fewer in front of the first block, the same bits.  (--experiments builds with the stream-K attention workspace: its counters sit behind the LN
+        // counters, one range.)
+        const bool attn_pp0 = std::is_same<T, f16>::value && moge_tune_get("ATTN_PP", 1) != 0;
+        const bool has_attn_ws = attn_pp0 && pl.attn_ws_bytes;
+        int* zero_p = pl.ln_cnt_bytes ? (int*)(ws + pl.ln_cnt) : (has_attn_ws ? (int*)(ws + pl.attn_ws) : nullptr);
+        const size_t zero_bytes = pl.ln_cnt_bytes ? (has_attn_ws ? (pl.attn_ws - pl.ln_cnt) + attention_pp_ws_counter_bytes(B, nh, Ntok) : pl.ln_cnt_bytes)
+                                                  : (has_attn_ws ? attention_pp_ws_counter_bytes(B, nh, Ntok) : 0);
         // img_dtype 3 = fp32 values to be rounded to fp16 on load (the model-dtype cast of a .half() model, v2.py:229)
-        if (img_dtype == 0 || img_dtype == 3) LCHK((launch_preprocess<float, T>(image, patches, B, imgH, imgW, rows, cols, KPATCH_PAD, 0, img_dtype == 3, !h->onnx_mode, mean, sd, st)));
-        else LCHK((launch_preprocess<f16, T>(image, patches, B, imgH, imgW, rows, cols, KPATCH_PAD, 0, 0, !h->onnx_mode, mean, sd, st)));
+        if (img_dtype == 0 || img_dtype == 3) LCHK((launch_preprocess<float, T>(image, patches, B, imgH, imgW, rows, cols, KPATCH_PAD, 0, img_dtype == 3, !h->onnx_mode, mean, sd, st, zero_p, (int)((zero_bytes + 3) / 4))));
+        else LCHK((launch_preprocess<f16, T>(image, patches, B, imgH, imgW, rows, cols, KPATCH_PAD, 0, 0, !h->onnx_mode, mean, sd, st, zero_p, (int)((zero_bytes + 3) / 4))));
     }
     const float* pos;
     CHK(get_pos(h, rows, cols, st, &pos));
-    LCHK(launch_cls_row(x, M(h, bb + "cls_token"), pos, B, Ntok, D, st));
-    {   // patch embed GEMM, epilogue adds bias + position embedding and writes the fp32 residual stream
+    {   // patch embed GEMM, epilogue adds bias + position embedding and writes the fp32 residual stream (and the cls row of every image)
         GemmArgs g = gemm_args();
         g.a = patches; g.lda = KPATCH_PAD; g.w = P<T>(h, "patch.w"); g.ldw = KPATCH_PAD;
         g.M = (int)BP; g.N = D; g.K = KPATCH_PAD;
         g.epi = EPI_PATCH; g.bias = M(h, bb + "patch_embed.proj.bias"); g.xres = x; g.pos = pos; g.Np = Np; g.Ntok = Ntok;
+        g.cls = M(h, bb + "cls_token");
         CHK(run_gemm<T>(h, g, AMODE_LINEAR, MOGE_KC_GEMM, st, KPATCH));
     }
     // fp16 throughput path: V row-major + attention_pp (LDS-DMA, transposed LDS reads); fp32 parity path: V^T + attention.hip
     const bool attn_pp = std::is_same<T, f16>::value && moge_tune_get("ATTN_PP", 1) != 0;
     if (!attn_pp) HIPCHK(hipMemsetAsync(vT, 0, (size_t)B * D * Npad * sizeof(T), st));      // zero the key padding of V^T
-    // stream-K attention (one image: 464 workgroups on 768 slots): its per-query-block counters start at zero; the kernel leaves them zero
+    // stream-K attention (--experiments builds; one image: 464 workgroups on 768 slots): its per-query-block counters start at zero (preprocess_kernel above); the kernel leaves them zero
     void* attn_ws = attn_pp && pl.attn_ws_bytes ? (void*)(ws + pl.attn_ws) : nullptr;
-    int* ln_cnt = pl.ln_cnt_bytes ? (int*)(ws + pl.ln_cnt) : nullptr;       // fused LN finalize (latency-regime GEMMs): row-block counters
-    if (ln_cnt) HIPCHK(hipMemsetAsync(ln_cnt, 0, attn_ws ? (pl.attn_ws - pl.ln_cnt) + attention_pp_ws_counter_bytes(B, nh, Ntok) : pl.ln_cnt_bytes, st));      // (adjacent regions: one memset)
-    else if (attn_ws) HIPCHK(hipMemsetAsync(attn_ws, 0, attention_pp_ws_counter_bytes(B, nh, Ntok), st));
+    int* ln_cnt = pl.ln_cnt_bytes ? (int*)(ws + pl.ln_cnt) : nullptr;       // fused LN finalize (latency-regime GEMMs): row-block counters, zeroed by preprocess_kernel
 
     // ---- ViT blocks (block.py:110-112) -----------------------------------------------------------------------------
     // LN fold (fp16 path): norm1 / norm2 never run as kernels.  LN(x) W^T + b = rstd (x W'^T - mean c) + b' with W' = g (.) W: the qkv and

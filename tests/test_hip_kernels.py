@@ -190,6 +190,19 @@ def test_attention_key_split_inside_the_workgroup(H, B, nh, N, ks):
     assert relmax(a, ref) < 1e-2
     assert relmax(a, plain) < 2e-3
     assert torch.equal(a, b)
+    # the second group starts from the running max the unsplit kernel carries out of tile 0, so its P operands are the unsplit kernel's: without dominant late keys
+    # (no overflow guard trips that raise the max in one key range and not in the other) the two forms differ by fp32 summation order only - a handful of last-bit
+    # differences after the fp16 rounding (observed 0.03-0.15 % of the values, rms 1e-6)
+    q2, k2, v2 = (torch.randn(B, nh, N, 64, generator=g) for _ in range(3))
+    try:
+        L.tune("ATTN_KS", 0)
+        plain2 = H.attention(1, q2, k2, v2)
+        L.tune("ATTN_KS", ks)
+        a2 = H.attention(1, q2, k2, v2)
+    finally:
+        L.tune("ATTN_KS", 1)
+    assert (a2 != plain2).float().mean().item() < 5e-3
+    assert relmax(a2, plain2) < 1e-3
 
 
 def test_attention_online_softmax_rescale(H):
