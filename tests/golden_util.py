@@ -22,6 +22,11 @@ def load_case(name):
     sd = case_state_dict(case, cfg)
     x = make_input(case)
     gold = {k: z[k] for k in z.files if k != "meta"}
+    # Re-draws of the reference's own fp16 drift (oracle/reference_redraws.py; only fixtures whose focal / shift solve is ill-conditioned carry them): see fp16_band
+    rd = os.path.join(GOLDEN_DIR, name + ".redraws.json")
+    if os.path.exists(rd):
+        with open(rd) as f:
+            meta["redraws16"] = json.load(f)["draws"]
     return case, cfg, sd, x, gold, meta
 
 
@@ -120,6 +125,16 @@ def fp16_band(meta: dict, gold: dict = None, form: str = "autocast") -> dict:
     if gold is not None:
         for k, v in reference_drift16(gold, prefix).items():
             drift[k] = max(drift.get(k, 0.0), v)
+    # A fixture whose focal / shift solve is ill-conditioned (v1_vitl_518: the reference's fp32 focal moves by 1e-3 when 1 % of the input pixels move by one fp16 ulp) has no
+    # stable single-draw drift: the focal is one number per image, points and depth inherit the recovered shift, and ANY last-bit change of the arithmetic - the
+    # reference's as much as the library's - re-draws all of them (the reference's .half() focal drift over 16 such re-draws: 1e-5 ... 2.6e-3; the library's over 10 of
+    # its own: 2e-4 ... 3.9e-3, profiles/r06al_ks_split_draws.log).  Such fixtures carry the reference's re-draws (oracle/reference_redraws.py ->
+    # tests/golden/<name>.redraws.json) and the reference's drift is the WIDEST of them, per output; the network in front of the solve is gated separately on a stable
+    # statistic (tests/test_hip_v1.py::test_v1_fp16_forward_noise_against_the_reference_redraws).
+    for rec in meta.get("redraws16", []):
+        for k, v in rec.get(form, {}).items():
+            if k in drift:
+                drift[k] = max(drift[k], v)
     for k, own in drift.items():
         band[k] = FP16_FACTOR_BY_KEY.get(k, FP16_FACTOR) * max(own, FP16_FLOOR.get(k, 5e-4))
     # intrinsics are ONE number per image (the focal; a least-squares functional of the point map), so the reference's own drift on a case
