@@ -20,6 +20,7 @@ __device__ __forceinline__ void aa_range(int o, float scale, int in_size, int& l
 }
 __device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
 
+constexpr int PATCH_K = 3 * 14 * 14;       // im2col row of a 14 x 14 RGB patch (model.hip KPATCH); the row pitch ldk pads it to a multiple of 64
 template <typename TIn, typename TOut>
 __global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict__ out, int B, int H, int W, int rows, int cols,
                                   int ldk, int nchw_out, int round16, int aa, float m0, float m1, float m2, float s0, float s1, float s2,
@@ -44,7 +45,7 @@ __global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict_
         const int b = t / OH;
         if (!nchw_out) {
             const int py = oy / 14, px = ox / 14;
-            const int j = 588 + (oy - py * 14) * 14 + (ox - px * 14);
+            const int j = PATCH_K + (oy - py * 14) * 14 + (ox - px * 14);
             if (j < ldk) out[((size_t)b * rows * cols + (size_t)py * cols + px) * ldk + j] = (TOut)0.f;
         }
         if (!aa) {
@@ -103,7 +104,7 @@ __global__ void preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict_
 template <typename TIn, typename TOut>
 int launch_preprocess(const void* img, void* out, int B, int H, int W, int rows, int cols, int ldk, int nchw_out, int round16, int aa,
                       const float* mean, const float* std_, hipStream_t st, int* zero_i32, int zero_n) {
-    if (!nchw_out && (ldk < 588 || ldk - 588 > 196)) return -1;         // (the padding columns are zeroed by the patch's own 196 pixels)
+    if (!nchw_out && (ldk < PATCH_K || ldk - PATCH_K > 196)) return -1;         // (the padding columns are zeroed by the patch's own 196 pixels)
     const long total = (long)B * rows * 14 * cols * 14;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 16384) blocks = 16384;
