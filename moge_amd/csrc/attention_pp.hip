@@ -717,7 +717,9 @@ __global__ __launch_bounds__(256, QB > 2 ? 2 : 3) void attn_pp16mq_kernel(const 
 // (same barriers: the shorter half adds one), so every SIMD holds two waves and the chain is half as long; then the second group leaves its unnormalised state
 // (O, l relative to its running max m) in LDS - the rings are dead by then - and the first group combines in a FIXED order, O = O_0 2^(m_0 - m*) + O_1 2^(m_1 - m*),
 // l likewise, normalises and stores.  No global workspace, no atomics, no second launch (the stream-K form of tools/experiments/ paid 7 us for those);
-// deterministic run to run.  The result differs from the unsplit kernel's in the last fp16 bit (the same fp32 terms summed in another order), so a single
+// deterministic run to run.  The second group does not take its running max from its own first tile: it reads the sequence's first K tile out of ring 0 and starts from the
+// max the unsplit kernel carries out of tile 0 (seed_k in the body), so both groups' P operands are the unsplit kernel's and only the fp32 summation order differs:
+// 0.03-0.15 % of the output values differ from the unsplit kernel's, by one fp16 ulp (profiles/r06al_ks_err.log).  That is still not bit-identity, so a single
 // image is no longer bit-identical to the same image inside a large batch in the fp16 modes (ATTN_KS = 0 restores that; the fp32 parity mode runs attention.hip
 // and is untouched).  Taken by launch_attn_pp16 for grids of at most one workgroup per CU and at least AP_KS_MIN_TILES key tiles.
 constexpr int AP_KS_MIN_TILES = 8;
